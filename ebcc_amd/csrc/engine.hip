@@ -1,0 +1,313 @@
+// engine.hip - context management and the residual-layer C-ABI (include/ebcc_hip.h).
+#include "engine.hpp"
+
+#include <cstdarg>
+#include <cstring>
+
+#include "../../include/ebcc_hip.h"
+
+namespace ebcc {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    std::fprintf(stderr, "ebcc-hip: %s\n", buf);
+}
+
+template <typename T>
+T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count)
+{
+    void *p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->allocs.push_back(p);
+    ctx->bytes += bytes;
+    return static_cast<T *>(p);
+}
+template float *ctx_alloc<float>(ebcc_hip_ctx *, size_t);
+template int32_t *ctx_alloc<int32_t>(ebcc_hip_ctx *, size_t);
+template uint32_t *ctx_alloc<uint32_t>(ebcc_hip_ctx *, size_t);
+template uint16_t *ctx_alloc<uint16_t>(ebcc_hip_ctx *, size_t);
+template uint8_t *ctx_alloc<uint8_t>(ebcc_hip_ctx *, size_t);
+template double *ctx_alloc<double>(ebcc_hip_ctx *, size_t);
+template unsigned long long *ctx_alloc<unsigned long long>(ebcc_hip_ctx *, size_t);
+template FrameState *ctx_alloc<FrameState>(ebcc_hip_ctx *, size_t);
+
+void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n)
+{
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_fs, ctx->rb.fs, n * sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
+    EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+void push_frame_states(ebcc_hip_ctx *ctx, size_t n)
+{
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->rb.fs, ctx->h_fs, n * sizeof(FrameState), hipMemcpyHostToDevice, ctx->stream));
+}
+
+}  // namespace ebcc
+
+using namespace ebcc;
+
+namespace ebcc {
+// j2k.hip
+bool j2k_create(ebcc_hip_ctx *ctx);
+void j2k_destroy(ebcc_hip_ctx *ctx);
+}  // namespace ebcc
+
+extern "C" {
+
+const char *ebcc_hip_last_error(void) { return g_last_error.c_str(); }
+
+int ebcc_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+ebcc_hip_ctx *ebcc_hip_create(int device, size_t max_frames, size_t height, size_t width)
+{
+    if (height < 1 || width < 1 || height > 2047 || width > 2047 || max_frames < 1) {
+        set_error("ebcc_hip_create: unsupported geometry %zu x %zu x %zu", max_frames, height, width);
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("ebcc_hip_create: no HIP device %d (found %d) - the MI355X engine has no CPU fallback", device, ndev);
+        return nullptr;
+    }
+    EBCC_HIP_CHECK(hipSetDevice(device));
+    ebcc_hip_ctx *ctx = new ebcc_hip_ctx();
+    ctx->device = device;
+    ctx->max_frames = max_frames;
+    ctx->height = (int) height;
+    ctx->width = (int) width;
+    ctx->n_pix = height * width;
+    EBCC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+
+    ResidualBuffers &rb = ctx->rb;
+    rb.g = make_grid((int) height, (int) width, kResidualStages);
+    rb.max_frames = (int) max_frames;
+    rb.np = (size_t) rb.g.npix();
+    const size_t tot = rb.np * max_frames;
+    // stream capacity: the reference allocates height*width*4 bytes when trunc_bits == 0 (spiht_re.c:433)
+    rb.stream_words = (ctx->n_pix * 4 + 64) / 4 + 64;
+    bool ok = true;
+    ok &= (rb.A = ctx_alloc<float>(ctx, tot)) != nullptr;
+    ok &= (rb.T = ctx_alloc<float>(ctx, tot)) != nullptr;
+    ok &= (rb.C = ctx_alloc<int32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.D = ctx_alloc<int32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.G = ctx_alloc<int32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.lip = ctx_alloc<uint32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.lsp = ctx_alloc<uint32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.lis0 = ctx_alloc<uint32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.lis1 = ctx_alloc<uint32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.sigord = ctx_alloc<uint32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.lspidx = ctx_alloc<uint32_t>(ctx, tot)) != nullptr;
+    ok &= (rb.stream = ctx_alloc<uint32_t>(ctx, rb.stream_words * max_frames)) != nullptr;
+    ok &= (rb.partial = ctx_alloc<double>(ctx, (size_t) kPartials * max_frames)) != nullptr;
+    ok &= (rb.fs = ctx_alloc<FrameState>(ctx, max_frames)) != nullptr;
+    ok &= (ctx->d_u64a = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
+    ok &= (ctx->d_u64b = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
+    ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
+    ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
+    if (ok) {
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64a, max_frames * sizeof(unsigned long long)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64b, max_frames * sizeof(unsigned long long)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64c, max_frames * sizeof(unsigned long long)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_active, max_frames * sizeof(int)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
+        EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
+        ok = j2k_create(ctx);
+    }
+    if (!ok) {
+        ebcc_hip_destroy(ctx);
+        return nullptr;
+    }
+    EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ctx;
+}
+
+void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    j2k_destroy(ctx);
+    for (void *p : ctx->allocs) hipFree(p);
+    if (ctx->h_u64a) hipHostFree(ctx->h_u64a);
+    if (ctx->h_u64b) hipHostFree(ctx->h_u64b);
+    if (ctx->h_u64c) hipHostFree(ctx->h_u64c);
+    if (ctx->h_active) hipHostFree(ctx->h_active);
+    if (ctx->h_fs) hipHostFree(ctx->h_fs);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *ebcc_hip_stream(ebcc_hip_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+size_t ebcc_hip_workspace_bytes(const ebcc_hip_ctx *ctx) { return ctx ? ctx->bytes : 0; }
+size_t ebcc_hip_padded_pixels(const ebcc_hip_ctx *ctx) { return ctx ? ctx->rb.np : 0; }
+
+void *ebcc_hip_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        set_error("ebcc_hip_malloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void ebcc_hip_free(void *p) { if (p) hipFree(p); }
+int ebcc_hip_memcpy_h2d(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyHostToDevice) != hipSuccess; }
+int ebcc_hip_memcpy_d2h(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) != hipSuccess; }
+
+// ------------------------------------------------------------------------------------------------
+// residual layer
+// ------------------------------------------------------------------------------------------------
+static int check_batch(ebcc_hip_ctx *ctx, size_t n_frames, const char *who)
+{
+    if (!ctx) { set_error("%s: null context", who); return 1; }
+    if (n_frames < 1 || n_frames > ctx->max_frames) {
+        set_error("%s: %zu frames exceeds the context capacity %zu", who, n_frames, ctx->max_frames);
+        return 1;
+    }
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// shared by ebcc_hip_spiht_encode and the frame codec: analysis must already have run
+static void run_spiht_encode(ebcc_hip_ctx *ctx, size_t n, const size_t *trunc_bits)
+{
+    hipStream_t s = ctx->stream;
+    fetch_frame_states(ctx, n);
+    for (size_t f = 0; f < n; f++) {
+        // spiht_re.c:458: bits0 = trunc_bits ? trunc_bits + 128 : 2^28
+        unsigned long long bits0 = trunc_bits[f] == 0 ? (1ull << 28) : (unsigned long long) trunc_bits[f] + 128;
+        ctx->h_u64a[f] = bits0;
+        ctx->h_fs[f].budget = bits0 - 128;
+    }
+    push_frame_states(ctx, n);
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, s);
+}
+
+static int collect_streams(ebcc_hip_ctx *ctx, size_t n, uint8_t **out_streams, size_t *out_sizes)
+{
+    fetch_frame_states(ctx, n);
+    for (size_t f = 0; f < n; f++) {
+        size_t nb = ctx->h_fs[f].stream_bytes;
+        out_sizes[f] = nb;
+        out_streams[f] = (uint8_t *) malloc(nb ? nb : 1);
+        if (!out_streams[f]) { set_error("out of host memory"); return 1; }
+        EBCC_HIP_CHECK(hipMemcpyAsync(out_streams[f], ctx->rb.stream + f * ctx->rb.stream_words, nb,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    }
+    EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ebcc_hip_spiht_encode(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, const size_t *trunc_bits,
+                          uint8_t **out_streams, size_t *out_sizes)
+{
+    if (check_batch(ctx, n_frames, "ebcc_hip_spiht_encode")) return 1;
+    for (size_t f = 0; f < n_frames; f++) {
+        // reference buffer is trunc_bits + 1 bytes (spiht_re.c:433); our device slot holds height*width*4
+        if (trunc_bits[f] != 0 && (trunc_bits[f] + 121 + 7) / 8 > ctx->rb.stream_words * 4 - 64) {
+            set_error("ebcc_hip_spiht_encode: trunc_bits %zu exceeds the stream slot", trunc_bits[f]);
+            return 1;
+        }
+    }
+    hipStream_t s = ctx->stream;
+    launch_pad_and_dc_from_image(d_images, ctx->rb, (int) n_frames, s);
+    launch_analysis(ctx->rb, (int) n_frames, s);
+    run_spiht_encode(ctx, n_frames, trunc_bits);
+    return collect_streams(ctx, n_frames, out_streams, out_sizes);
+}
+
+int ebcc_hip_spiht_coeffs(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, int32_t *coeffs, int *dc)
+{
+    if (check_batch(ctx, n_frames, "ebcc_hip_spiht_coeffs")) return 1;
+    hipStream_t s = ctx->stream;
+    launch_pad_and_dc_from_image(d_images, ctx->rb, (int) n_frames, s);
+    launch_analysis(ctx->rb, (int) n_frames, s);
+    EBCC_HIP_CHECK(hipMemcpyAsync(coeffs, ctx->rb.C, n_frames * ctx->rb.np * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    fetch_frame_states(ctx, n_frames);
+    for (size_t f = 0; f < n_frames; f++) dc[f] = (int) ctx->h_fs[f].dc;
+    return 0;
+}
+
+int ebcc_hip_spiht_decode_prefix(ebcc_hip_ctx *ctx, size_t n_frames, const size_t *trunc_bits, float *d_images_out)
+{
+    if (check_batch(ctx, n_frames, "ebcc_hip_spiht_decode_prefix")) return 1;
+    hipStream_t s = ctx->stream;
+    fetch_frame_states(ctx, n_frames);
+    for (size_t f = 0; f < n_frames; f++) {
+        if (trunc_bits[f] <= 128) { set_error("decode_prefix: trunc_bits must exceed 128"); return 1; }
+        ctx->h_u64b[f] = trunc_bits[f];
+        ctx->h_fs[f].dec_dc = (int) ctx->h_fs[f].dc;
+    }
+    push_frame_states(ctx, n_frames);
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n_frames * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    launch_reconstruct(ctx->rb, (int) n_frames, ctx->d_u64b, nullptr, s);
+    launch_synthesis(ctx->rb, (int) n_frames, nullptr, s);
+    launch_emit_image(d_images_out, ctx->rb, (int) n_frames, s);
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// parse + validate the 15-byte IMS header on the host (spiht_re.c:480-503)
+static int check_ims_header(ebcc_hip_ctx *ctx, const uint8_t *b, size_t n, size_t num_bits)
+{
+    if (n < 15 || b[0] != 'I' || b[1] != 'M' || b[2] != 'S') { set_error("SPIHT stream: bad magic"); return 1; }
+    unsigned long long hi = 0;
+    for (int i = 0; i < 8; i++) hi = (hi << 8) | b[3 + i];
+    unsigned lo = ((unsigned) b[11] << 8) | b[12];
+    unsigned stages = (unsigned) (hi >> 58), sx = (unsigned) (hi >> 46) & 0xFFF, sy = (unsigned) (hi >> 34) & 0xFFF;
+    unsigned ex = (unsigned) (hi >> 24) & 0x3FF, ey = (unsigned) (hi >> 14) & 0x3FF;
+    unsigned long long bits0 = ((hi & 0x1FFF) << 16) | lo;
+    const Grid &g = ctx->rb.g;
+    if ((int) stages != g.stages || (int) sx != g.size_x || (int) sy != g.size_y || (int) ex != g.extra_x ||
+        (int) ey != g.extra_y) {
+        set_error("SPIHT stream geometry (%u stages, %ux%u +%u,%u) does not match the context (%dx%d)", stages, sx, sy,
+                  ex, ey, g.size_x, g.size_y);
+        return 1;
+    }
+    unsigned long long nb = num_bits > bits0 ? bits0 : num_bits;
+    if (nb <= 128) { set_error("SPIHT stream: num_bits must exceed 128"); return 1; }
+    return 0;
+}
+
+int ebcc_hip_spiht_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes,
+                          const size_t *num_bits, size_t n_frames, float *d_images_out)
+{
+    if (check_batch(ctx, n_frames, "ebcc_hip_spiht_decode")) return 1;
+    hipStream_t s = ctx->stream;
+    const size_t slot = ctx->rb.stream_words * 4;
+    for (size_t f = 0; f < n_frames; f++) {
+        if (sizes[f] > slot - 64) { set_error("SPIHT stream of %zu bytes exceeds the slot", sizes[f]); return 1; }
+        if (check_ims_header(ctx, streams[f], sizes[f], num_bits[f])) return 1;
+        ctx->h_u64a[f] = sizes[f];
+        ctx->h_u64b[f] = num_bits[f];
+        EBCC_HIP_CHECK(hipMemcpyAsync((uint8_t *) ctx->rb.stream + f * slot, streams[f], sizes[f], hipMemcpyHostToDevice, s));
+    }
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n_frames * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n_frames * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n_frames, nullptr, s);
+    launch_synthesis(ctx->rb, (int) n_frames, nullptr, s);
+    launch_emit_image(d_images_out, ctx->rb, (int) n_frames, s);
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// engine.hpp - per-device context of the MI355X EBCC engine.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "residual.hpp"
+
+struct ebcc_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t max_frames = 0;
+    int height = 0, width = 0;
+    size_t n_pix = 0;                      // height * width
+    size_t bytes = 0;                      // device bytes owned
+    ebcc::ResidualBuffers rb{};
+    // per-frame parameter arrays (device) and pinned host mirrors
+    unsigned long long *d_u64a = nullptr, *d_u64b = nullptr, *d_u64c = nullptr;
+    int *d_active = nullptr;
+    unsigned long long *h_u64a = nullptr, *h_u64b = nullptr, *h_u64c = nullptr;
+    int *h_active = nullptr;
+    ebcc::FrameState *h_fs = nullptr;      // pinned
+    std::vector<void *> allocs;
+    void *j2k = nullptr;                   // base-layer state (j2k.hpp)
+};
+
+namespace ebcc {
+
+void set_error(const char *fmt, ...);
+template <typename T>
+T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count);
+
+// synchronous copy of the frame states to ctx->h_fs
+void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n_frames);
+void push_frame_states(ebcc_hip_ctx *ctx, size_t n_frames);
+
+}  // namespace ebcc

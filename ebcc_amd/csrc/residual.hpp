@@ -1,0 +1,103 @@
+// residual.hpp - device-side residual layer of the EBCC codec (pad + DC + CDF 9/7 + SPIHT).
+// Replaces reference src/spiht/{dwt.h,spiht_re.c,ml.h,bitio.h}; every launcher cites what it covers.
+#pragma once
+
+#include "common.hpp"
+
+namespace ebcc {
+
+// Per-frame scalar state living in device memory (one entry per frame of the batch).
+struct FrameState {
+    // ---- input statistics (reference src/ebcc_codec.c:598-605, :515-533)
+    unsigned long long min_key, max_key;   // (order_key << 32) | tie-break index
+    float minv, maxv;
+    int has_nonfinite;
+    int const_field;
+    // ---- residual statistics (:712-719, :730-746)
+    unsigned long long rmin_key, rmax_key;
+    float rmin, rmax;
+    // ---- DC removal (src/spiht/dwt.h:319-334)
+    double dc_sum;
+    float dc;
+    int dc_uncertain;
+    // ---- SPIHT encode (src/spiht/spiht_re.c:432-475)
+    int cmax;                               // max |coefficient|
+    int top_step;
+    unsigned long long budget;              // bits0 - 128
+    unsigned long long emitted;             // SPIHT bits written (<= budget + 1)
+    unsigned int stream_bytes;
+    unsigned int refine_base[32];           // 0-based index of the first refinement bit of each step
+    unsigned int refine_count[32];          // LSP entries refined at that step
+    unsigned int step_reached[32];          // 1 if the refinement pass of the step was entered
+    // ---- probe statistics (:477-513)
+    unsigned int maxerr_bits;               // float bits of max |x - (d + r)| (non-negative => monotone)
+    double err_sum;
+    int err_sum_inexact;
+    unsigned long long nbad;                // count(|x - d| > target)
+    // ---- decode
+    int dec_stages, dec_dc, dec_top_step;
+    unsigned long long dec_budget;
+};
+
+struct ResidualBuffers {
+    Grid g;
+    int max_frames;
+    size_t np;                  // padded pixels per frame
+    float *A, *T;               // [frames][np] transform ping-pong
+    int32_t *C;                 // [frames][np] integer coefficients
+    int32_t *D, *G;             // [frames][np] descendant / grand-descendant max magnitude
+    uint32_t *lip, *lsp, *lis0, *lis1;   // [frames][np]
+    uint32_t *sigord, *lspidx;  // [frames][np] 1-based ordinal of the significance bit / LSP slot
+    uint32_t *stream;           // [frames][stream_words] SPIHT byte stream (device copy)
+    size_t stream_words;
+    double *partial;            // [frames][kPartials] deterministic reduction scratch
+    FrameState *fs;             // [frames]
+};
+constexpr int kPartials = 256;
+
+// ---------------------------------------------------------------- launchers (all asynchronous on `s`)
+
+// min/max of r = data - decoded  -> fs.rmin/rmax   (src/ebcc_codec.c:712-716,730-733)
+void launch_residual_minmax(const float *data, const float *decoded, int n_frames, size_t n_pix,
+                            FrameState *fs, hipStream_t s);
+
+// load_image + sub_dc prologue: A = mirror-pad(((r - rmin) / (rmax - rmin)) * 255), fs.dc  (dwt.h:41-78,319-334)
+void launch_pad_and_dc(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
+                       hipStream_t s);
+
+// same but from an already normalised [0,1] image (unit tests / spiht_encode entry point)
+void launch_pad_and_dc_from_image(const float *image, const ResidualBuffers &rb, int n_frames, hipStream_t s);
+
+// dwt2full + normalize: A (minus dc) -> C, fs.cmax, D, G   (dwt.h:293-303,355-368; spiht_re.c:54-60,160-206)
+void launch_analysis(const ResidualBuffers &rb, int n_frames, hipStream_t s);
+
+// spiht_encode_process + IMS header -> rb.stream, fs.emitted/stream_bytes, sigord/lspidx  (spiht_re.c:208-317,448-464)
+// fs[f].budget must be set (bits0 - 128) and bits0 per frame is passed for the header.
+void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, hipStream_t s);
+
+// Decoder state after the first `trunc_bits[f]` stream bits, rebuilt from the encoder's bookkeeping:
+// A = coefficient grid as spiht_decode_process would leave it  (spiht_re.c:319-430 semantics)
+void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,
+                        const int *d_active, hipStream_t s);
+
+// idwt2full on A (dwt.h:305-317); result in A
+void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
+
+// add_dc + crop + /255 (dwt.h:336-353, spiht_re.c:512-516) then r*(rmax-rmin)+rmin and the error
+// statistics of src/ebcc_codec.c:477-501 against data/decoded  -> fs.maxerr_bits, fs.err_sum
+void launch_probe_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
+                        const int *d_active, hipStream_t s);
+
+// add_dc + crop + /255 and out += r*(rmax-rmin)+rmin   (src/ebcc_codec.c:1306-1308); dc from fs.dec_dc
+void launch_add_residual(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
+
+// plain spiht_decode output image in [0,1] (spiht_re.c:508-516) for the unit entry point
+void launch_emit_image(float *image_out, const ResidualBuffers &rb, int n_frames, hipStream_t s);
+
+// spiht_decode header parse + spiht_decode_process: stream bytes -> A (float coefficient grid), fs.dec_*
+// d_streams: [frames][stream_words*4] bytes; d_sizes / d_num_bits per frame.
+void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const unsigned long long *d_sizes,
+                         const unsigned long long *d_num_bits, const ResidualBuffers &rb, int n_frames,
+                         const int *d_active, hipStream_t s);
+
+}  // namespace ebcc

@@ -1,0 +1,743 @@
+// residual_dwt.hip - pad / DC / CDF 9/7 lifting / truncation / error statistics kernels of the residual
+// layer.  gfx950 only, compiled with -ffp-contract=off: every expression below is the same sequence of
+// IEEE fp32 operations the reference executes on x86-64 (no FMA), see SURVEY.md Appendix B.
+//
+// Lifting layout: a line of n samples is held de-interleaved in LDS as E[k] = s[2k], O[k] = s[2k+1].
+// The four lifting steps are data-parallel sweeps separated by barriers; each output element is the
+// same 2-3 operand fp32 expression as in the reference's sequential loops
+// (reference src/spiht/dwt.h:87-112 rows, :142-167 columns, :114-140 / :169-272 inverse).
+// Rows: one row per workgroup iteration, HBM access is full contiguous rows (float2 per lane).
+// Columns: a tile of CW adjacent columns x full height is staged through LDS so that every HBM
+// access is a CW*4-byte row segment; the strided walk happens only in LDS.
+#include "residual.hpp"
+
+namespace ebcc {
+
+namespace {
+
+__device__ constexpr float kAlpha = -1.586134342f;
+__device__ constexpr float kBeta  = -0.05298011854f;
+__device__ constexpr float kGamma = 0.8829110762f;
+__device__ constexpr float kDelta = 0.44355068522f;
+__device__ constexpr float kXi    = 1.149604398f;
+
+constexpr int kRowThreads = 256;
+constexpr int kColThreads = 1024;
+
+// ------------------------------------------------------------------------------------------------
+// forward / inverse lifting sweeps on an LDS tile: `lines` lines, element (k, line) at [k*ls + line*ks]
+// (rows: ks = half-padded stride, ls = 1 ... we simply pass index functors)
+// ------------------------------------------------------------------------------------------------
+template <typename Idx>
+__device__ inline void lift_forward_tile(float *E, float *O, int half, int lines, Idx at, int tid, int nt)
+{
+    const int total = half * lines;
+    // step 1: O[k] = O[k] + alpha*(E[k] + E[k+1]);  last: O[h-1] + (2*alpha)*E[h-1]      dwt.h:92-94
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float o = O[at(k, l)];
+        if (k + 1 < half) o = o + kAlpha * (E[at(k, l)] + E[at(k + 1, l)]);
+        else              o = o + (2 * kAlpha) * E[at(k, l)];
+        O[at(k, l)] = o;
+    }
+    __syncthreads();
+    // step 2: E[k] = E[k] + beta*(O[k] + O[k-1]);  first: beta*(O[0] + O[1])             dwt.h:96-98
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float e = E[at(k, l)];
+        if (k > 0) e = e + kBeta * (O[at(k, l)] + O[at(k - 1, l)]);
+        else       e = e + kBeta * (O[at(0, l)] + O[at(1, l)]);
+        E[at(k, l)] = e;
+    }
+    __syncthreads();
+    // step 3: O[k] += gamma*(E[k] + E[k+1]);  last: gamma*(E[h-1] + E[h-2])               dwt.h:100-102
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float o = O[at(k, l)];
+        if (k + 1 < half) o = o + kGamma * (E[at(k, l)] + E[at(k + 1, l)]);
+        else              o = o + kGamma * (E[at(k, l)] + E[at(k - 1, l)]);
+        O[at(k, l)] = o;
+    }
+    __syncthreads();
+    // step 4: E[k] += delta*(O[k] + O[k-1]);  first: delta*(O[0] + O[1])                  dwt.h:104-106
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float e = E[at(k, l)];
+        if (k > 0) e = e + kDelta * (O[at(k, l)] + O[at(k - 1, l)]);
+        else       e = e + kDelta * (O[at(0, l)] + O[at(1, l)]);
+        E[at(k, l)] = e;
+    }
+    __syncthreads();
+}
+
+// On entry E = low band, O = high band (unscaled, as stored).  On exit E[k] = x[2k], O[k] = x[2k+1].
+template <typename Idx>
+__device__ inline void lift_inverse_tile(float *E, float *O, int half, int lines, Idx at, int tid, int nt)
+{
+    const int total = half * lines;
+    // un-scale                                                                              dwt.h:120-123
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        E[at(k, l)] = E[at(k, l)] / kXi;
+        O[at(k, l)] = O[at(k, l)] * kXi;
+    }
+    __syncthreads();
+    // E[k] -= delta*(O[k] + O[k-1]); first uses O[0] + O[1]                                 dwt.h:125-127
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float e = E[at(k, l)];
+        if (k > 0) e = e - kDelta * (O[at(k, l)] + O[at(k - 1, l)]);
+        else       e = e - kDelta * (O[at(0, l)] + O[at(1, l)]);
+        E[at(k, l)] = e;
+    }
+    __syncthreads();
+    // O[k] -= gamma*(E[k] + E[k+1]); last uses E[h-1] + E[h-2]                              dwt.h:129-131
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float o = O[at(k, l)];
+        if (k + 1 < half) o = o - kGamma * (E[at(k, l)] + E[at(k + 1, l)]);
+        else              o = o - kGamma * (E[at(k, l)] + E[at(k - 1, l)]);
+        O[at(k, l)] = o;
+    }
+    __syncthreads();
+    // x[2k] = E[k] - beta*(O[k] + O[k-1]); first uses O[0] + O[1]                           dwt.h:133-135
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float e = E[at(k, l)];
+        if (k > 0) e = e - kBeta * (O[at(k, l)] + O[at(k - 1, l)]);
+        else       e = e - kBeta * (O[at(0, l)] + O[at(1, l)]);
+        E[at(k, l)] = e;
+    }
+    __syncthreads();
+    // x[2k+1] = O[k] - alpha*(x[2k] + x[2k+2]); last: O[h-1] - (2*alpha)*x[n-2]             dwt.h:137-139
+    for (int i = tid; i < total; i += nt) {
+        int k = i / lines, l = i - k * lines;
+        float o = O[at(k, l)];
+        if (k + 1 < half) o = o - kAlpha * (E[at(k, l)] + E[at(k + 1, l)]);
+        else              o = o - (2 * kAlpha) * E[at(k, l)];
+        O[at(k, l)] = o;
+    }
+    __syncthreads();
+}
+
+struct RowIdx { __device__ int operator()(int k, int) const { return k; } };
+template <int CW> struct ColIdx { __device__ int operator()(int k, int l) const { return k * CW + l; } };
+
+// ------------------------------------------------------------------------------------------------
+// row kernels: grid (blocks, frames)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRowThreads) void k_rows_fwd(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int stride, size_t frame_stride, int n, int rows,
+                                                           const FrameState *fs, int sub_dc, const int *active)
+{
+    extern __shared__ float sm[];
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const int half = n >> 1;
+    float *E = sm, *O = sm + half;
+    src += (size_t) frame * frame_stride;
+    dst += (size_t) frame * frame_stride;
+    const float dc = sub_dc ? fs[frame].dc : 0.0f;
+    const int tid = threadIdx.x;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float2 *s2 = reinterpret_cast<const float2 *>(src + (size_t) row * stride);
+        for (int k = tid; k < half; k += kRowThreads) {
+            float2 v = s2[k];
+            // sub_dc (dwt.h:330-332): data -= dc.  x - 0.0f == x bit-for-bit, so the no-DC levels share the path.
+            E[k] = v.x - dc;
+            O[k] = v.y - dc;
+        }
+        __syncthreads();
+        lift_forward_tile(E, O, half, 1, RowIdx(), tid, kRowThreads);
+        float *d = dst + (size_t) row * stride;
+        for (int k = tid; k < half; k += kRowThreads) {
+            d[k] = E[k] * kXi;                    // dwt.h:109
+            d[half + k] = O[k] / kXi;             // dwt.h:110
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kRowThreads) void k_rows_inv(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int stride, size_t frame_stride, int n, int rows,
+                                                           const int *active)
+{
+    extern __shared__ float sm[];
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const int half = n >> 1;
+    float *E = sm, *O = sm + half;
+    src += (size_t) frame * frame_stride;
+    dst += (size_t) frame * frame_stride;
+    const int tid = threadIdx.x;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *s = src + (size_t) row * stride;
+        for (int k = tid; k < half; k += kRowThreads) {
+            E[k] = s[k];
+            O[k] = s[half + k];
+        }
+        __syncthreads();
+        lift_inverse_tile(E, O, half, 1, RowIdx(), tid, kRowThreads);
+        float2 *d2 = reinterpret_cast<float2 *>(dst + (size_t) row * stride);
+        for (int k = tid; k < half; k += kRowThreads) d2[k] = make_float2(E[k], O[k]);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column kernels: grid (tiles, frames); tile = CW columns x n rows in LDS
+// ------------------------------------------------------------------------------------------------
+template <int CW>
+__global__ __launch_bounds__(kColThreads) void k_cols_fwd(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int stride, size_t frame_stride, int n, int cols,
+                                                           const int *active)
+{
+    extern __shared__ float sm[];
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const int half = n >> 1;
+    float *E = sm, *O = sm + (size_t) half * CW;
+    src += (size_t) frame * frame_stride;
+    dst += (size_t) frame * frame_stride;
+    const int tid = threadIdx.x;
+    const int ntiles = (cols + CW - 1) / CW;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = tile * CW;
+        const int w = min(CW, cols - x0);
+        for (int i = tid; i < n * CW; i += kColThreads) {
+            int y = i / CW, c = i - y * CW;
+            float v = (c < w) ? src[(size_t) y * stride + x0 + c] : 0.0f;
+            ((y & 1) ? O : E)[(y >> 1) * CW + c] = v;
+        }
+        __syncthreads();
+        lift_forward_tile(E, O, half, CW, ColIdx<CW>(), tid, kColThreads);
+        for (int i = tid; i < half * CW; i += kColThreads) {
+            int k = i / CW, c = i - k * CW;
+            if (c < w) {
+                dst[(size_t) k * stride + x0 + c] = E[i] * kXi;             // dwt.h:164
+                dst[(size_t) (half + k) * stride + x0 + c] = O[i] / kXi;    // dwt.h:165
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(kColThreads) void k_cols_inv(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int stride, size_t frame_stride, int n, int cols,
+                                                           const int *active)
+{
+    extern __shared__ float sm[];
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const int half = n >> 1;
+    float *E = sm, *O = sm + (size_t) half * CW;
+    src += (size_t) frame * frame_stride;
+    dst += (size_t) frame * frame_stride;
+    const int tid = threadIdx.x;
+    const int ntiles = (cols + CW - 1) / CW;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = tile * CW;
+        const int w = min(CW, cols - x0);
+        for (int i = tid; i < half * CW; i += kColThreads) {
+            int k = i / CW, c = i - k * CW;
+            E[i] = (c < w) ? src[(size_t) k * stride + x0 + c] : 0.0f;
+            O[i] = (c < w) ? src[(size_t) (half + k) * stride + x0 + c] : 0.0f;
+        }
+        __syncthreads();
+        lift_inverse_tile(E, O, half, CW, ColIdx<CW>(), tid, kColThreads);
+        for (int i = tid; i < n * CW; i += kColThreads) {
+            int y = i / CW, c = i - y * CW;
+            if (c < w) dst[(size_t) y * stride + x0 + c] = ((y & 1) ? O : E)[(y >> 1) * CW + c];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual min/max with "first occurrence wins" tie-break (reference findMinMaxf, ebcc_codec.c:515-533)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_minmax_init(FrameState *fs, int n_frames)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames) {
+        fs[f].rmin_key = ~0ull;
+        fs[f].rmax_key = 0ull;
+    }
+}
+
+__device__ inline unsigned long long wave_min_u64(unsigned long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ inline unsigned long long wave_max_u64(unsigned long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_residual_minmax(const float *__restrict__ data,
+                                                          const float *__restrict__ decoded, size_t n_pix,
+                                                          FrameState *fs)
+{
+    const int frame = blockIdx.y;
+    const float *x = data + (size_t) frame * n_pix;
+    const float *d = decoded + (size_t) frame * n_pix;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
+        float r = x[i] - d[i];                                   // ebcc_codec.c:713
+        unsigned long long k = (unsigned long long) float_order_key(r) << 32;
+        unsigned long long lo = k | (unsigned int) i, hi = k | (0xFFFFFFFFu - (unsigned int) i);
+        kmin = lo < kmin ? lo : kmin;
+        kmax = hi > kmax ? hi : kmax;
+    }
+    kmin = wave_min_u64(kmin);
+    kmax = wave_max_u64(kmax);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&fs[frame].rmin_key, kmin);
+        atomicMax(&fs[frame].rmax_key, kmax);
+    }
+}
+
+__global__ void k_residual_minmax_finish(const float *data, const float *decoded, size_t n_pix, FrameState *fs,
+                                         int n_frames)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    size_t imin = (unsigned int) fs[f].rmin_key;
+    size_t imax = 0xFFFFFFFFu - (unsigned int) fs[f].rmax_key;
+    const float *x = data + (size_t) f * n_pix;
+    const float *d = decoded + (size_t) f * n_pix;
+    fs[f].rmin = x[imin] - d[imin];
+    fs[f].rmax = x[imax] - d[imax];
+}
+
+// ------------------------------------------------------------------------------------------------
+// load_image (+ residual normalisation) and deterministic DC sum
+// ------------------------------------------------------------------------------------------------
+template <bool FROM_IMAGE>
+__global__ __launch_bounds__(256) void k_pad_load(const float *__restrict__ data, const float *__restrict__ decoded,
+                                                   float *__restrict__ A, Grid g, size_t n_pix, size_t np,
+                                                   const FrameState *fs, double *partial)
+{
+    __shared__ double red[256];
+    const int frame = blockIdx.y;
+    const float *x = data + (size_t) frame * n_pix;
+    const float *d = FROM_IMAGE ? nullptr : decoded + (size_t) frame * n_pix;
+    float *a = A + (size_t) frame * np;
+    float rmin = 0, rng = 1;
+    if (!FROM_IMAGE) {
+        rmin = fs[frame].rmin;
+        rng = fs[frame].rmax - fs[frame].rmin;
+    }
+    // fixed partition of the padded grid: block b owns [b*chunk, (b+1)*chunk)
+    const size_t chunk = (np + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t) blockIdx.x * chunk;
+    const size_t hi = lo + chunk < np ? lo + chunk : np;
+    double acc = 0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        int y = (int) (i / g.nx), xx = (int) (i - (size_t) y * g.nx);
+        float v;
+        if (y >= g.size_y && xx >= g.size_x) {
+            v = 0.0f;                                                   // dwt.h:74-76
+        } else {
+            int sy = y < g.size_y ? y : 2 * g.size_y - 1 - y;           // dwt.h:71-73
+            int sx = xx < g.size_x ? xx : 2 * g.size_x - 1 - xx;        // dwt.h:68-70
+            size_t si = (size_t) sy * g.size_x + sx;
+            float rn;
+            if (FROM_IMAGE) rn = x[si];
+            else rn = ((x[si] - d[si]) - rmin) / rng;                   // ebcc_codec.c:731,745
+            v = rn * 255.0f;                                            // dwt.h:65
+        }
+        a[i] = v;
+        acc += (double) v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int) threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t) frame * kPartials + blockIdx.x] = red[0];
+}
+
+__global__ void k_dc_finish(const double *partial, int n_partials, size_t np, FrameState *fs, int n_frames)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    double s = 0;
+    for (int i = 0; i < n_partials; i++) s += partial[(size_t) f * kPartials + i];
+    // The reference sums sequentially in double (dwt.h:324-329); only floor(mean) survives.  Both
+    // orders are within eps of the exact sum; if the floor could differ, fall back to the exact order.
+    const double eps = 0.0625 + (double) np * 1e-9;
+    double m = floor(s / (double) np);
+    double m_lo = floor((s - eps) / (double) np), m_hi = floor((s + eps) / (double) np);
+    fs[f].dc_sum = s;
+    fs[f].dc = (float) m;
+    fs[f].dc_uncertain = (m_lo != m_hi) ? 1 : 0;
+}
+
+// rare fallback: exact reference order, one lane per frame
+__global__ void k_dc_sequential(const float *A, size_t np, FrameState *fs, int n_frames)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames || !fs[f].dc_uncertain) return;
+    const float *a = A + (size_t) f * np;
+    double s = 0;
+    for (size_t i = 0; i < np; i++) s += a[i];
+    s /= (double) np;
+    fs[f].dc = (float) floor(s);
+    fs[f].dc_uncertain = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalize (dwt.h:355-368) -> integer coefficients, running max (spiht_re.c:54-59)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_cmax_init(FrameState *fs, int n_frames)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames) fs[f].cmax = 2;                              // "max = 2.0", spiht_re.c:32
+}
+
+__global__ __launch_bounds__(256) void k_truncate(const float *__restrict__ A, int32_t *__restrict__ C, size_t np,
+                                                   FrameState *fs)
+{
+    const int frame = blockIdx.y;
+    const float *a = A + (size_t) frame * np;
+    int32_t *c = C + (size_t) frame * np;
+    int m = 0;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (size_t) gridDim.x * blockDim.x) {
+        float v = a[i];
+        int q = (int) v;                                            // truncation toward zero == dwt.h:362-366
+        c[i] = q;
+        int aq = q < 0 ? -q : q;
+        m = aq > m ? aq : m;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        int o = __shfl_xor(m, d);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 2) atomicMax(&fs[frame].cmax, m);
+}
+
+// spiht_re.c:60: step = floor(log(max)/log(2.0)).  The quotient is evaluated by the host libm for every
+// power of two (step_of_pow2[k]); for other integers < 2^24 the floor is unambiguous.
+__global__ void k_top_step(FrameState *fs, int n_frames, const int *step_of_pow2)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    int m = fs[f].cmax;
+    int k = 31 - __clz(m);
+    fs[f].top_step = (m == (1 << k)) ? step_of_pow2[k] : k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// descendant maxima (replaces the recursion of spiht_re.c:160-206)
+//   D[p] = max |c| over all descendants of p,  G[p] = max over descendants at depth >= 2
+// ------------------------------------------------------------------------------------------------
+__device__ inline int first_child(const Grid &g, int x, int y)
+{
+    int cx, cy;
+    if (x < g.lx && y < g.ly) {                                     // spiht_re.c:133-147
+        cx = (x & 1) ? x + g.lx - 1 : x;
+        cy = (y & 1) ? y + g.ly - 1 : y;
+        if (cx == x && cy == y) return -1;
+    } else {                                                        // spiht_re.c:148-154
+        cx = 2 * x; cy = 2 * y;
+        if (cx >= g.nx || cy >= g.ny) return -1;
+    }
+    return cx + cy * g.nx;
+}
+
+__global__ __launch_bounds__(256) void k_descmax(const int32_t *__restrict__ C, int32_t *__restrict__ D,
+                                                  int32_t *__restrict__ G, Grid g, size_t np, int rx, int ry,
+                                                  int ex, int ey, int child_has_d)
+{
+    const int frame = blockIdx.y;
+    const int32_t *c = C + (size_t) frame * np;
+    int32_t *dd = D + (size_t) frame * np;
+    int32_t *gg = G + (size_t) frame * np;
+    const int total = rx * ry;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int y = i / rx, x = i - y * rx;
+        if (x < ex && y < ey) continue;
+        int ch = first_child(g, x, y);
+        int dmax = 0, gmax = 0;
+        if (ch >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int q = ch + (k & 1) + (k >> 1) * g.nx;
+                int v = c[q];
+                v = v < 0 ? -v : v;
+                int dv = child_has_d ? dd[q] : 0;
+                dmax = max(dmax, max(v, dv));
+                gmax = max(gmax, dv);
+            }
+        }
+        dd[x + y * g.nx] = dmax;
+        gg[x + y * g.nx] = gmax;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// probe statistics / final combination
+// ------------------------------------------------------------------------------------------------
+__global__ void k_probe_init(FrameState *fs, int n_frames, const int *active)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames && (!active || active[f])) {
+        fs[f].maxerr_bits = 0;
+        fs[f].err_sum = 0;
+    }
+}
+
+// residual pixel from the synthesised grid: add_dc (dwt.h:345-350), /255 (spiht_re.c:514),
+// de-normalisation (ebcc_codec.c:752)
+__device__ inline float residual_value(float a, float dc, float rmin, float rng)
+{
+    float v = floorf(a + dc);
+    v = v > 255.0f ? 255.0f : (v < 0.0f ? 0.0f : v);
+    float rn = v / 255.0f;
+    return rn * rng + rmin;
+}
+
+__global__ __launch_bounds__(256) void k_probe_stats(const float *__restrict__ data, const float *__restrict__ decoded,
+                                                      const float *__restrict__ A, Grid g, size_t n_pix, size_t np,
+                                                      FrameState *fs, double *partial, const int *active)
+{
+    __shared__ double red[256];
+    __shared__ float redm[256];
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const float *x = data + (size_t) frame * n_pix;
+    const float *d = decoded + (size_t) frame * n_pix;
+    const float *a = A + (size_t) frame * np;
+    const float dc = fs[frame].dc, rmin = fs[frame].rmin, rng = fs[frame].rmax - fs[frame].rmin;
+    const size_t chunk = (n_pix + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t) blockIdx.x * chunk;
+    const size_t hi = lo + chunk < n_pix ? lo + chunk : n_pix;
+    double acc = 0;
+    float mx = 0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        int y = (int) (i / g.size_x), xx = (int) (i - (size_t) y * g.size_x);
+        float r = residual_value(a[(size_t) y * g.nx + xx], dc, rmin, rng);
+        float t = x[i] - (d[i] + r);                                // ebcc_codec.c:481,498
+        acc += (double) t;
+        float e = fabsf(t);
+        mx = e > mx ? e : mx;
+    }
+    red[threadIdx.x] = acc;
+    redm[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int) threadIdx.x < s) {
+            red[threadIdx.x] += red[threadIdx.x + s];
+            redm[threadIdx.x] = fmaxf(redm[threadIdx.x], redm[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[(size_t) frame * kPartials + blockIdx.x] = red[0];
+        atomicMax(&fs[frame].maxerr_bits, __float_as_uint(redm[0]));
+    }
+}
+
+__global__ void k_probe_finish(const double *partial, int n_partials, FrameState *fs, int n_frames, const int *active)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames || (active && !active[f])) return;
+    double s = 0;
+    for (int i = 0; i < n_partials; i++) s += partial[(size_t) f * kPartials + i];
+    fs[f].err_sum = s;
+}
+
+__global__ __launch_bounds__(256) void k_add_residual(float *__restrict__ out, const float *__restrict__ A, Grid g,
+                                                       size_t n_pix, size_t np, const FrameState *fs, const int *active)
+{
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    float *o = out + (size_t) frame * n_pix;
+    const float *a = A + (size_t) frame * np;
+    const float dc = (float) fs[frame].dec_dc, rmin = fs[frame].rmin, rng = fs[frame].rmax - fs[frame].rmin;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
+        int y = (int) (i / g.size_x), xx = (int) (i - (size_t) y * g.size_x);
+        o[i] = o[i] + residual_value(a[(size_t) y * g.nx + xx], dc, rmin, rng);    // ebcc_codec.c:1307
+    }
+}
+
+__global__ __launch_bounds__(256) void k_emit_image(float *__restrict__ out, const float *__restrict__ A, Grid g,
+                                                     size_t n_pix, size_t np, const FrameState *fs)
+{
+    const int frame = blockIdx.y;
+    float *o = out + (size_t) frame * n_pix;
+    const float *a = A + (size_t) frame * np;
+    const float dc = (float) fs[frame].dec_dc;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
+        int y = (int) (i / g.size_x), xx = (int) (i - (size_t) y * g.size_x);
+        float v = floorf(a[(size_t) y * g.nx + xx] + dc);
+        v = v > 255.0f ? 255.0f : (v < 0.0f ? 0.0f : v);
+        o[i] = v / 255.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+void allow_big_lds(K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        EBCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+}
+
+void rows_fwd(const float *src, float *dst, const ResidualBuffers &rb, int n, int rows, int n_frames, int sub_dc,
+              const int *active, hipStream_t s)
+{
+    dim3 grid(min(rows, 96), n_frames);
+    size_t lds = (size_t) n * sizeof(float);
+    hipLaunchKernelGGL(k_rows_fwd, grid, dim3(kRowThreads), lds, s, src, dst, rb.g.nx, rb.np, n, rows, rb.fs, sub_dc,
+                       active);
+}
+void rows_inv(const float *src, float *dst, const ResidualBuffers &rb, int n, int rows, int n_frames,
+              const int *active, hipStream_t s)
+{
+    dim3 grid(min(rows, 96), n_frames);
+    size_t lds = (size_t) n * sizeof(float);
+    hipLaunchKernelGGL(k_rows_inv, grid, dim3(kRowThreads), lds, s, src, dst, rb.g.nx, rb.np, n, rows, active);
+}
+template <bool FWD>
+void cols_pass(const float *src, float *dst, const ResidualBuffers &rb, int n, int cols, int n_frames,
+               const int *active, hipStream_t s)
+{
+    const size_t lds_limit = 156 * 1024;
+    if ((size_t) n * 32 * sizeof(float) <= lds_limit) {
+        size_t lds = (size_t) n * 32 * sizeof(float);
+        auto k = FWD ? k_cols_fwd<32> : k_cols_inv<32>;
+        allow_big_lds(k, lds);
+        dim3 grid(ceil_div(cols, 32), n_frames);
+        hipLaunchKernelGGL(k, grid, dim3(kColThreads), lds, s, src, dst, rb.g.nx, rb.np, n, cols, active);
+    } else {
+        size_t lds = (size_t) n * 16 * sizeof(float);
+        auto k = FWD ? k_cols_fwd<16> : k_cols_inv<16>;
+        allow_big_lds(k, lds);
+        dim3 grid(ceil_div(cols, 16), n_frames);
+        hipLaunchKernelGGL(k, grid, dim3(kColThreads), lds, s, src, dst, rb.g.nx, rb.np, n, cols, active);
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+void launch_residual_minmax(const float *data, const float *decoded, int n_frames, size_t n_pix, FrameState *fs,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(k_minmax_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, fs, n_frames);
+    hipLaunchKernelGGL(k_residual_minmax, dim3(64, n_frames), dim3(256), 0, s, data, decoded, n_pix, fs);
+    hipLaunchKernelGGL(k_residual_minmax_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, data, decoded, n_pix,
+                       fs, n_frames);
+}
+
+static void finish_dc(const ResidualBuffers &rb, int n_frames, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dc_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, kPartials, rb.np, rb.fs,
+                       n_frames);
+    hipLaunchKernelGGL(k_dc_sequential, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.A, rb.np, rb.fs, n_frames);
+}
+
+void launch_pad_and_dc(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames, hipStream_t s)
+{
+    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
+    hipLaunchKernelGGL(k_pad_load<false>, dim3(kPartials, n_frames), dim3(256), 0, s, data, decoded, rb.A, rb.g, n_pix,
+                       rb.np, rb.fs, rb.partial);
+    finish_dc(rb, n_frames, s);
+}
+
+void launch_pad_and_dc_from_image(const float *image, const ResidualBuffers &rb, int n_frames, hipStream_t s)
+{
+    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
+    hipLaunchKernelGGL(k_pad_load<true>, dim3(kPartials, n_frames), dim3(256), 0, s, image, (const float *) nullptr,
+                       rb.A, rb.g, n_pix, rb.np, rb.fs, rb.partial);
+    finish_dc(rb, n_frames, s);
+}
+
+static int *g_step_table = nullptr;   // device copy of floor(log(2^k)/log(2.0)) evaluated by the host libm
+
+static const int *step_table(hipStream_t s)
+{
+    if (!g_step_table) {
+        int h[32];
+        for (int k = 0; k < 32; k++) {
+            float m = (float) (1u << k);
+            h[k] = (int) floor(log((double) m) / log(2.0));        // spiht_re.c:60 with max = 2^k
+        }
+        EBCC_HIP_CHECK(hipMalloc(&g_step_table, sizeof h));
+        EBCC_HIP_CHECK(hipMemcpyAsync(g_step_table, h, sizeof h, hipMemcpyHostToDevice, s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return g_step_table;
+}
+
+void launch_analysis(const ResidualBuffers &rb, int n_frames, hipStream_t s)
+{
+    const Grid &g = rb.g;
+    int nx = g.nx, ny = g.ny;
+    for (int lv = 0; lv < g.stages; lv++) {                         // dwt.h:297-301
+        rows_fwd(rb.A, rb.T, rb, nx, ny, n_frames, lv == 0, nullptr, s);
+        cols_pass<true>(rb.T, rb.A, rb, ny, nx, n_frames, nullptr, s);
+        nx >>= 1; ny >>= 1;
+    }
+    hipLaunchKernelGGL(k_cmax_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames);
+    hipLaunchKernelGGL(k_truncate, dim3(128, n_frames), dim3(256), 0, s, rb.A, rb.C, rb.np, rb.fs);
+    hipLaunchKernelGGL(k_top_step, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, step_table(s));
+    for (int lv = 1; lv < g.stages; lv++) {
+        int rx = g.nx >> lv, ry = g.ny >> lv;
+        hipLaunchKernelGGL(k_descmax, dim3(ceil_div(rx * ry, 256), n_frames), dim3(256), 0, s, rb.C, rb.D, rb.G, g,
+                           rb.np, rx, ry, rx >> 1, ry >> 1, lv > 1 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_descmax, dim3(ceil_div(g.lx * g.ly, 256), n_frames), dim3(256), 0, s, rb.C, rb.D, rb.G, g,
+                       rb.np, g.lx, g.ly, 0, 0, g.stages > 1 ? 1 : 0);
+}
+
+void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
+{
+    const Grid &g = rb.g;
+    for (int lv = g.stages - 1; lv >= 0; lv--) {                    // dwt.h:309-315
+        int nx = g.nx >> lv, ny = g.ny >> lv;
+        cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
+        rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
+    }
+}
+
+void launch_probe_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
+                        const int *d_active, hipStream_t s)
+{
+    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
+    hipLaunchKernelGGL(k_probe_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, d_active);
+    hipLaunchKernelGGL(k_probe_stats, dim3(kPartials, n_frames), dim3(256), 0, s, data, decoded, rb.A, rb.g, n_pix,
+                       rb.np, rb.fs, rb.partial, d_active);
+    hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, kPartials, rb.fs,
+                       n_frames, d_active);
+}
+
+void launch_add_residual(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
+{
+    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
+    hipLaunchKernelGGL(k_add_residual, dim3(128, n_frames), dim3(256), 0, s, out, rb.A, rb.g, n_pix, rb.np, rb.fs,
+                       d_active);
+}
+
+void launch_emit_image(float *image_out, const ResidualBuffers &rb, int n_frames, hipStream_t s)
+{
+    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
+    hipLaunchKernelGGL(k_emit_image, dim3(128, n_frames), dim3(256), 0, s, image_out, rb.A, rb.g, n_pix, rb.np, rb.fs);
+}
+
+}  // namespace ebcc

@@ -1,0 +1,741 @@
+// residual_spiht.hip - SPIHT bit-plane coder on CDNA4 wavefronts (gfx950 only).
+//
+// The reference coder (src/spiht/spiht_re.c:208-430) walks three lists sequentially; the bit order is
+// defined by list order.  Here one workgroup owns one frame and sweeps each list in chunks:
+//   - every entry's bit string depends only on coefficient data (significance of a pixel, of a
+//     descendant set via the precomputed maxima D/G), so a chunk is a data-parallel map;
+//   - bit offsets, LSP/LIP/LIS append slots and the stable compaction of survivors come from one packed
+//     exclusive scan (wave shuffles + LDS across waves);
+//   - entries appended to the LIS during a pass land behind the sweep pointer and are reached by the same
+//     sweep, which reproduces the reference's "list grows while being walked" order (spiht_re.c:237);
+//   - bits are OR-ed into an LDS window and flushed as whole big-endian words.
+// While encoding, every pixel records the ordinal of its significance bit and its LSP slot.  With the
+// per-step refinement offsets this determines the decoder state after ANY prefix of the stream, which
+// turns the reference's truncation search (17 full SPIHT decodes, ebcc_codec.c:777-795) into an
+// element-wise reconstruction per probe.
+#include "residual.hpp"
+
+namespace ebcc {
+
+namespace {
+
+constexpr int kEncThreads = 256;
+constexpr int kEncWaves = kEncThreads / kWave;
+constexpr int kHeaderBits = 120;      // IMS header incl. the 8-bit step (spiht_re.c:448-464,63)
+constexpr int kMaxEntryBits = 9;      // set bit + 4 x (significance + sign)
+constexpr int kWindowWords = (kEncThreads * kMaxEntryBits) / 32 + 4;
+
+__device__ inline int first_child(const Grid &g, int x, int y)
+{
+    int cx, cy;
+    if (x < g.lx && y < g.ly) {                                     // spiht_re.c:133-147
+        cx = (x & 1) ? x + g.lx - 1 : x;
+        cy = (y & 1) ? y + g.ly - 1 : y;
+        if (cx == x && cy == y) return -1;
+    } else {                                                        // spiht_re.c:148-154
+        cx = 2 * x; cy = 2 * y;
+        if (cx >= g.nx || cy >= g.ny) return -1;
+    }
+    return cx + cy * g.nx;
+}
+__device__ inline int first_child_of(const Grid &g, int p) { return first_child(g, p % g.nx, p / g.nx); }
+
+__device__ inline unsigned long long shfl_up_u64(unsigned long long v, int d)
+{
+    unsigned int lo = __shfl_up((unsigned int) v, d), hi = __shfl_up((unsigned int) (v >> 32), d);
+    return ((unsigned long long) hi << 32) | lo;
+}
+
+// exclusive scan of a packed counter word across the workgroup; returns the block total in `total`
+template <int NWAVES>
+__device__ inline unsigned long long block_scan(unsigned long long v, unsigned long long *wave_tot,
+                                                unsigned long long &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long y = shfl_up_u64(x, d);
+        if (lane >= d) x += y;
+    }
+    if (NWAVES == 1) {
+        unsigned int lo = __shfl((unsigned int) x, 63), hi = __shfl((unsigned int) (x >> 32), 63);
+        total = ((unsigned long long) hi << 32) | lo;
+        return x - v;
+    }
+    if (lane == 63) wave_tot[w] = x;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVES; i++) {
+        unsigned long long t = wave_tot[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + x - v;
+}
+
+// ---- bit window -------------------------------------------------------------------------------
+// `off` = 0-based index of the entry's first SPIHT bit, `limit` = number of SPIHT bits that may be
+// written in total (budget + 1, spiht_re.c:225 writes the bit that crosses the budget).
+struct BitWindow {
+    unsigned int *w;            // LDS words
+    unsigned long long base;    // absolute stream bit index of w[0] bit 31
+};
+
+__device__ inline void window_put(const BitWindow &bw, unsigned int val, int nb, unsigned long long off,
+                                  unsigned long long limit)
+{
+    if (nb == 0 || off >= limit) return;
+    if (off + nb > limit) {
+        int keep = (int) (limit - off);
+        val >>= (nb - keep);
+        nb = keep;
+    }
+    unsigned long long rel = (kHeaderBits + off) - bw.base;
+    int j = (int) (rel >> 5), sh = (int) (rel & 31);
+    unsigned long long x = (unsigned long long) val << (64 - nb - sh);
+    unsigned int hi = (unsigned int) (x >> 32), lo = (unsigned int) x;
+    if (hi) atomicOr(&bw.w[j], hi);
+    if (lo) atomicOr(&bw.w[j + 1], lo);
+}
+
+// zero the window for a chunk whose first bit has SPIHT index `first`
+__device__ inline void window_open(BitWindow &bw, unsigned long long first)
+{
+    for (int i = threadIdx.x; i < kWindowWords; i += blockDim.x) bw.w[i] = 0;
+    bw.base = ((kHeaderBits + first) >> 5) << 5;
+    __syncthreads();
+}
+
+// OR the window into the big-endian byte stream
+__device__ inline void window_flush(const BitWindow &bw, unsigned int *stream, size_t stream_words)
+{
+    __syncthreads();
+    size_t w0 = (size_t) (bw.base >> 5);
+    for (int i = threadIdx.x; i < kWindowWords; i += blockDim.x) {
+        unsigned int v = bw.w[i];
+        if (v && w0 + i < stream_words) atomicOr(&stream[w0 + i], __builtin_bswap32(v));
+    }
+    __syncthreads();
+}
+
+// ================================================================================================
+// encoder: one workgroup per frame
+// ================================================================================================
+__global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
+    const int32_t *__restrict__ Cb, const int32_t *__restrict__ Db, const int32_t *__restrict__ Gb, uint32_t *lipb,
+    uint32_t *lspb, uint32_t *lis0b, uint32_t *lis1b, uint32_t *sigordb, uint32_t *lspidxb, uint32_t *streamb,
+    size_t stream_words, Grid g, size_t np, FrameState *fsb, const unsigned long long *bits0)
+{
+    __shared__ unsigned long long wave_tot[kEncWaves];
+    __shared__ unsigned int window[kWindowWords];
+
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int32_t *C = Cb + (size_t) frame * np;
+    const int32_t *D = Db + (size_t) frame * np;
+    const int32_t *G = Gb + (size_t) frame * np;
+    uint32_t *lip = lipb + (size_t) frame * np;
+    uint32_t *lsp = lspb + (size_t) frame * np;
+    uint32_t *cur = lis0b + (size_t) frame * np;
+    uint32_t *nxt = lis1b + (size_t) frame * np;
+    uint32_t *sigord = sigordb + (size_t) frame * np;
+    uint32_t *lspidx = lspidxb + (size_t) frame * np;
+    uint32_t *stream = streamb + (size_t) frame * stream_words;
+    FrameState &fs = fsb[frame];
+
+    const unsigned long long budget = fs.budget;
+    const unsigned long long limit = budget + 1;
+    const int top = fs.top_step;
+    BitWindow bw{window, 0};
+
+    // ---- IMS header, spiht_re.c:448-464 + step byte :63 (15 bytes, written by one lane)
+    if (tid == 0) {
+        unsigned long long b0 = bits0[frame];
+        unsigned char h[16];
+        h[0] = 'I'; h[1] = 'M'; h[2] = 'S';
+        // 6b stages | 12b size_x | 12b size_y | 10b extra_x | 10b extra_y | 1b color | 29b bits0 = 80 bits
+        // first 64 of the 80 bits: everything up to the top 13 bits of bits0; the low 16 bits of bits0 follow
+        unsigned long long hi = 0;
+        hi = (hi << 6) | (unsigned) g.stages;
+        hi = (hi << 12) | (unsigned) g.size_x;
+        hi = (hi << 12) | (unsigned) g.size_y;
+        hi = (hi << 10) | (unsigned) g.extra_x;
+        hi = (hi << 10) | (unsigned) g.extra_y;
+        hi = (hi << 1) | 0u;
+        hi = (hi << 13) | ((b0 >> 16) & 0x1FFFull);
+        unsigned int lo = (unsigned int) (b0 & 0xFFFF);
+        for (int i = 0; i < 8; i++) h[3 + i] = (unsigned char) (hi >> (56 - 8 * i));
+        h[11] = (unsigned char) (lo >> 8);
+        h[12] = (unsigned char) lo;
+        h[13] = (unsigned char) (int) fs.dc;
+        h[14] = (unsigned char) top;
+        h[15] = 0;
+        for (int i = 0; i < 4; i++) {
+            unsigned int wv = h[4 * i] | (h[4 * i + 1] << 8) | (h[4 * i + 2] << 16) | ((unsigned) h[4 * i + 3] << 24);
+            atomicOr(&stream[i], wv);
+        }
+        for (int i = 0; i < 32; i++) { fs.refine_base[i] = 0; fs.refine_count[i] = 0; fs.step_reached[i] = 0; }
+    }
+
+    // ---- seed lists, spiht_re.c:65-77: LIP = LL raster order; LIS = type-A entries of LL pixels with an odd coordinate
+    unsigned int nlip = 0, nlis = 0, nlsp = 0;
+    {
+        const int nll = g.lx * g.ly;
+        for (int base = 0; base < nll; base += kEncThreads) {
+            int i = base + tid;
+            bool valid = i < nll;
+            int y = valid ? i / g.lx : 0, x = valid ? i - y * g.lx : 0;
+            unsigned int p = (unsigned int) (x + y * g.nx);
+            bool isset = valid && ((x & 1) || (y & 1));
+            unsigned long long tot;
+            unsigned long long ex = block_scan<kEncWaves>(isset ? 1ull : 0ull, wave_tot, tot);
+            if (valid) lip[i] = p;
+            if (isset) cur[nlis + (unsigned int) ex] = p << 1;           // bit0 = 0: type A
+            nlis += (unsigned int) tot;
+        }
+        nlip = (unsigned int) nll;
+    }
+    __syncthreads();
+
+    unsigned long long nbits = 0;          // SPIHT bits produced so far (uniform across the workgroup)
+    bool stop = false;
+
+    for (int s = top; s >= 0 && !stop; --s) {
+        const unsigned int n_old = nlsp;
+
+        // ---------------- LIP pass, spiht_re.c:220-234
+        {
+            unsigned int wr = 0;
+            for (unsigned int base = 0; base < nlip && !stop; base += kEncThreads) {
+                unsigned int i = base + tid;
+                bool valid = i < nlip;
+                unsigned int p = valid ? lip[i] : 0;
+                int c = valid ? C[p] : 0;
+                unsigned int a = (unsigned int) (c < 0 ? -c : c);
+                bool sig = valid && (a >> s) != 0;
+                int nb = valid ? (sig ? 2 : 1) : 0;
+                unsigned int val = sig ? (2u | (c > 0 ? 0u : 1u)) : 0u;          // sign: 0 = positive, :229
+                unsigned long long pack = (unsigned long long) nb | ((unsigned long long) (sig ? 1 : 0) << 16) |
+                                          ((unsigned long long) ((valid && !sig) ? 1 : 0) << 32);
+                unsigned long long tot;
+                unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, tot);
+                unsigned long long off = nbits + (ex & 0xFFFF);
+                window_open(bw, nbits);
+                window_put(bw, val, nb, off, limit);
+                if (sig) {
+                    unsigned int slot = nlsp + (unsigned int) ((ex >> 16) & 0xFFFF);
+                    lsp[slot] = p;
+                    sigord[p] = (uint32_t) (off + 1);
+                    lspidx[p] = slot;
+                } else if (valid) {
+                    lip[wr + (unsigned int) (ex >> 32)] = p;
+                }
+                window_flush(bw, stream, stream_words);
+                nbits += tot & 0xFFFF;
+                nlsp += (unsigned int) ((tot >> 16) & 0xFFFF);
+                wr += (unsigned int) (tot >> 32);
+                if (nbits > budget) stop = true;
+            }
+            nlip = wr;
+        }
+        if (stop) break;
+
+        // ---------------- LIS pass, spiht_re.c:237-305 (entries appended during the sweep are swept too)
+        {
+            unsigned int ncur = nlis, nnext = 0;
+            unsigned int base = 0;
+            while (base < ncur && !stop) {
+                unsigned int chunk_end = min(base + (unsigned int) kEncThreads, ncur);
+                unsigned int i = base + tid;
+                bool valid = i < chunk_end;
+                unsigned int e = valid ? cur[i] : 0;
+                unsigned int p = e >> 1;
+                bool isB = e & 1;
+                int nb = 0, n_lsp = 0, n_lip = 0, n_app = 0, surv = 0;
+                unsigned int val = 0;
+                int ch = -1;
+                int cc[4] = {0, 0, 0, 0};
+                if (valid) {
+                    if (!isB) {
+                        bool sig = (D[p] >> s) != 0;                             // is_significant_set_A, :160-182
+                        if (sig) {
+                            ch = first_child_of(g, (int) p);
+                            val = 1; nb = 1;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                int q = ch + (k & 1) + (k >> 1) * g.nx;          // :255-257 (dy outer, dx inner)
+                                int c = C[q];
+                                cc[k] = c;
+                                unsigned int a = (unsigned int) (c < 0 ? -c : c);
+                                if ((a >> s) != 0) {
+                                    val = (val << 2) | 2u | (c > 0 ? 0u : 1u);
+                                    nb += 2; n_lsp++;
+                                } else {
+                                    val <<= 1;
+                                    nb += 1; n_lip++;
+                                }
+                            }
+                            if (first_child_of(g, ch) >= 0) n_app = 1;          // :273-278
+                        } else {
+                            val = 0; nb = 1; surv = 1;
+                        }
+                    } else {
+                        bool sig = (G[p] >> s) != 0;                             // is_significant_set_B, :184-206
+                        val = sig ? 1u : 0u; nb = 1;
+                        if (sig) { ch = first_child_of(g, (int) p); n_app = 4; } // :292-300
+                        else surv = 1;
+                    }
+                }
+                unsigned long long pack = (unsigned long long) nb | ((unsigned long long) n_lsp << 12) |
+                                          ((unsigned long long) n_lip << 24) | ((unsigned long long) n_app << 36) |
+                                          ((unsigned long long) surv << 48);
+                unsigned long long tot;
+                unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, tot);
+                unsigned long long off = nbits + (ex & 0xFFF);
+                window_open(bw, nbits);
+                window_put(bw, val, nb, off, limit);
+                if (valid) {
+                    unsigned int r_lsp = nlsp + (unsigned int) ((ex >> 12) & 0xFFF);
+                    unsigned int r_lip = nlip + (unsigned int) ((ex >> 24) & 0xFFF);
+                    unsigned int r_app = ncur + (unsigned int) ((ex >> 36) & 0xFFF);
+                    unsigned int r_surv = nnext + (unsigned int) ((ex >> 48) & 0xFFF);
+                    if (!isB && ch >= 0) {
+                        unsigned long long pos = off + 1;                        // next bit after the set bit
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            unsigned int q = (unsigned int) (ch + (k & 1) + (k >> 1) * g.nx);
+                            int c = cc[k];
+                            unsigned int a = (unsigned int) (c < 0 ? -c : c);
+                            if ((a >> s) != 0) {
+                                lsp[r_lsp] = q;
+                                sigord[q] = (uint32_t) (pos + 1);
+                                lspidx[q] = r_lsp;
+                                r_lsp++;
+                                pos += 2;
+                            } else {
+                                lip[r_lip++] = q;
+                                pos += 1;
+                            }
+                        }
+                        if (n_app) cur[r_app] = (p << 1) | 1u;                   // -(p+1): type B
+                    } else if (isB && ch >= 0) {
+                        cur[r_app + 0] = (unsigned int) ch << 1;
+                        cur[r_app + 1] = (unsigned int) (ch + 1) << 1;
+                        cur[r_app + 2] = (unsigned int) (ch + g.nx) << 1;
+                        cur[r_app + 3] = (unsigned int) (ch + g.nx + 1) << 1;
+                    }
+                    if (surv) nxt[r_surv] = e;
+                }
+                window_flush(bw, stream, stream_words);
+                nbits += tot & 0xFFF;
+                nlsp += (unsigned int) ((tot >> 12) & 0xFFF);
+                nlip += (unsigned int) ((tot >> 24) & 0xFFF);
+                ncur += (unsigned int) ((tot >> 36) & 0xFFF);
+                nnext += (unsigned int) ((tot >> 48) & 0xFFF);
+                base = chunk_end;
+                if (nbits > budget) stop = true;
+            }
+            uint32_t *t = cur; cur = nxt; nxt = t;
+            nlis = nnext;
+        }
+        if (stop) break;
+
+        // ---------------- refinement pass, spiht_re.c:308-314: one bit for every LSP entry older than this step
+        if (tid == 0) {
+            fs.refine_base[s] = (unsigned int) nbits;
+            fs.refine_count[s] = n_old;
+            fs.step_reached[s] = 1;
+        }
+        for (unsigned int base = 0; base < n_old && !stop; base += kEncThreads) {
+            unsigned int i = base + tid;
+            bool valid = i < n_old;
+            unsigned int bit = 0;
+            if (valid) {
+                int c = C[lsp[i]];
+                unsigned int a = (unsigned int) (c < 0 ? -c : c);
+                bit = (a >> s) & 1u;
+            }
+            window_open(bw, nbits);
+            window_put(bw, bit, valid ? 1 : 0, nbits + tid, limit);
+            window_flush(bw, stream, stream_words);
+            nbits += min((unsigned int) kEncThreads, n_old - base);
+            if (nbits > budget) stop = true;
+        }
+    }
+
+    if (tid == 0) {
+        unsigned long long emitted = nbits < limit ? nbits : limit;
+        fs.emitted = emitted;
+        fs.stream_bytes = (unsigned int) ((kHeaderBits + emitted + 7) >> 3);     // bitio_flush, bitio.h:78-88
+    }
+}
+
+// ================================================================================================
+// reconstruct the decoder's coefficient grid after a prefix of the stream (see file header)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_reconstruct(const int32_t *__restrict__ Cb, const uint32_t *__restrict__ sigordb,
+                                                      const uint32_t *__restrict__ lspidxb, float *__restrict__ Ab,
+                                                      size_t np, const FrameState *fsb,
+                                                      const unsigned long long *trunc_bits, const int *active)
+{
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const FrameState &fs = fsb[frame];
+    // spiht_decode: num_bits = min(num_bits, bits0) - 128   (spiht_re.c:495-500)
+    unsigned long long nb = trunc_bits[frame], bits0 = fs.budget + 128;
+    if (nb > bits0) nb = bits0;
+    const unsigned long long B = nb - 128;
+    __shared__ unsigned int rbase[32], rreach[32];
+    if (threadIdx.x < 32) {
+        rbase[threadIdx.x] = fs.refine_base[threadIdx.x];
+        rreach[threadIdx.x] = fs.step_reached[threadIdx.x];
+    }
+    __syncthreads();
+    const int32_t *C = Cb + (size_t) frame * np;
+    const uint32_t *so = sigordb + (size_t) frame * np;
+    const uint32_t *li = lspidxb + (size_t) frame * np;
+    float *A = Ab + (size_t) frame * np;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (size_t) gridDim.x * blockDim.x) {
+        uint32_t o = so[i];
+        float out = 0.0f;
+        if (o != 0xFFFFFFFFu && (unsigned long long) o <= B) {
+            int c = C[i];
+            unsigned int a = (unsigned int) (c < 0 ? -c : c);
+            int ss = 31 - __clz(a);
+            unsigned int mag = 1u << ss;                                 // spiht_re.c:338,370
+            uint32_t slot = li[i];
+            for (int s = ss - 1; s >= 0; --s) {
+                if (!rreach[s]) break;
+                unsigned long long ord = (unsigned long long) rbase[s] + slot + 1;   // 1-based ordinal of the refinement bit
+                if (ord > B + 1) break;                                  // the bit crossing the budget is still applied (:418-426)
+                mag |= a & (1u << s);
+            }
+            out = c < 0 ? -(float) mag : (float) mag;
+        }
+        A[i] = out;
+    }
+}
+
+// ================================================================================================
+// decoder: one wavefront per frame; the variable-length parse of a 64-entry chunk is a uniform scalar
+// loop over a register-resident bit window, the list/coefficient updates are lane-parallel
+// ================================================================================================
+__device__ inline unsigned int load_be_word(const uint8_t *s, unsigned long long size, unsigned long long wi)
+{
+    unsigned long long b = wi * 4;
+    if (b + 4 <= size) {
+        unsigned int v = *reinterpret_cast<const unsigned int *>(s + b);
+        return __builtin_bswap32(v);
+    }
+    unsigned int v = 0;                                               // bitio.h:60-63: past the end reads as 0
+    for (int k = 0; k < 4; k++) v = (v << 8) | (b + k < size ? s[b + k] : 0u);
+    return v;
+}
+
+// uniform bit fetch from the wave-resident window (word l lives in lane l)
+__device__ inline unsigned int win_bit(unsigned int wreg, int o)
+{
+    unsigned int w = __builtin_amdgcn_readlane(wreg, __builtin_amdgcn_readfirstlane(o >> 5));
+    return (w >> (31 - (o & 31))) & 1u;
+}
+
+// per-lane fetch of up to 32 bits starting at window offset o
+__device__ inline unsigned int win_bits_lane(unsigned int wreg, int o, int n)
+{
+    unsigned int w0 = __shfl(wreg, o >> 5), w1 = __shfl(wreg, (o >> 5) + 1);
+    unsigned long long x = ((unsigned long long) w0 << 32) | w1;
+    if (n == 0) return 0;
+    return (unsigned int) ((x << (o & 31)) >> (64 - n));
+}
+
+__device__ inline unsigned int read_bits_uniform(const uint8_t *s, unsigned long long size, unsigned long long pos, int n)
+{
+    unsigned long long wi = pos >> 5;
+    unsigned long long x = ((unsigned long long) load_be_word(s, size, wi) << 32) | load_be_word(s, size, wi + 1);
+    return (unsigned int) ((x << (pos & 31)) >> (64 - n));
+}
+
+__global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restrict__ streams, size_t stream_stride,
+                                                        const unsigned long long *sizes,
+                                                        const unsigned long long *num_bits_in, int32_t *Cb,
+                                                        uint32_t *lipb, uint32_t *lspb, uint32_t *lis0b,
+                                                        uint32_t *lis1b, Grid g, size_t np, FrameState *fsb,
+                                                        const int *active)
+{
+    const int frame = blockIdx.x;
+    if (active && !active[frame]) return;
+    const int lane = threadIdx.x;
+    const uint8_t *S = streams + (size_t) frame * stream_stride;
+    const unsigned long long size = sizes[frame];
+    int32_t *C = Cb + (size_t) frame * np;
+    uint32_t *lip = lipb + (size_t) frame * np;
+    uint32_t *lsp = lspb + (size_t) frame * np;
+    uint32_t *cur = lis0b + (size_t) frame * np;
+    uint32_t *nxt = lis1b + (size_t) frame * np;
+    FrameState &fs = fsb[frame];
+
+    // header, spiht_re.c:480-503 (geometry was validated on the host against `g`)
+    unsigned long long bits0 = read_bits_uniform(S, size, 24 + 6 + 12 + 12 + 10 + 10 + 1, 29);
+    unsigned long long nbits_arg = num_bits_in[frame];
+    if (nbits_arg > bits0) nbits_arg = bits0;
+    const unsigned long long B = nbits_arg - 128;
+    const int dc = (int) read_bits_uniform(S, size, 104, 8);
+    const int top = (int) read_bits_uniform(S, size, 112, 8);
+    if (lane == 0) { fs.dec_dc = dc; fs.dec_top_step = top; fs.dec_budget = B; }
+
+    // seed lists, spiht_re.c:106-115
+    unsigned int nlip = 0, nlis = 0, nlsp = 0;
+    {
+        const int nll = g.lx * g.ly;
+        for (int base = 0; base < nll; base += kWave) {
+            int i = base + lane;
+            bool valid = i < nll;
+            int y = valid ? i / g.lx : 0, x = valid ? i - y * g.lx : 0;
+            unsigned int p = (unsigned int) (x + y * g.nx);
+            bool isset = valid && ((x & 1) || (y & 1));
+            unsigned long long m = __ballot(isset);
+            if (valid) lip[i] = p;
+            if (isset) cur[nlis + __popcll(m & ((1ull << lane) - 1))] = p << 1;
+            nlis += (unsigned int) __popcll(m);
+        }
+        nlip = (unsigned int) nll;
+    }
+
+    unsigned long long cnt = 0;            // SPIHT bits consumed (bit_cnt of the reference)
+    bool stop = false;
+    const unsigned long long lanemask_lt = (1ull << lane) - 1;
+
+    for (int s = top; s >= 0 && !stop; --s) {
+        const unsigned int n_old = nlsp;
+        const int one = 1 << s;
+
+        // ---------------- LIP pass, spiht_re.c:331-343
+        {
+            unsigned int wr = 0;
+            for (unsigned int base = 0; base < nlip && !stop; base += kWave) {
+                int m = (int) min((unsigned int) kWave, nlip - base);
+                bool valid = lane < m;
+                unsigned int p = valid ? lip[base + lane] : 0;
+                unsigned long long pos = kHeaderBits + cnt;
+                unsigned int wreg = load_be_word(S, size, (pos >> 5) + lane);
+                int o0 = (int) (pos & 31), o = o0, myoff = 0;
+                for (int j = 0; j < m; j++) {
+                    unsigned int b = win_bit(wreg, o);
+                    if (lane == j) myoff = o;
+                    o = __builtin_amdgcn_readfirstlane(o + 1 + (int) b);
+                }
+                unsigned int bits2 = win_bits_lane(wreg, myoff, 2);
+                bool sig = valid && (bits2 & 2u);
+                bool neg = bits2 & 1u;
+                unsigned long long k1 = cnt + (unsigned long long) (myoff - o0) + 1;   // ordinal of the significance bit
+                bool act = valid && k1 <= B;                                           // :334
+                bool overrun = valid && (k1 > B || (sig && k1 + 1 > B));               // :334,:339
+                unsigned long long msig = __ballot(act && sig), mkeep = __ballot(valid && !(act && sig));
+                if (act && sig) {
+                    lsp[nlsp + __popcll(msig & lanemask_lt)] = p;
+                    C[p] = neg ? -one : one;                                           // :338
+                } else if (valid) {
+                    lip[wr + __popcll(mkeep & lanemask_lt)] = p;
+                }
+                nlsp += (unsigned int) __popcll(msig);
+                wr += (unsigned int) __popcll(mkeep);
+                cnt += (unsigned long long) (o - o0);
+                __threadfence_block();
+                if (__ballot(overrun)) stop = true;
+            }
+            nlip = wr;
+        }
+        if (stop) break;
+
+        // ---------------- LIS pass, spiht_re.c:346-410
+        {
+            unsigned int ncur = nlis, nnext = 0, base = 0;
+            while (base < ncur && !stop) {
+                int m = (int) min((unsigned int) kWave, ncur - base);
+                bool valid = lane < m;
+                unsigned int e = valid ? cur[base + lane] : 0;
+                unsigned int p = e >> 1;
+                int isB = (int) (e & 1u);
+                unsigned long long pos = kHeaderBits + cnt;
+                unsigned int wreg = load_be_word(S, size, (pos >> 5) + lane);          // 64 words >= 64*9+31 bits
+                int o0 = (int) (pos & 31), o = o0, myoff = 0, mylen = 0;
+                for (int j = 0; j < m; j++) {
+                    int tb = __builtin_amdgcn_readlane(isB, j);
+                    int start = o;
+                    unsigned int sb = win_bit(wreg, o);
+                    o = __builtin_amdgcn_readfirstlane(o + 1);
+                    if (!tb && sb) {
+                        for (int k = 0; k < 4; k++) {
+                            unsigned int cb = win_bit(wreg, o);
+                            o = __builtin_amdgcn_readfirstlane(o + 1 + (int) cb);
+                        }
+                    }
+                    if (lane == j) { myoff = start; mylen = o - start; }
+                }
+                unsigned int mybits = win_bits_lane(wreg, myoff, mylen);               // MSB-first, mylen <= 9
+                unsigned long long k = cnt + (unsigned long long) (myoff - o0);        // bits consumed before this entry
+                bool setbit = valid && mylen > 0 && ((mybits >> (mylen - 1)) & 1u);
+                bool act = valid && (k + 1 <= B);                                      // :358 / :394
+                bool overrun = valid && !act;
+                int n_lsp = 0, n_lip = 0, n_app = 0, surv = 0;
+                int ch = -1;
+                unsigned int csig = 0, cneg = 0, cact = 0;                             // per-child flags
+                if (act) {
+                    if (!isB) {
+                        if (setbit) {
+                            ch = first_child_of(g, (int) p);
+                            int rem = mylen - 1;
+                            unsigned long long kk = k + 1;                              // bits consumed so far
+                            bool alive = true;
+                            for (int c = 0; c < 4; c++) {
+                                unsigned int sb = (mybits >> (rem - 1)) & 1u;
+                                kk += 1;
+                                if (alive && kk > B) { alive = false; overrun = true; }   // :367
+                                if (alive) {
+                                    cact |= 1u << c;
+                                    if (sb) {
+                                        csig |= 1u << c;
+                                        if ((mybits >> (rem - 2)) & 1u) cneg |= 1u << c;
+                                        n_lsp++;
+                                    } else {
+                                        n_lip++;
+                                    }
+                                }
+                                rem -= 1;
+                                if (sb) {
+                                    kk += 1;
+                                    rem -= 1;
+                                    if (alive && kk > B) { alive = false; overrun = true; } // :371 (value already assigned)
+                                }
+                            }
+                            if (alive && first_child_of(g, ch) >= 0) n_app = 1;
+                        } else {
+                            surv = 1;
+                        }
+                    } else {
+                        if (setbit) { ch = first_child_of(g, (int) p); n_app = 4; }
+                        else surv = 1;
+                    }
+                }
+                // wave exclusive scans of the four counters
+                unsigned int pk = (unsigned int) n_lsp | ((unsigned int) n_lip << 8) | ((unsigned int) n_app << 16) |
+                                  ((unsigned int) surv << 24);
+                // counters per lane <= 4, wave totals <= 256: use 64-bit packing to avoid carries
+                unsigned long long pack = (unsigned long long) n_lsp | ((unsigned long long) n_lip << 16) |
+                                          ((unsigned long long) n_app << 32) | ((unsigned long long) surv << 48);
+                (void) pk;
+                unsigned long long x = pack;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    unsigned long long yv = shfl_up_u64(x, d);
+                    if (lane >= d) x += yv;
+                }
+                unsigned long long tot = ((unsigned long long) __shfl((unsigned int) (x >> 32), 63) << 32) |
+                                         __shfl((unsigned int) x, 63);
+                unsigned long long ex = x - pack;
+                unsigned int r_lsp = nlsp + (unsigned int) (ex & 0xFFFF);
+                unsigned int r_lip = nlip + (unsigned int) ((ex >> 16) & 0xFFFF);
+                unsigned int r_app = ncur + (unsigned int) ((ex >> 32) & 0xFFFF);
+                unsigned int r_surv = nnext + (unsigned int) ((ex >> 48) & 0xFFFF);
+                if (act) {
+                    if (!isB && ch >= 0) {
+                        for (int c = 0; c < 4; c++) {
+                            if (!((cact >> c) & 1u)) break;
+                            unsigned int q = (unsigned int) (ch + (c & 1) + (c >> 1) * g.nx);
+                            if ((csig >> c) & 1u) {
+                                lsp[r_lsp++] = q;
+                                C[q] = ((cneg >> c) & 1u) ? -one : one;                // :370
+                            } else {
+                                lip[r_lip++] = q;
+                            }
+                        }
+                        if (n_app) cur[r_app] = (p << 1) | 1u;
+                    } else if (isB && ch >= 0) {
+                        cur[r_app + 0] = (unsigned int) ch << 1;
+                        cur[r_app + 1] = (unsigned int) (ch + 1) << 1;
+                        cur[r_app + 2] = (unsigned int) (ch + g.nx) << 1;
+                        cur[r_app + 3] = (unsigned int) (ch + g.nx + 1) << 1;
+                    }
+                    if (surv) nxt[r_surv] = e;
+                }
+                __threadfence_block();
+                nlsp += (unsigned int) (tot & 0xFFFF);
+                nlip += (unsigned int) ((tot >> 16) & 0xFFFF);
+                ncur += (unsigned int) ((tot >> 32) & 0xFFFF);
+                nnext += (unsigned int) ((tot >> 48) & 0xFFFF);
+                cnt += (unsigned long long) (o - o0);
+                base += (unsigned int) m;
+                if (__ballot(overrun)) stop = true;
+            }
+            uint32_t *t = cur; cur = nxt; nxt = t;
+            nlis = nnext;
+        }
+        if (stop) break;
+
+        // ---------------- refinement pass, spiht_re.c:413-428
+        for (unsigned int base = 0; base < n_old && !stop; base += kWave) {
+            int m = (int) min((unsigned int) kWave, n_old - base);
+            bool valid = lane < m;
+            unsigned long long pos = kHeaderBits + cnt;
+            unsigned int wreg = load_be_word(S, size, (pos >> 5) + lane);
+            int o0 = (int) (pos & 31);
+            unsigned int bit = win_bits_lane(wreg, o0 + lane, 1);
+            unsigned long long k = cnt + lane + 1;                                     // ordinal of this bit
+            bool act = valid && k <= B + 1;                                            // applied, then checked (:418-426)
+            if (act && bit) {
+                unsigned int p = lsp[base + lane];
+                int c = C[p];
+                C[p] = c >= 0 ? (c | one) : -((-c) | one);
+            }
+            cnt += (unsigned long long) m;
+            __threadfence_block();
+            if (cnt > B) stop = true;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_int_to_float(const int32_t *__restrict__ C, float *__restrict__ A, size_t np,
+                                                       const int *active)
+{
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const int32_t *c = C + (size_t) frame * np;
+    float *a = A + (size_t) frame * np;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (size_t) gridDim.x * blockDim.x)
+        a[i] = (float) c[i];
+}
+
+}  // namespace
+
+// ================================================================================================
+void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, hipStream_t s)
+{
+    EBCC_HIP_CHECK(hipMemsetAsync(rb.sigord, 0xFF, (size_t) n_frames * rb.np * sizeof(uint32_t), s));
+    EBCC_HIP_CHECK(hipMemsetAsync(rb.stream, 0, (size_t) n_frames * rb.stream_words * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_spiht_encode, dim3(n_frames), dim3(kEncThreads), 0, s, rb.C, rb.D, rb.G, rb.lip, rb.lsp,
+                       rb.lis0, rb.lis1, rb.sigord, rb.lspidx, rb.stream, rb.stream_words, rb.g, rb.np, rb.fs, d_bits0);
+}
+
+void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,
+                        const int *d_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reconstruct, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, rb.A, rb.np,
+                       rb.fs, d_trunc_bits, d_active);
+}
+
+void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const unsigned long long *d_sizes,
+                         const unsigned long long *d_num_bits, const ResidualBuffers &rb, int n_frames,
+                         const int *d_active, hipStream_t s)
+{
+    // spiht_decode_init clears the coefficient grid, spiht_re.c:101
+    EBCC_HIP_CHECK(hipMemsetAsync(rb.C, 0, (size_t) n_frames * rb.np * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_spiht_decode, dim3(n_frames), dim3(kWave), 0, s, d_streams, stream_stride, d_sizes, d_num_bits,
+                       rb.C, rb.lip, rb.lsp, rb.lis0, rb.lis1, rb.g, rb.np, rb.fs, d_active);
+    hipLaunchKernelGGL(k_int_to_float, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.A, rb.np, d_active);
+}
+
+}  // namespace ebcc

@@ -1,0 +1,87 @@
+/*
+ * ebcc_hip.h - C-ABI of the MI355X (gfx950) EBCC engine: plain pointers and sizes only.
+ *
+ * The drop-in surface of the reference is include/ebcc_codec.h (same symbols as
+ * /root/reference/src/ebcc_codec.h:41-49 plus the HDF5 plugin symbols of src/h5z_ebcc.c:14-28,38).
+ * This header is ADDITIVE: device-resident batch entry points that the reference cannot offer
+ * (its API is one host frame per call), plus unit-level entry points used by the parity tests.
+ * Every function cites the reference interface it replaces.
+ *
+ * Conventions: return 0 on success, non-zero on error (message on stderr); "d_" pointers are HIP
+ * device pointers on the context's device; all other pointers are host memory; work is enqueued on
+ * the context's stream and the call returns after the stream has been synchronised unless stated.
+ */
+#ifndef EBCC_HIP_H
+#define EBCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ebcc_codec.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+typedef struct ebcc_hip_ctx ebcc_hip_ctx;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int ebcc_hip_device_count(void);
+/* One context per (device, frame geometry); owns a HIP stream and all workspaces for up to
+ * max_frames frames of height x width.  Returns NULL on failure. */
+ebcc_hip_ctx *ebcc_hip_create(int device, size_t max_frames, size_t height, size_t width);
+void ebcc_hip_destroy(ebcc_hip_ctx *ctx);
+/* the context's hipStream_t (so callers can order their own work against it) */
+void *ebcc_hip_stream(ebcc_hip_ctx *ctx);
+size_t ebcc_hip_workspace_bytes(const ebcc_hip_ctx *ctx);
+
+/* raw device-memory helpers so that C / ctypes callers need no other HIP binding */
+void *ebcc_hip_malloc(size_t bytes);
+void ebcc_hip_free(void *d_ptr);
+int ebcc_hip_memcpy_h2d(void *d_dst, const void *src, size_t bytes);
+int ebcc_hip_memcpy_d2h(void *dst, const void *d_src, size_t bytes);
+
+/* ---- residual layer --------------------------------------------------------------------------
+ * Batch forms of spiht_encode / spiht_decode, /root/reference/src/spiht/spiht_re.h:20-21
+ * (num_stages is fixed to WAVELET_LEVELS = 3, src/ebcc_codec.c:28,748). */
+
+/* d_images: [n_frames][height][width] fp32 in [0,1].  trunc_bits[f] as in spiht_encode.
+ * out_streams[f] receives a malloc()'d byte stream of out_sizes[f] bytes (free with free_buffer). */
+int ebcc_hip_spiht_encode(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, const size_t *trunc_bits,
+                          uint8_t **out_streams, size_t *out_sizes);
+
+/* streams[f]/sizes[f]/num_bits[f] as in spiht_decode(buffer_in, input_size, ..., num_bits);
+ * d_images_out: [n_frames][height][width] fp32. */
+int ebcc_hip_spiht_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes,
+                          const size_t *num_bits, size_t n_frames, float *d_images_out);
+
+/* After ebcc_hip_spiht_encode on this context: the image spiht_decode(buf, trunc_bits/8, ..., trunc_bits)
+ * would return for a prefix of each stream, rebuilt from the encoder's bookkeeping without parsing
+ * (the device form of one probe of the truncation search, src/ebcc_codec.c:778-779). */
+int ebcc_hip_spiht_decode_prefix(ebcc_hip_ctx *ctx, size_t n_frames, const size_t *trunc_bits, float *d_images_out);
+
+/* Parity diagnostics: integer wavelet coefficients of the padded grid after load_image + sub_dc +
+ * dwt2full + normalize (src/spiht/spiht_re.c:435,461,466,467).  coeffs: host [n_frames][padded pixels],
+ * dc: host [n_frames]. */
+int ebcc_hip_spiht_coeffs(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, int32_t *coeffs, int *dc);
+size_t ebcc_hip_padded_pixels(const ebcc_hip_ctx *ctx);
+
+/* ---- frame codec -----------------------------------------------------------------------------
+ * Batch forms of ebcc_encode / ebcc_decode (src/ebcc_codec.h:41-42) for frames resident in HBM.
+ * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
+ * one frame / ebcc_encode_chunking with chunk_dims {1,H,W} produce). */
+int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
+                           uint8_t **out_streams, size_t *out_sizes);
+int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
+                           float *d_frames_out);
+
+/* last error text of the calling thread ("" if none) */
+const char *ebcc_hip_last_error(void);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBCC_HIP_H */

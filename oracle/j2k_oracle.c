@@ -257,7 +257,7 @@ static void mqe_encode(mq_t *m, int cx, int d)
         mqe_renorm(m);
     }
 }
-static int mqe_numbytes(const mq_t *m) { return (int) (m->wp - m->start) + 1 - 1 + 0 + (m->wp >= m->start ? 0 : 0) + 0 + 1 - 1; }
+static int mqe_numbytes(const mq_t *m) { return (int) (m->wp - m->start); }   /* bytes completed, excluding the one being formed */
 static void mqe_flush(mq_t *m)
 {
     /* SETBITS + two BYTEOUTs, C.2.9 */
@@ -668,6 +668,12 @@ size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *he
                     c->data = (uint8_t *) malloc((size_t) c->len + 2);
                     memcpy(c->data, p, (size_t) c->len);
                     p += c->len;
+                    if (getenv("ORC_J2K_DUMP")) {
+                        unsigned hsh = 0;
+                        for (int k = 0; k < c->len; k++) hsh = hsh * 131 + c->data[k];
+                        fprintf(stderr, "r%d b%d c%d numbps %d passes %d len %d hash %08x first %02x %02x last %02x\n", r, b, ci,
+                                c->numbps, c->npasses, c->len, hsh, c->data[0], c->len > 1 ? c->data[1] : 0, c->data[c->len - 1]);
+                    }
                     /* tier-1 + dequantisation straight into the tile buffer */
                     t1_t t1;
                     t1_alloc(&t1, c->x1 - c->x0, c->y1 - c->y0);
@@ -701,9 +707,502 @@ size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *he
     return (size_t) W * H;
 }
 
+/* ================================================================================================
+ * encoder
+ * ============================================================================================== */
+static const double NORMS_REAL[4][10] = {   /* synthesis-basis L2 norms OpenJPEG uses for the 9/7 (its 2/K convention) */
+    {1.000, 1.965, 4.177, 8.403, 16.90, 33.84, 67.69, 135.3, 270.6, 540.9},
+    {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
+    {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
+    {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2}};
+
+#define NMSEDEC_BITS 7
+#define NMSEDEC_FRACBITS 6
+static int16_t LUT_SIG[128], LUT_SIG0[128], LUT_REF[128], LUT_REF0[128];
+static int luts_ready = 0;
+static void init_luts(void)
+{
+    if (luts_ready) return;
+    /* squared-error reduction estimates (T.800 J.14.4), fixed point with 13 fractional bits */
+    for (int i = 0; i < 128; i++) {
+        double t = i / pow(2, NMSEDEC_FRACBITS), u, v;
+        int x;
+        u = t; v = t - 1.5;
+        x = (int) (floor((u * u - v * v) * pow(2, NMSEDEC_FRACBITS) + 0.5) / pow(2, NMSEDEC_FRACBITS) * 8192.0);
+        LUT_SIG[i] = (int16_t) (x > 0 ? x : 0);
+        x = (int) (floor((u * u) * pow(2, NMSEDEC_FRACBITS) + 0.5) / pow(2, NMSEDEC_FRACBITS) * 8192.0);
+        LUT_SIG0[i] = (int16_t) (x > 0 ? x : 0);
+        u = t - 1.0;
+        v = (i & (1 << (NMSEDEC_BITS - 1))) ? t - 1.5 : t - 0.5;
+        x = (int) (floor((u * u - v * v) * pow(2, NMSEDEC_FRACBITS) + 0.5) / pow(2, NMSEDEC_FRACBITS) * 8192.0);
+        LUT_REF[i] = (int16_t) (x > 0 ? x : 0);
+        x = (int) (floor((u * u) * pow(2, NMSEDEC_FRACBITS) + 0.5) / pow(2, NMSEDEC_FRACBITS) * 8192.0);
+        LUT_REF0[i] = (int16_t) (x > 0 ? x : 0);
+    }
+    luts_ready = 1;
+}
+const int16_t *orc_j2k_lut(int which) { init_luts(); return which == 0 ? LUT_SIG : which == 1 ? LUT_SIG0 : which == 2 ? LUT_REF : LUT_REF0; }
+
+static int nmsedec_sig(uint32_t x, int bpno) { return bpno > 0 ? LUT_SIG[(x >> bpno) & 127] : LUT_SIG0[x & 127]; }
+static int nmsedec_ref(uint32_t x, int bpno) { return bpno > 0 ? LUT_REF[(x >> bpno) & 127] : LUT_REF0[x & 127]; }
+
+/* ---- forward 9/7 on one interleaved line (even = low), OpenJPEG order and scaling (low/K, high*K) */
+static void fdwt_step(float *w, int a, int b, int end, int m, float c)
+{
+    /* w[a + 2i ... ] is updated from its two neighbours of the other parity */
+    float *fl = w + a, *fw = w + b + 1;
+    int imax = end < m ? end : m;
+    if (imax > 0) {
+        fw[-1] += (fl[0] + fw[0]) * c;
+        fw += 2;
+        for (int i = 1; i < imax; i++) { fw[-1] += (fw[-2] + fw[0]) * c; fw += 2; }
+    }
+    if (m < end) fw[-1] += (2 * fw[-2]) * c;
+}
+static void fdwt97_line(float *w, int sn, int dn)
+{
+    const float invK = (float) (1.0 / 1.230174105);
+    if (sn + dn <= 1) return;
+    fdwt_step(w, 0, 1, dn, dn < sn - 1 ? dn : sn - 1, DWT_ALPHA);
+    fdwt_step(w, 1, 0, sn, sn < dn ? sn : dn, DWT_BETA);
+    fdwt_step(w, 0, 1, dn, dn < sn - 1 ? dn : sn - 1, DWT_GAMMA);
+    fdwt_step(w, 1, 0, sn, sn < dn ? sn : dn, DWT_DELTA);
+    for (int i = 0; i < sn; i++) w[2 * i] *= invK;
+    for (int i = 0; i < dn; i++) w[2 * i + 1] *= DWT_K;
+}
+
+static void fdwt97_tile(float *buf, const tile_t *t)
+{
+    int W = t->W;
+    float *line = (float *) malloc((size_t) (t->W > t->H ? t->W : t->H) * sizeof(float) + 64);
+    for (int r = J2K_NRES - 1; r >= 1; r--) {
+        int rw = t->res[r].x1, rh = t->res[r].y1;
+        int sn = t->res[r - 1].y1, dn = rh - sn;
+        /* vertical pass first (opj_dwt_encode_procedure) */
+        for (int x = 0; x < rw; x++) {
+            if (rh == 1) break;
+            for (int i = 0; i < rh; i++) line[i] = buf[(size_t) i * W + x];
+            fdwt97_line(line, sn, dn);
+            for (int i = 0; i < sn; i++) buf[(size_t) i * W + x] = line[2 * i];
+            for (int i = 0; i < dn; i++) buf[(size_t) (sn + i) * W + x] = line[2 * i + 1];
+        }
+        sn = t->res[r - 1].x1; dn = rw - sn;
+        for (int y = 0; y < rh; y++) {
+            if (rw == 1) break;
+            float *row = buf + (size_t) y * W;
+            memcpy(line, row, (size_t) rw * sizeof(float));
+            fdwt97_line(line, sn, dn);
+            for (int i = 0; i < sn; i++) row[i] = line[2 * i];
+            for (int i = 0; i < dn; i++) row[sn + i] = line[2 * i + 1];
+        }
+    }
+    free(line);
+}
+
+/* ---- T1 encoder (D.3 coding passes) with OpenJPEG's distortion bookkeeping */
+typedef struct {
+    t1_t t;
+    uint32_t *mag;      /* |quantised| with 6 fractional bits */
+} t1e_t;
+
+static void t1e_sign(t1_t *t, mq_t *mq, int x, int y, int neg)
+{
+    int xb, cx = ctx_sc(t, x, y, &xb);
+    mqe_encode(mq, cx, neg ^ xb);
+    FL(t, x, y) |= F_SIG | (neg ? F_NEG : 0);
+}
+
+static void t1_encode_cblk(t1e_t *e, cblk_t *cb, int orient, int level, float stepsize)
+{
+    t1_t *t = &e->t;
+    int w = t->w, h = t->h;
+    uint32_t max = 0;
+    for (int i = 0; i < w * h; i++) if (e->mag[i] > max) max = e->mag[i];
+    cb->numbps = max ? (floorlog2((int) max) + 1) - NMSEDEC_FRACBITS : 0;
+    cb->totalpasses = 0;
+    cb->len = 0;
+    if (cb->numbps <= 0) return;            /* numbps < 0 leaves the loop below empty in OpenJPEG; same outcome */
+
+    size_t cap = (size_t) w * h * 4 + 64;
+    uint8_t *store = (uint8_t *) calloc(cap + 2, 1);
+    mq_t mq;
+    mqe_init(&mq, store + 1);
+    int bpno = cb->numbps - 1, passtype = 2, passno = 0;
+    double cum = 0;
+    for (; bpno >= 0; passno++) {
+        int nmsedec = 0;
+        uint32_t one = 1u << (bpno + NMSEDEC_FRACBITS);
+        for (int y0 = 0; y0 < h; y0 += 4) {
+            if (passtype == 0) {
+                for (int x = 0; x < w; x++)
+                    for (int y = y0; y < y0 + 4 && y < h; y++) {
+                        if ((FL(t, x, y) & (F_SIG | F_VISIT)) || !has_sig_neighbour(t, x, y)) continue;
+                        uint32_t m = e->mag[y * w + x];
+                        int v = (m & one) ? 1 : 0;
+                        mqe_encode(&mq, ctx_zc(t, x, y, orient), v);
+                        if (v) {
+                            nmsedec += nmsedec_sig(m, bpno);
+                            t1e_sign(t, &mq, x, y, t->data[y * w + x] < 0);
+                        }
+                        FL(t, x, y) |= F_VISIT;
+                    }
+            } else if (passtype == 1) {
+                for (int x = 0; x < w; x++)
+                    for (int y = y0; y < y0 + 4 && y < h; y++) {
+                        if ((FL(t, x, y) & (F_SIG | F_VISIT)) != F_SIG) continue;
+                        uint32_t m = e->mag[y * w + x];
+                        nmsedec += nmsedec_ref(m, bpno);
+                        mqe_encode(&mq, ctx_mag(t, x, y), (m & one) ? 1 : 0);
+                        FL(t, x, y) |= F_REFINED;
+                    }
+            } else {
+                for (int x = 0; x < w; x++) {
+                    int y = y0, agg = 0, partial = 0;
+                    if (y0 + 3 < h) {
+                        agg = 1;
+                        for (int k = 0; k < 4; k++)
+                            if ((FL(t, x, y0 + k) & (F_SIG | F_VISIT)) || has_sig_neighbour(t, x, y0 + k)) { agg = 0; break; }
+                    }
+                    if (agg) {
+                        int runlen = 0;
+                        for (; runlen < 4; runlen++)
+                            if (e->mag[(y0 + runlen) * w + x] & one) break;
+                        mqe_encode(&mq, CTX_AGG, runlen != 4);
+                        if (runlen == 4) continue;
+                        mqe_encode(&mq, CTX_UNI, runlen >> 1);
+                        mqe_encode(&mq, CTX_UNI, runlen & 1);
+                        y = y0 + runlen;
+                        partial = 1;
+                    }
+                    for (; y < y0 + 4 && y < h; y++) {
+                        if (!partial && (FL(t, x, y) & (F_SIG | F_VISIT))) continue;
+                        uint32_t m = e->mag[y * w + x];
+                        int v = (m & one) ? 1 : 0;
+                        if (!partial) mqe_encode(&mq, ctx_zc(t, x, y, orient), v);
+                        partial = 0;
+                        if (v) {
+                            nmsedec += nmsedec_sig(m, bpno);
+                            t1e_sign(t, &mq, x, y, t->data[y * w + x] < 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (passtype == 2)
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) FL(t, x, y) &= (uint8_t) ~F_VISIT;
+
+        /* opj_t1_getwmsedec */
+        /* the distortion weight uses the step WITHOUT the sub-band gain (OpenJPEG keeps its pre-2.4 behaviour) */
+        double st = (double) stepsize / (double) (1 << (orient == 0 ? 0 : (orient == 3 ? 2 : 1)));
+        double wm = 1.0 * NORMS_REAL[orient][level] * st * (double) (1 << bpno);
+        wm *= wm * nmsedec / 8192.0;
+        cum += wm;
+        cb->disto[passno] = cum;
+        if (passtype == 2 && bpno == 0) {                  /* the only terminated pass with cblksty 0 */
+            mqe_flush(&mq);
+            cb->rate[passno] = mqe_numbytes(&mq);
+        } else {
+            cb->rate[passno] = (int) ((uint32_t) mqe_numbytes(&mq) + 3u);
+        }
+        if (++passtype == 3) { passtype = 0; bpno--; }
+    }
+    cb->totalpasses = passno;
+    /* pass rates must be non-decreasing and never end on 0xFF */
+    int last = mqe_numbytes(&mq);
+    for (int p = passno; p > 0;) {
+        --p;
+        if (cb->rate[p] > last) cb->rate[p] = last; else last = cb->rate[p];
+    }
+    uint8_t *bytes = store + 1;
+    for (int p = 0; p < passno; p++)
+        if (cb->rate[p] > 0 && bytes[cb->rate[p] - 1] == 0xFF) cb->rate[p]--;
+    cb->len = mqe_numbytes(&mq);
+    cb->data = (uint8_t *) malloc((size_t) cb->len + 1);
+    memcpy(cb->data, bytes, (size_t) cb->len);
+    free(store);
+}
+
+/* ---- bit writer (B.10.1) and tag-tree encoder (B.10.2) */
+typedef struct { uint8_t *start, *p, *end; uint32_t buf; int ct; int ok; } biow_t;
+static void biow_init(biow_t *b, uint8_t *p, size_t len) { b->start = b->p = p; b->end = p + len; b->buf = 0; b->ct = 8; b->ok = 1; }
+static int biow_byteout(biow_t *b)
+{
+    b->buf = (b->buf << 8) & 0xFFFF;
+    b->ct = b->buf == 0xFF00 ? 7 : 8;
+    if (b->p >= b->end) { b->ok = 0; return 0; }
+    *b->p++ = (uint8_t) (b->buf >> 8);
+    return 1;
+}
+static void biow_bit(biow_t *b, int v)
+{
+    if (b->ct == 0) biow_byteout(b);
+    b->ct--;
+    b->buf |= (uint32_t) (v & 1) << b->ct;
+}
+static void biow_bits(biow_t *b, uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) biow_bit(b, (int) ((v >> i) & 1)); }
+static int biow_flush(biow_t *b)
+{
+    if (!biow_byteout(b)) return 0;
+    if (b->ct == 7 && !biow_byteout(b)) return 0;
+    return b->ok;
+}
+static void tgt_reset(tgt_t *t) { for (int i = 0; i < t->nnodes; i++) { t->nodes[i].value = 999; t->nodes[i].low = 0; t->nodes[i].known = 0; } }
+static void tgt_setvalue(tgt_t *t, int leaf, int value)
+{
+    tgnode_t *n = &t->nodes[leaf];
+    while (n && n->value > value) { n->value = value; n = n->parent; }
+}
+static void tgt_encode(biow_t *b, tgt_t *t, int leaf, int threshold)
+{
+    tgnode_t *stk[32], **sp = stk, *node = &t->nodes[leaf];
+    while (node->parent) { *sp++ = node; node = node->parent; }
+    int low = 0;
+    for (;;) {
+        if (low > node->low) node->low = low; else low = node->low;
+        while (low < threshold) {
+            if (low >= node->value) {
+                if (!node->known) { biow_bit(b, 1); node->known = 1; }
+                break;
+            }
+            biow_bit(b, 0);
+            ++low;
+        }
+        node->low = low;
+        if (sp == stk) break;
+        node = *--sp;
+    }
+}
+static void put_numpasses(biow_t *b, int n)
+{
+    if (n == 1) biow_bits(b, 0, 1);
+    else if (n == 2) biow_bits(b, 2, 2);
+    else if (n <= 5) biow_bits(b, 0xC | (uint32_t) (n - 3), 4);
+    else if (n <= 36) biow_bits(b, 0x1E0 | (uint32_t) (n - 6), 9);
+    else biow_bits(b, 0xFF80 | (uint32_t) (n - 37), 16);
+}
+
+/* One LRCP pass over the tile for a single layer: writes all packets, returns bytes or -1 if they do not fit. */
+static long t2_encode(tile_t *t, uint8_t *dest, size_t maxlen, int final)
+{
+    uint8_t *c = dest;
+    size_t length = maxlen;
+    for (int r = 0; r < J2K_NRES; r++) {
+        res_t *rs = &t->res[r];
+        tgt_t *incl[3] = {0}, *imsb[3] = {0};
+        int empty = 1;
+        for (int b = 0; b < rs->nbands; b++) {
+            band_t *bd = &rs->bands[b];
+            int nc = bd->ncw * bd->nch;
+            if (!nc) continue;
+            incl[b] = tgt_create(bd->ncw, bd->nch);
+            imsb[b] = tgt_create(bd->ncw, bd->nch);
+            tgt_reset(incl[b]); tgt_reset(imsb[b]);
+            for (int ci = 0; ci < nc; ci++) {
+                cblk_t *cb = &bd->cblks[ci];
+                tgt_setvalue(imsb[b], ci, bd->numbps - cb->numbps);
+                if (cb->npasses) empty = 0;
+            }
+        }
+        biow_t bio;
+        biow_init(&bio, c, length);
+        (void) empty;
+        biow_bit(&bio, 1);                       /* OpenJPEG 2.4.0 never signals an empty packet */
+        {
+            for (int b = 0; b < rs->nbands; b++) {
+                band_t *bd = &rs->bands[b];
+                int nc = bd->ncw * bd->nch;
+                if (!nc) continue;
+                for (int ci = 0; ci < nc; ci++)
+                    if (bd->cblks[ci].npasses) tgt_setvalue(incl[b], ci, 0);
+                for (int ci = 0; ci < nc; ci++) {
+                    cblk_t *cb = &bd->cblks[ci];
+                    tgt_encode(&bio, incl[b], ci, 1);
+                    if (!cb->npasses) continue;
+                    cb->numlenbits = 3;
+                    tgt_encode(&bio, imsb[b], ci, 999);
+                    put_numpasses(&bio, cb->npasses);
+                    int seglen = cb->rate[cb->npasses - 1];
+                    int inc = floorlog2(seglen) + 1 - (cb->numlenbits + floorlog2(cb->npasses));
+                    if (inc < 0) inc = 0;
+                    for (int k = 0; k < inc; k++) biow_bit(&bio, 1);       /* comma code */
+                    biow_bit(&bio, 0);
+                    cb->numlenbits += inc;
+                    biow_bits(&bio, (uint32_t) seglen, cb->numlenbits + floorlog2(cb->npasses));
+                }
+            }
+        }
+        int ok = biow_flush(&bio);
+        for (int b = 0; b < 3; b++) { tgt_free(incl[b]); tgt_free(imsb[b]); }
+        if (!ok) return -1;
+        size_t nb = (size_t) (bio.p - bio.start);
+        c += nb; length -= nb;
+        for (int b = 0; b < rs->nbands; b++) {
+            band_t *bd = &rs->bands[b];
+            for (int ci = 0; ci < bd->ncw * bd->nch; ci++) {
+                cblk_t *cb = &bd->cblks[ci];
+                if (!cb->npasses) continue;
+                size_t sl = (size_t) cb->rate[cb->npasses - 1];
+                if (sl > length) return -1;
+                if (final) memcpy(c, cb->data, sl);
+                c += sl; length -= sl;
+            }
+        }
+    }
+    return (long) (c - dest);
+}
+
+/* opj_tcd_makelayer for the single layer: choose the number of passes per code-block for a slope threshold */
+static void make_layer(tile_t *t, double thresh)
+{
+    for (int r = 0; r < J2K_NRES; r++)
+        for (int b = 0; b < t->res[r].nbands; b++) {
+            band_t *bd = &t->res[r].bands[b];
+            for (int ci = 0; ci < bd->ncw * bd->nch; ci++) {
+                cblk_t *cb = &bd->cblks[ci];
+                int n = 0;
+                if (thresh < 0) n = cb->totalpasses;             /* "use all passes" */
+                else for (int p = 0; p < cb->totalpasses; p++) {
+                    uint32_t dr; double dd;
+                    if (n == 0) { dr = (uint32_t) cb->rate[p]; dd = cb->disto[p]; }
+                    else { dr = (uint32_t) (cb->rate[p] - cb->rate[n - 1]); dd = cb->disto[p] - cb->disto[n - 1]; }
+                    if (!dr) { if (dd != 0) n = p + 1; continue; }
+                    if (thresh - (dd / dr) < DBL_EPSILON) n = p + 1;
+                }
+                cb->npasses = n;
+            }
+        }
+}
+
 size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
 {
-    (void) img; (void) height; (void) width; (void) base_cr; (void) out;
-    (void) mqe_init; (void) mqe_encode; (void) mqe_flush; (void) mqe_numbytes;
-    return 0;
+    init_luts();
+    const int W = (int) width, H = (int) height, prec = 16, guard = 2;
+    tile_t t;
+    tile_init(&t, W, H);
+
+    /* QCD step sizes: opj_dwt_calc_explicit_stepsizes + encode_stepsize */
+    int expn[3 * J2K_NRES - 2], mant[3 * J2K_NRES - 2];
+    for (int bi = 0; bi < 3 * J2K_NRES - 2; bi++) {
+        int resno = bi == 0 ? 0 : (bi - 1) / 3 + 1, orient = bi == 0 ? 0 : (bi - 1) % 3 + 1;
+        int level = J2K_NRES - 1 - resno;
+        double stepsize = 1.0 / NORMS_REAL[orient][level];
+        int v = (int) floor(stepsize * 8192.0);
+        int p = floorlog2(v) - 13, n = 11 - floorlog2(v);
+        mant[bi] = (n < 0 ? v >> -n : v << n) & 0x7FF;
+        expn[bi] = prec - p;
+    }
+    for (int r = 0; r < J2K_NRES; r++)
+        for (int b = 0; b < t.res[r].nbands; b++) {
+            band_t *bd = &t.res[r].bands[b];
+            int bi = r == 0 ? 0 : 3 * (r - 1) + b + 1;
+            band_set_quant(bd, expn[bi], mant[bi], prec, guard);
+            /* encoder-side step carries the sub-band gain (OpenJPEG pairs this with its 2/K synthesis scaling) */
+            int log2_gain = bd->orient == 0 ? 0 : (bd->orient == 3 ? 2 : 1);
+            bd->stepsize = (float) ((1.0 + mant[bi] / 2048.0) * pow(2.0, (double) (prec + log2_gain - expn[bi])));
+        }
+
+    /* DC level shift to float, forward transform */
+    float *buf = (float *) malloc((size_t) W * H * sizeof(float));
+    for (size_t i = 0; i < (size_t) W * H; i++) buf[i] = (float) ((int) img[i] - (1 << (prec - 1)));
+    fdwt97_tile(buf, &t);
+
+    /* tier-1 */
+    for (int r = 0; r < J2K_NRES; r++)
+        for (int b = 0; b < t.res[r].nbands; b++) {
+            band_t *bd = &t.res[r].bands[b];
+            for (int ci = 0; ci < bd->ncw * bd->nch; ci++) {
+                cblk_t *cb = &bd->cblks[ci];
+                t1e_t e;
+                int w = cb->x1 - cb->x0, h = cb->y1 - cb->y0;
+                t1_alloc(&e.t, w, h);
+                e.mag = (uint32_t *) malloc((size_t) w * h * sizeof(uint32_t));
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) {
+                        float cf = buf[(size_t) (bd->offy + cb->y0 - bd->y0 + y) * W + bd->offx + cb->x0 - bd->x0 + x];
+                        int q = (int) lrintf((cf / bd->stepsize) * (float) (1 << NMSEDEC_FRACBITS));
+                        e.t.data[y * w + x] = q;
+                        e.mag[y * w + x] = (uint32_t) (q < 0 ? -q : q);
+                    }
+                t1_encode_cblk(&e, cb, bd->orient, bd->level, bd->stepsize);
+                free(e.mag);
+                t1_free(&e.t);
+            }
+        }
+    free(buf);
+
+    /* main header (A.5.1, A.6.1, A.6.4, A.9.2) */
+    static const char comment[] = "Created by OpenJPEG version 2.4.0";
+    size_t cap = 1024 + (size_t) W * H * 4;
+    uint8_t *o = (uint8_t *) calloc(cap, 1), *p = o;
+#define PUT16(v) do { *p++ = (uint8_t) ((v) >> 8); *p++ = (uint8_t) (v); } while (0)
+#define PUT32(v) do { PUT16((uint32_t) (v) >> 16); PUT16((uint32_t) (v) & 0xFFFF); } while (0)
+    PUT16(0xFF4F);
+    PUT16(0xFF51); PUT16(41); PUT16(0); PUT32(W); PUT32(H); PUT32(0); PUT32(0); PUT32(W); PUT32(H); PUT32(0); PUT32(0);
+    PUT16(1); *p++ = (uint8_t) (prec - 1); *p++ = 1; *p++ = 1;
+    PUT16(0xFF52); PUT16(12); *p++ = 0; *p++ = 0; PUT16(1); *p++ = 0; *p++ = J2K_NRES - 1; *p++ = 4; *p++ = 4; *p++ = 0; *p++ = 0;
+    PUT16(0xFF5C); PUT16(3 + 2 * (3 * J2K_NRES - 2)); *p++ = (uint8_t) (2 + (guard << 5));
+    for (int bi = 0; bi < 3 * J2K_NRES - 2; bi++) PUT16((uint32_t) ((expn[bi] << 11) | mant[bi]));
+    PUT16(0xFF64); PUT16(4 + (int) strlen(comment)); PUT16(1);
+    memcpy(p, comment, strlen(comment)); p += strlen(comment);
+    size_t main_hdr = (size_t) (p - o);
+
+    /* rate target: opj_j2k_setup_encoder + opj_j2k_update_rates (single tile, single layer) */
+    float rate = base_cr / 2;
+    if (rate <= 1.0f) rate = 0.0f;                               /* lossless: keep every pass */
+    if (rate > 0.0f) {
+        rate = (float) (((double) prec * (double) W * (double) H) / ((double) rate * 8.0)) - 0.0f;
+        rate -= (float) main_hdr / 1.0f;
+        if (rate < 30.0f) rate = 30.0f;
+    }
+
+    /* PCRD: opj_tcd_rateallocate */
+    double smin = DBL_MAX, smax = 0;
+    for (int r = 0; r < J2K_NRES; r++)
+        for (int b = 0; b < t.res[r].nbands; b++) {
+            band_t *bd = &t.res[r].bands[b];
+            for (int ci = 0; ci < bd->ncw * bd->nch; ci++) {
+                cblk_t *cb = &bd->cblks[ci];
+                for (int ps = 0; ps < cb->totalpasses; ps++) {
+                    int dr; double dd;
+                    if (ps == 0) { dr = cb->rate[0]; dd = cb->disto[0]; }
+                    else { dr = cb->rate[ps] - cb->rate[ps - 1]; dd = cb->disto[ps] - cb->disto[ps - 1]; }
+                    if (dr == 0) continue;
+                    double slope = dd / dr;
+                    if (slope < smin) smin = slope;
+                    if (slope > smax) smax = slope;
+                }
+            }
+        }
+    uint8_t *sot = p;
+    p += 12 + 2;
+    size_t room = cap - (size_t) (p - o) - 2;
+    double good = -1;                                            /* rate 0: every pass */
+    if (rate > 0.0f) {
+        size_t maxlen = (size_t) ceil(rate);
+        if (maxlen > room) maxlen = room;
+        double lo = smin, hi = smax, thresh = 0, stable = 0;
+        for (int i = 0; i < 128; i++) {
+            thresh = (lo + hi) / 2;
+            make_layer(&t, thresh);
+            if (t2_encode(&t, p, maxlen, 0) < 0) { lo = thresh; continue; }
+            hi = thresh;
+            stable = thresh;
+        }
+        good = stable == 0 ? thresh : stable;
+    }
+    make_layer(&t, good);
+    long body = t2_encode(&t, p, room, 1);
+    if (body < 0) { free(o); tile_free(&t); return 0; }
+    p += body;
+    /* SOT (A.4.2) / SOD */
+    uint8_t *q = sot, *save = p;
+    p = q;
+    PUT16(0xFF90); PUT16(10); PUT16(0); PUT32(12 + 2 + body); *p++ = 0; *p++ = 1;
+    PUT16(0xFF93);
+    p = save;
+    PUT16(0xFFD9);
+    tile_free(&t);
+    *out = o;
+    return (size_t) (p - o);
 }

@@ -1,0 +1,134 @@
+"""CPU tests: the oracle (oracle/*.c) against the committed golden vectors that were produced by the
+reference build (oracle/make_golden.py), and - when that build is present (dev container) - directly
+against it.  Bit-exact everywhere."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _lib as L
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def load(name):
+    return json.load(open(os.path.join(L.GOLDEN, name)))
+
+
+@pytest.mark.parametrize("kat", load("spiht_kat.json"), ids=lambda k: f"{k['h']}x{k['w']}")
+def test_spiht_known_answers(kat):
+    img = L.kat_image(kat["h"], kat["w"])
+    s = L.orc_spiht_encode(img, kat["trunc_bits"])
+    assert len(s) == kat["n"]
+    assert sha(s) == kat["stream_sha256"]
+    if "stream_hex" in kat:
+        assert s.hex() == kat["stream_hex"]
+    dec = L.orc_spiht_decode(s, kat["h"], kat["w"])
+    assert sha(dec.tobytes()) == kat["decoded_sha256"]
+
+
+def test_survey_kat_prefixes():
+    """SURVEY.md section 8(c) table (sha256 prefixes measured from the reference build)."""
+    want = {(32, 32, 4096): ("6a538f1114869faa910aebb7", 528), (33, 47, 8192): ("ab343752056b65205b692fa8", 1040),
+            (64, 64, 0): ("812a615043f9590d1beaad27", 4249)}
+    for (h, w, tb), (pre, n) in want.items():
+        s = L.orc_spiht_encode(L.kat_image(h, w), tb)
+        assert len(s) == n and sha(s).startswith(pre)
+
+
+def test_spiht_truncated_decode_edge_cases():
+    img = L.smooth_image(40, 56, 1)
+    s = L.orc_spiht_encode(img, 6000)
+    for nbytes in (17, 18, 40, len(s) // 2, len(s)):
+        d = L.orc_spiht_decode(s[:nbytes], 40, 56, 8 * nbytes)
+        assert d.shape == (40, 56) and np.isfinite(d).all() and d.min() >= 0 and d.max() <= 1
+    # monotone quality: the full stream is at least as good as a short prefix
+    e_full = np.abs(L.orc_spiht_decode(s, 40, 56) - img).mean()
+    e_short = np.abs(L.orc_spiht_decode(s[:40], 40, 56, 320) - img).mean()
+    assert e_full <= e_short
+
+
+_streams = load("codec_streams.json")
+_inputs = np.load(os.path.join(L.GOLDEN, "codec_inputs.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(_streams), ids=str)
+def test_frame_codec_streams(name, monkeypatch):
+    c = _streams[name]
+    if c["quantile"] is None:
+        monkeypatch.delenv("EBCC_INIT_BASE_ERROR_QUANTILE", raising=False)
+    else:
+        monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", c["quantile"])
+    L.oracle().orc_set_j2k_backend(0)
+    cfg = L.make_config((1, c["h"], c["w"]), base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+    want = bytes.fromhex(c["stream_hex"])
+    got = L.orc_encode(_inputs[c["input"]], cfg)
+    assert got == want
+    dec = L.orc_decode(want)
+    assert sha(dec.tobytes()) == c["decoded_sha256"]
+
+
+def test_residual_branch_is_exercised():
+    assert sum(1 for c in _streams.values() if c["coeffs_size"] > 0) >= 4
+
+
+def _make_data(shape):
+    idx = np.indices(shape, dtype=np.float32)
+    return np.ascontiguousarray(idx[0] * 100.0 + idx[1] * 1.5 + idx[2] * 0.25, dtype=np.float32)
+
+
+@pytest.mark.parametrize("name", sorted(load("ebck.json")), ids=str)
+def test_ebck_containers(name):
+    c = load("ebck.json")[name]
+    shape, chunk = tuple(c["shape"]), tuple(c["chunk"])
+    cfg = L.make_config(shape, chunk if any(chunk) else None, base_cr=2.0, error=c["error"], residual_type=c["mode"])
+    L.oracle().orc_set_j2k_backend(0)
+    s = L.orc_encode(_make_data(shape), cfg, "orc_" + c["fn"])
+    assert len(s) == c["n"] and sha(s) == c["stream_sha256"]
+    d = L.orc_decode(s, "orc_ebcc_decode_chunking")
+    assert sha(d.tobytes()) == c["decoded_sha256"]
+    # header fields, reference tests/test_c_api.py:182-188
+    assert s[:4] == b"EBCK"
+    ver, ndims = np.frombuffer(s[4:12], np.uint32)
+    dims = tuple(int(v) for v in np.frombuffer(s[16:40], np.uint64))
+    assert ver == 1 and ndims == 3 and dims == shape
+
+
+@pytest.mark.skipif(not os.path.exists(L.REF_SO), reason="reference build only exists in the dev container")
+def test_j2k_restatement_matches_openjpeg_live():
+    lib = L.oracle()
+    if not hasattr(lib, "orc_opj_encode"):
+        pytest.skip("oracle built without the OpenJPEG backend")
+
+    def enc(fn, img, cr):
+        out = ctypes.c_void_p()
+        n = fn(img.ctypes.data, img.shape[0], img.shape[1], ctypes.c_float(cr), ctypes.byref(out))
+        s = ctypes.string_at(out.value, n)
+        lib.orc_free(out)
+        return s
+
+    for h, w in [(32, 32), (45, 70), (100, 130)]:
+        f = L.era5_like(h, w, h + w)
+        img = np.ascontiguousarray((((f - f.min()) / (f.max() - f.min())) * np.float32(65535)).astype(np.uint16))
+        for cr in (1.0, 4.0, 17.0, 60.0, 900.0):
+            assert enc(lib.orc_opj_encode, img, cr) == enc(lib.orc_j2k_encode, img, cr), (h, w, cr)
+
+
+def test_j2k_nmsedec_tables_match_openjpeg_binary_dump():
+    """Spot values read from the rodata of libopenjp2 2.4.0 (lut_nmsedec_*), kept as literals."""
+    lib = L.oracle()
+    lib.orc_j2k_lut.restype = ctypes.POINTER(ctypes.c_int16)
+    sig = [lib.orc_j2k_lut(0)[i] for i in range(128)]
+    sig0 = [lib.orc_j2k_lut(1)[i] for i in range(128)]
+    ref = [lib.orc_j2k_lut(2)[i] for i in range(128)]
+    ref0 = [lib.orc_j2k_lut(3)[i] for i in range(128)]
+    assert sig[:20] == [0] * 20 and sig[-6:] == [28416, 28800, 29184, 29568, 29952, 30336]
+    assert sig0[:20] == [0, 0, 0, 0, 0, 0, 128, 128, 128, 128, 256, 256, 256, 384, 384, 512, 512, 640, 640, 768]
+    assert sig0[-6:] == [29824, 30208, 30720, 31232, 31744, 32256]
+    assert ref[:4] == [6144, 6016, 5888, 5760] and ref[-6:] == [5376, 5504, 5632, 5760, 5888, 6016]
+    assert ref0[:4] == [8192, 7936, 7680, 7424] and ref0[-6:] == [6784, 6912, 7168, 7424, 7680, 7936]

@@ -1,6 +1,7 @@
 // engine.hpp - per-device context of the MI355X EBCC engine.
 #pragma once
 
+#include <cstdint>
 #include <string>
 #include <vector>
 

@@ -1,6 +1,294 @@
-// j2k.hip - JPEG 2000 base layer on device (placeholder until the kernels land)
+// j2k.hip - base-layer buffers of a context, host-side codestream parsing for the decode path and the
+// unit-level C-ABI entry points of the JPEG 2000 layer (include/ebcc_hip.h).
+#include <cstring>
+#include <vector>
+
+#include "../../include/ebcc_hip.h"
 #include "engine.hpp"
+#include "j2k.hpp"
+
 namespace ebcc {
-bool j2k_create(ebcc_hip_ctx *) { return true; }
-void j2k_destroy(ebcc_hip_ctx *) {}
+
+bool j2k_create(ebcc_hip_ctx *ctx)
+{
+    J2kBuffers *jb = new J2kBuffers();
+    ctx->j2k = jb;
+    std::vector<J2kBlock> blocks;
+    jb->geom = make_j2k_geom(ctx->height, ctx->width, blocks);
+    const J2kGeom &g = jb->geom;
+    const size_t n_pix = ctx->n_pix, F = ctx->max_frames;
+    const size_t total = F * g.nblocks, groups = (total + 63) / 64;
+    jb->max_frames = (int) F;
+    jb->fs = ctx->rb.fs;
+    // the largest codestream keeps every pass: bounded by the code-block slots; 2 bytes/sample is far above
+    // anything the 9/7 + MQ coder emits for 16-bit data, and the writer never exceeds the slots it copies from
+    jb->stream_cap = ((n_pix * 3 + 4096 + 63) / 64) * 64;
+    bool ok = true;
+    ok &= (jb->d_geom = (J2kGeom *) ctx_alloc<uint8_t>(ctx, sizeof(J2kGeom))) != nullptr;
+    ok &= (jb->d_blocks = (J2kBlock *) ctx_alloc<uint8_t>(ctx, sizeof(J2kBlock) * blocks.size())) != nullptr;
+    ok &= (jb->d_blkmap = ctx_alloc<uint16_t>(ctx, n_pix)) != nullptr;
+    ok &= (jb->B = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
+    ok &= (jb->Q6 = ctx_alloc<int32_t>(ctx, F * n_pix)) != nullptr;
+    ok &= (jb->DEC = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
+    ok &= (jb->V = ctx_alloc<int32_t>(ctx, F * n_pix)) != nullptr;
+    ok &= (jb->BP = ctx_alloc<unsigned long long>(ctx, groups * kJ2kMaxPlanes * 64 * 64)) != nullptr;
+    ok &= (jb->SGN = ctx_alloc<unsigned long long>(ctx, groups * 64 * 64)) != nullptr;
+    ok &= (jb->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;
+    ok &= (jb->blkmax = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->numbps = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->totalpasses = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->cblk_len = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->npass = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->rates = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
+    ok &= (jb->disto = ctx_alloc<double>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
+    ok &= (jb->cblk_bytes = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kCblkBytes)) != nullptr;
+    ok &= (jb->stream = ctx_alloc<uint8_t>(ctx, F * jb->stream_cap)) != nullptr;
+    ok &= (jb->dec_table = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * 4)) != nullptr;
+    ok &= (jb->jf = (J2kFrame *) ctx_alloc<uint8_t>(ctx, sizeof(J2kFrame) * F)) != nullptr;
+    ok &= (jb->partial = ctx_alloc<double>(ctx, F * kPartials)) != nullptr;
+    ok &= (jb->partial_u = ctx_alloc<unsigned long long>(ctx, F * kPartials)) != nullptr;
+    if (!ok) return false;
+    if (g.nblocks >= 65535) { set_error("too many code-blocks"); return false; }
+    std::vector<uint16_t> map(n_pix, 0);
+    for (size_t b = 0; b < blocks.size(); b++)
+        for (int y = 0; y < blocks[b].h; y++)
+            for (int x = 0; x < blocks[b].w; x++) map[(size_t) (blocks[b].y + y) * g.W + blocks[b].x + x] = (uint16_t) b;
+    hipStream_t s = ctx->stream;
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_geom, &jb->geom, sizeof(J2kGeom), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blocks, blocks.data(), sizeof(J2kBlock) * blocks.size(), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blkmap, map.data(), n_pix * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return true;
 }
+
+void j2k_destroy(ebcc_hip_ctx *ctx)
+{
+    delete static_cast<J2kBuffers *>(ctx->j2k);
+    ctx->j2k = nullptr;
+}
+
+// ================================================================================================
+// host-side codestream parsing (main header + tier-2 packet headers, T.800 Annex A / B.10) for the
+// decode path: fills {offset, length, numbps, npasses} per code-block.  Serial and tiny (~300
+// code-blocks per frame); tier-1 and everything per-sample runs on the device.
+// ================================================================================================
+namespace {
+
+struct BitReader {
+    const uint8_t *p, *end;
+    unsigned buf = 0;
+    int ct = 0;
+    int bit()
+    {
+        if (ct == 0) {
+            buf = (buf << 8) & 0xFFFF;
+            ct = buf == 0xFF00 ? 7 : 8;
+            if (p < end) buf |= *p++;
+        }
+        ct--;
+        return (buf >> ct) & 1;
+    }
+    int bits(int n) { int v = 0; for (int i = n - 1; i >= 0; i--) v |= bit() << i; return v; }
+    void align() { if ((buf & 0xFF) == 0xFF && p < end) p++; ct = 0; }
+};
+
+struct HostTree {
+    const J2kBand *bd;
+    std::vector<int> val, low;
+    explicit HostTree(const J2kBand &b) : bd(&b)
+    {
+        int n = 0;
+        for (int l = 0; l < b.tree_levels; l++) n += b.lvl_w[l] * b.lvl_h[l];
+        val.assign(n, 999); low.assign(n, 0);
+    }
+    bool decode(BitReader &br, int cx, int cy, int threshold)
+    {
+        int lowv = 0, idx = 0;
+        for (int l = bd->tree_levels - 1; l >= 0; l--) {
+            idx = bd->lvl_off[l] + (cy >> l) * bd->lvl_w[l] + (cx >> l);
+            if (lowv > low[idx]) low[idx] = lowv; else lowv = low[idx];
+            while (lowv < threshold && lowv < val[idx]) {
+                if (br.bit()) val[idx] = lowv; else ++lowv;
+            }
+            low[idx] = lowv;
+        }
+        return val[idx] < threshold;
+    }
+};
+
+unsigned be16(const uint8_t *p) { return ((unsigned) p[0] << 8) | p[1]; }
+unsigned be32(const uint8_t *p) { return ((unsigned) p[0] << 24) | ((unsigned) p[1] << 16) | ((unsigned) p[2] << 8) | p[3]; }
+int flog2(int a) { int l = 0; while (a > 1) { a >>= 1; l++; } return l; }
+
+}  // namespace
+
+// returns false on a malformed / unsupported codestream
+bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table /* [nblocks][4] */)
+{
+    if (n < 4 || be16(cs) != 0xFF4F) { set_error("J2K: missing SOC"); return false; }
+    size_t pos = 2;
+    int W = 0, H = 0, nres = 0, qsty = -1, guard = 0;
+    int expn[kJ2kBands] = {0}, mant[kJ2kBands] = {0};
+    const uint8_t *tile_data = nullptr, *tile_end = nullptr;
+    while (pos + 4 <= n) {
+        unsigned mk = be16(cs + pos), len = be16(cs + pos + 2);
+        const uint8_t *p = cs + pos + 4;
+        if (pos + 2 + len > n) { set_error("J2K: truncated marker segment"); return false; }
+        if (mk == 0xFF51) { W = (int) (be32(p + 2) - be32(p + 10)); H = (int) (be32(p + 6) - be32(p + 14)); }
+        else if (mk == 0xFF52) nres = p[5] + 1;
+        else if (mk == 0xFF5C) {
+            qsty = p[0] & 0x1F; guard = p[0] >> 5;
+            int nb = (int) (len - 3) / 2;
+            for (int i = 0; i < nb && i < kJ2kBands; i++) { unsigned v = be16(p + 1 + 2 * i); expn[i] = (int) (v >> 11); mant[i] = (int) (v & 0x7FF); }
+        } else if (mk == 0xFF90) {
+            unsigned psot = be32(p + 2);
+            const uint8_t *sot = cs + pos;
+            pos += 2 + len;
+            if (pos + 2 > n || be16(cs + pos) != 0xFF93) { set_error("J2K: missing SOD"); return false; }
+            tile_data = cs + pos + 2;
+            tile_end = psot ? sot + psot : cs + n - 2;
+            if (tile_end > cs + n) { set_error("J2K: tile-part overruns the stream"); return false; }
+            break;
+        }
+        pos += 2 + len;
+    }
+    if (!tile_data || W != g.W || H != g.H || nres != kJ2kRes || qsty != 2 || guard != 2) {
+        set_error("J2K: codestream (%dx%d, %d resolutions, qsty %d) does not match the context (%dx%d)", W, H, nres, qsty, g.W, g.H);
+        return false;
+    }
+    for (int b = 0; b < g.nbands; b++)
+        if (expn[b] != g.bands[b].expn || mant[b] != g.bands[b].mant) { set_error("J2K: unexpected quantisation table"); return false; }
+    std::memset(table, 0, sizeof(int) * 4 * (size_t) g.nblocks);
+    const uint8_t *p = tile_data;
+    for (int r = 0; r < kJ2kRes; r++) {
+        BitReader br{p, tile_end};
+        std::vector<int> included;
+        if (br.bit()) {
+            for (int bi = 0; bi < g.nbands; bi++) {
+                const J2kBand &bd = g.bands[bi];
+                if (bd.res != r || bd.ncw * bd.nch == 0) continue;
+                HostTree incl(bd), imsb(bd);
+                for (int cy = 0; cy < bd.nch; cy++)
+                    for (int cx = 0; cx < bd.ncw; cx++) {
+                        if (!incl.decode(br, cx, cy, 1)) continue;
+                        int blk = bd.first_block + cy * bd.ncw + cx;
+                        int i = 1;
+                        while (!imsb.decode(br, cx, cy, i)) i++;
+                        int np;
+                        if (!br.bit()) np = 1;
+                        else if (!br.bit()) np = 2;
+                        else { int v = br.bits(2); if (v != 3) np = 3 + v; else { v = br.bits(5); np = v != 31 ? 6 + v : 37 + br.bits(7); } }
+                        int lblock = 3;
+                        while (br.bit()) lblock++;
+                        int len = br.bits(lblock + flog2(np));
+                        table[4 * blk + 1] = len;
+                        table[4 * blk + 2] = bd.numbps + 1 - i;
+                        table[4 * blk + 3] = np;
+                        included.push_back(blk);
+                    }
+            }
+        }
+        br.align();
+        p = br.p;
+        for (int blk : included) {
+            if (p + table[4 * blk + 1] > tile_end) { set_error("J2K: packet body overruns the tile-part"); return false; }
+            table[4 * blk + 0] = (int) (p - cs);
+            p += table[4 * blk + 1];
+        }
+    }
+    return true;
+}
+
+}  // namespace ebcc
+
+using namespace ebcc;
+
+extern "C" {
+
+// ---- unit-level entry points of the base layer (parity tests) -------------------------------------
+// j2k_encode_internal (src/ebcc_codec.c:105-180) for a batch: frames are scaled to u16 with their own
+// min/max as ebcc_encode does (:675-689), then coded at rate cr[f].
+__attribute__((visibility("default"))) int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames,
+                                                               const float *cr, uint8_t **out_streams, size_t *out_sizes,
+                                                               float *minmax)
+{
+    if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_j2k_encode: bad batch"); return 1; }
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
+    hipStream_t s = ctx->stream;
+    const int n = (int) n_frames;
+    launch_input_stats(d_frames, n, ctx->n_pix, ctx->rb.fs, s);
+    launch_j2k_analysis(d_frames, jb, n, s);
+    std::vector<J2kFrame> jf(n_frames);
+    EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t f = 0; f < n_frames; f++) { jf[f].cr = cr[f]; jf[f].target = 0; jf[f].overflow = 0; }
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n_frames, hipMemcpyHostToDevice, s));
+    launch_j2k_rate(jb, n, nullptr, s);
+    launch_j2k_write(jb, n, nullptr, s);
+    EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
+    fetch_frame_states(ctx, n_frames);
+    for (size_t f = 0; f < n_frames; f++) {
+        if (ctx->h_fs[f].const_field) { out_sizes[f] = 0; out_streams[f] = (uint8_t *) malloc(1); continue; }
+        if (jf[f].overflow) { set_error("code-block byte slot overflow"); return 1; }
+        out_sizes[f] = (size_t) jf[f].stream_bytes;
+        out_streams[f] = (uint8_t *) malloc(out_sizes[f]);
+        EBCC_HIP_CHECK(hipMemcpyAsync(out_streams[f], jb.stream + f * jb.stream_cap, out_sizes[f], hipMemcpyDeviceToHost, s));
+        if (minmax) { minmax[2 * f] = ctx->h_fs[f].minv; minmax[2 * f + 1] = ctx->h_fs[f].maxv; }
+    }
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// After ebcc_hip_j2k_encode: the field j2k_decode_internal (:1092-1136) would return for those streams,
+// decoded in place from the encoder's code-block slots; nbad[f] = count(|x - d| > target[f]).
+__attribute__((visibility("default"))) int ebcc_hip_j2k_emulated_decode(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames,
+                                                                         const float *target, float *d_out,
+                                                                         unsigned long long *nbad, double *err_sum)
+{
+    if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_j2k_emulated_decode: bad batch"); return 1; }
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
+    hipStream_t s = ctx->stream;
+    std::vector<J2kFrame> jf(n_frames);
+    EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t f = 0; f < n_frames; f++) jf[f].target = target[f];
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n_frames, hipMemcpyHostToDevice, s));
+    launch_j2k_probe_decode(d_frames, jb, (int) n_frames, nullptr, s);
+    EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n_frames * ctx->n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t f = 0; f < n_frames; f++) { nbad[f] = jf[f].nbad; err_sum[f] = jf[f].err_sum; }
+    return 0;
+}
+
+// j2k_decode_internal for a batch of codestreams with the given (minval, maxval)
+__attribute__((visibility("default"))) int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes,
+                                                               size_t n_frames, const float *minmax, float *d_out)
+{
+    if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_j2k_decode: bad batch"); return 1; }
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
+    hipStream_t s = ctx->stream;
+    const J2kGeom &g = jb.geom;
+    std::vector<int> table((size_t) n_frames * g.nblocks * 4);
+    fetch_frame_states(ctx, n_frames);
+    for (size_t f = 0; f < n_frames; f++) {
+        if (sizes[f] > jb.stream_cap) { set_error("codestream larger than the slot"); return 1; }
+        if (!j2k_parse_codestream(streams[f], sizes[f], g, table.data() + f * g.nblocks * 4)) return 1;
+        EBCC_HIP_CHECK(hipMemcpyAsync(jb.stream + f * jb.stream_cap, streams[f], sizes[f], hipMemcpyHostToDevice, s));
+        ctx->h_fs[f].minv = minmax[2 * f];
+        ctx->h_fs[f].maxv = minmax[2 * f + 1];
+        ctx->h_fs[f].const_field = 0;
+    }
+    push_frame_states(ctx, n_frames);
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_j2k_decode(jb, (int) n_frames, s);
+    EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n_frames * ctx->n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

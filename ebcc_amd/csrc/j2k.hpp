@@ -1,0 +1,107 @@
+// j2k.hpp - JPEG 2000 base layer of the EBCC codec on gfx950.
+// Replaces the OpenJPEG calls of the reference (/root/reference/src/ebcc_codec.c:105-180 encode,
+// :1092-1136 decode): single tile, 1 component, 16-bit unsigned, irreversible 9/7, 5 decompositions,
+// 64x64 code-blocks, LRCP, 1 quality layer with rate base_cr/2 - bit-exact with OpenJPEG 2.4.0.
+#pragma once
+
+#include "common.hpp"
+#include "residual.hpp"
+
+namespace ebcc {
+
+constexpr int kJ2kRes = 6;
+constexpr int kJ2kBands = 3 * kJ2kRes - 2;
+constexpr int kJ2kMaxPlanes = 26;       // bit-plane masks kept per code-block (Mb <= 16 + ... + guard)
+constexpr int kJ2kMaxPasses = 3 * kJ2kMaxPlanes;
+constexpr int kJ2kCblkBytes = 16 * 1024; // byte slot per code-block
+constexpr int kT1StateWords = 66 + 4 * 64;   // S[-1..64], NEG, VIS, REF, SPS row masks
+
+struct J2kBand {
+    int res, orient, level;
+    int x0, y0, x1, y1;          // band-domain bounds
+    int offx, offy;              // placement inside the tile buffer
+    int ncw, nch;                // code-block grid
+    int first_block;             // index of its first code-block
+    int expn, mant, numbps;      // QCD entry, Mb
+    float step_enc, step_dec;    // encoder step (with sub-band gain) / decoder step
+    double norm;                 // synthesis norm used in the distortion weights
+    int tree_off;                // offset of its tag-tree nodes in the per-frame node arrays
+    int tree_levels;
+    int lvl_w[12], lvl_h[12], lvl_off[12];
+};
+
+struct J2kBlock {
+    int band;
+    int x, y;                    // top-left in the tile buffer
+    int w, h;
+    int cx, cy;                  // position in the band's code-block grid
+};
+
+// geometry shared by all frames of a context (device + host copies)
+struct J2kGeom {
+    int W, H, nblocks, nbands, tree_nodes;
+    int rw[kJ2kRes], rh[kJ2kRes];
+    J2kBand bands[kJ2kBands];
+};
+
+struct J2kFrame {                 // per-frame scalars (device)
+    float cr;                     // rate of the current probe
+    float target;                 // error target of the current search
+    int maxlen;
+    int body_bytes;               // packet bytes of the current layer assignment
+    int stream_bytes;             // whole codestream
+    unsigned long long nbad;      // count(|x - d| > target) of the last decode
+    double err_sum;               // sum(x - d)
+    int overflow;                 // a code-block outgrew its byte slot
+};
+
+struct J2kBuffers {
+    J2kGeom geom;                 // host copy
+    J2kGeom *d_geom;
+    J2kBlock *d_blocks;
+    std::uint16_t *d_blkmap;      // [H*W] code-block id of every tile-buffer position
+    int max_frames;
+    float *B;                     // [frames][H*W] tile buffer (coefficients / samples)
+    int32_t *Q6;                  // [frames][H*W] quantised coefficients with 6 fractional bits
+    float *DEC;                   // [frames][H*W] last decoded field (fp32, de-normalised)
+    unsigned long long *BP;       // [groups][planes][64][64] bit-plane row masks, lane-interleaved
+    unsigned long long *SGN;      // [groups][64][64] sign row masks
+    unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
+    int *blkmax;                  // [frames*nblocks] max |q6|
+    int *numbps;                  // [frames*nblocks]
+    int *totalpasses;             // [frames*nblocks]
+    int *cblk_len;                // [frames*nblocks]
+    int *rates;                   // [frames*nblocks][kJ2kMaxPasses]
+    double *disto;                // [frames*nblocks][kJ2kMaxPasses]
+    int *npass;                   // [frames*nblocks] passes in the current layer
+    uint8_t *cblk_bytes;          // [frames*nblocks][kJ2kCblkBytes]
+    uint8_t *stream;              // [frames][stream_cap] codestream
+    size_t stream_cap;
+    int32_t *V;                   // [frames][H*W] tier-1 decoder output (half units), decode path
+    int *dec_table;               // [frames*nblocks][4]: offset, len, numbps, npasses (decode path)
+    J2kFrame *jf;                 // [frames]
+    FrameState *fs;               // [frames] (shared with the residual layer)
+    double *partial;              // [frames][kPartials]
+    unsigned long long *partial_u;// [frames][kPartials]
+};
+
+J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks);
+
+// ---- launchers (asynchronous on s) ---------------------------------------------------------------
+// check_nan_inf + findMinMaxf (ebcc_codec.c:598-605,515-533) -> fs.minv/maxv/const_field/has_nonfinite
+void launch_input_stats(const float *data, int n_frames, size_t n_pix, FrameState *fs, hipStream_t s);
+// scale to u16 (:686-689), DC level shift, forward 9/7, quantisation, tier-1 of every code-block,
+// distortion tables: everything of opj_encode that does not depend on the rate
+void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, hipStream_t s);
+// rate allocation for jf[f].cr (opj_tcd_rateallocate) -> npass, jf.body_bytes/stream_bytes
+void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
+// write the codestream of the current layer assignment into jb.stream
+void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
+// what opj_decode returns for the current layer assignment (decoded in place from the code-block
+// slots), mapped to fp32 as :1130 -> jb.DEC, and the error statistics against `data`
+void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
+// true decode of codestreams whose packet headers were parsed on the host into jb.dec_table
+// (fs[f].minv/maxv must hold the header's values); result in jb.DEC
+void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s);
+
+}  // namespace ebcc

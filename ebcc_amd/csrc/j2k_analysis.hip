@@ -1,0 +1,586 @@
+// j2k_analysis.hip - rate-independent half of the JPEG 2000 encoder on gfx950:
+//   input statistics, u16 scaling + DC level shift, forward 9/7 (OpenJPEG 2.4.0 arithmetic order),
+//   quantisation to bit-plane row masks (wave ballots), tier-1 coding of every code-block (one
+//   code-block per lane, t1_core.hpp) and the per-pass distortion tables for rate allocation.
+// OpenJPEG runs all of this inside every opj_encode call; the reference calls opj_encode ~22 times per
+// frame with different rates (/root/reference/src/ebcc_codec.c:545-596).  None of it depends on the
+// rate, so here it runs once per frame.
+#include <cmath>
+#include <vector>
+
+#include "j2k.hpp"
+#include "t1_core.hpp"
+
+namespace ebcc {
+
+// ================================================================================================
+// geometry (T.800 B.5-B.7 with default precincts), quantisation parameters (E.1)
+// ================================================================================================
+static int ceildivpow2(int a, int b) { return (int) (((long long) a + (1ll << b) - 1) >> b); }
+static int floorlog2i(int a) { int l = 0; while (a > 1) { a >>= 1; l++; } return l; }
+
+static const double kNormsReal[4][10] = {
+    {1.000, 1.965, 4.177, 8.403, 16.90, 33.84, 67.69, 135.3, 270.6, 540.9},
+    {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
+    {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
+    {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2}};
+
+J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
+{
+    J2kGeom g{};
+    g.W = W; g.H = H;
+    const int prec = 16, guard = 2;
+    for (int r = 0; r < kJ2kRes; r++) {
+        g.rw[r] = ceildivpow2(W, kJ2kRes - 1 - r);
+        g.rh[r] = ceildivpow2(H, kJ2kRes - 1 - r);
+    }
+    blocks.clear();
+    int bi = 0, nodes = 0;
+    for (int r = 0; r < kJ2kRes; r++) {
+        int lv = kJ2kRes - 1 - r;
+        int nb = r == 0 ? 1 : 3;
+        for (int b = 0; b < nb; b++, bi++) {
+            J2kBand &bd = g.bands[bi];
+            bd.res = r; bd.level = lv;
+            if (r == 0) {
+                bd.orient = 0;
+                bd.x0 = 0; bd.y0 = 0; bd.x1 = g.rw[0]; bd.y1 = g.rh[0];
+                bd.offx = 0; bd.offy = 0;
+            } else {
+                bd.orient = b + 1;
+                int xb = bd.orient & 1, yb = bd.orient >> 1;
+                bd.x0 = 0; bd.y0 = 0;                               // tile origin is (0,0)
+                bd.x1 = ceildivpow2(W - (xb << lv), lv + 1);
+                bd.y1 = ceildivpow2(H - (yb << lv), lv + 1);
+                bd.offx = xb ? g.rw[r - 1] : 0;
+                bd.offy = yb ? g.rh[r - 1] : 0;
+            }
+            // QCD entry: opj_dwt_calc_explicit_stepsizes + opj_dwt_encode_stepsize
+            double stepsize = 1.0 / kNormsReal[bd.orient][lv];
+            int v = (int) std::floor(stepsize * 8192.0);
+            int p = floorlog2i(v) - 13, n = 11 - floorlog2i(v);
+            bd.mant = (n < 0 ? v >> -n : v << n) & 0x7FF;
+            bd.expn = prec - p;
+            bd.numbps = bd.expn + guard - 1;
+            int log2_gain = bd.orient == 0 ? 0 : (bd.orient == 3 ? 2 : 1);
+            bd.step_enc = (float) ((1.0 + bd.mant / 2048.0) * std::pow(2.0, (double) (prec + log2_gain - bd.expn)));
+            bd.step_dec = (float) ((1.0 + bd.mant / 2048.0) * std::pow(2.0, (double) (prec - bd.expn)));
+            bd.norm = kNormsReal[bd.orient][lv];
+            int bw = bd.x1 - bd.x0, bh = bd.y1 - bd.y0;
+            bd.first_block = (int) blocks.size();
+            if (bw <= 0 || bh <= 0) { bd.ncw = bd.nch = 0; bd.tree_levels = 0; bd.tree_off = nodes; continue; }
+            bd.ncw = (bd.x1 + 63) / 64;
+            bd.nch = (bd.y1 + 63) / 64;
+            for (int cy = 0; cy < bd.nch; cy++)
+                for (int cx = 0; cx < bd.ncw; cx++) {
+                    J2kBlock k{};
+                    k.band = bi; k.cx = cx; k.cy = cy;
+                    int x0 = cx * 64, y0 = cy * 64;
+                    int x1 = std::min(x0 + 64, bd.x1), y1 = std::min(y0 + 64, bd.y1);
+                    k.x = bd.offx + x0; k.y = bd.offy + y0; k.w = x1 - x0; k.h = y1 - y0;
+                    blocks.push_back(k);
+                }
+            // tag-tree level layout (B.10.2)
+            int lw = bd.ncw, lh = bd.nch, off = 0, L = 0;
+            bd.tree_off = nodes;
+            for (;;) {
+                bd.lvl_w[L] = lw; bd.lvl_h[L] = lh; bd.lvl_off[L] = off;
+                off += lw * lh; L++;
+                if (lw * lh <= 1) break;
+                lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+            }
+            bd.tree_levels = L;
+            nodes += off;
+        }
+    }
+    g.nbands = bi;
+    g.nblocks = (int) blocks.size();
+    g.tree_nodes = nodes;
+    return g;
+}
+
+namespace {
+
+// ================================================================================================
+// input statistics
+// ================================================================================================
+__global__ void k_in_init(FrameState *fs, int n)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) { fs[f].min_key = ~0ull; fs[f].max_key = 0ull; fs[f].has_nonfinite = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_in_minmax(const float *__restrict__ data, size_t n_pix, FrameState *fs)
+{
+    const int frame = blockIdx.y;
+    const float *x = data + (size_t) frame * n_pix;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    int bad = 0;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (isnan(v) || isinf(v)) bad = 1;                            // check_nan_inf, ebcc_codec.c:598-605
+        unsigned long long k = (unsigned long long) float_order_key(v) << 32;
+        unsigned long long lo = k | (unsigned int) i, hi = k | (0xFFFFFFFFu - (unsigned int) i);
+        kmin = lo < kmin ? lo : kmin;
+        kmax = hi > kmax ? hi : kmax;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(kmin, d); kmin = o < kmin ? o : kmin;
+        o = __shfl_xor(kmax, d); kmax = o > kmax ? o : kmax;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&fs[frame].min_key, kmin);
+        atomicMax(&fs[frame].max_key, kmax);
+    }
+    if (bad) fs[frame].has_nonfinite = 1;
+}
+
+__global__ void k_in_finish(const float *data, size_t n_pix, FrameState *fs, int n)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const float *x = data + (size_t) f * n_pix;
+    float mn = x[(unsigned int) fs[f].min_key], mx = x[0xFFFFFFFFu - (unsigned int) fs[f].max_key];
+    fs[f].minv = mn; fs[f].maxv = mx;
+    fs[f].const_field = (mn == mx) ? 1 : 0;                           // ebcc_codec.c:678
+}
+
+// ================================================================================================
+// scaling to u16 (ebcc_codec.c:688), DC level shift to float (opj_tcd_dc_level_shift_encode)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_scale_shift(const float *__restrict__ data, float *__restrict__ B, size_t n_pix,
+                                                      const FrameState *fs)
+{
+    const int frame = blockIdx.y;
+    if (fs[frame].const_field) return;
+    const float *x = data + (size_t) frame * n_pix;
+    float *b = B + (size_t) frame * n_pix;
+    const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
+        unsigned int u = __float2uint_rz(((x[i] - mn) / rng) * 65535.0f) & 0xFFFFu;
+        b[i] = (float) ((int) u - 32768);
+    }
+}
+
+// ================================================================================================
+// 9/7 lifting with OpenJPEG's boundary handling and arithmetic order
+// ================================================================================================
+__device__ constexpr float kA = -1.586134342f, kB = -0.052980118f, kG = 0.882911075f, kD = 0.443506852f;
+__device__ constexpr float kK = 1.230174105f, kTwoInvK = 1.625732422f;
+
+// high[i] += (low[i] + low[i+1]) * c, last high of an even-length line uses 2*low[i]   (opj_dwt_encode_step2)
+template <typename Idx>
+__device__ inline void fstep_hi(float *E, float *O, int sn, int dn, int lines, Idx at, float c, int tid, int nt)
+{
+    for (int t = tid; t < dn * lines; t += nt) {
+        int i = t / lines, l = t - i * lines;
+        float o = O[at(i, l)];
+        if (i + 1 < sn) o = o + ((E[at(i, l)] + E[at(i + 1, l)]) * c);
+        else            o = o + ((2 * E[at(i, l)]) * c);
+        O[at(i, l)] = o;
+    }
+    __syncthreads();
+}
+// low[i] += (high[i-1] + high[i]) * c with high[-1] := high[0]; last low of an odd-length line uses 2*high[i-1]
+template <typename Idx>
+__device__ inline void fstep_lo(float *E, float *O, int sn, int dn, int lines, Idx at, float c, int tid, int nt)
+{
+    for (int t = tid; t < sn * lines; t += nt) {
+        int i = t / lines, l = t - i * lines;
+        float e = E[at(i, l)];
+        if (i < dn) {
+            float hl = i == 0 ? O[at(0, l)] : O[at(i - 1, l)];
+            e = e + ((hl + O[at(i, l)]) * c);
+        } else {
+            e = e + ((2 * O[at(i - 1, l)]) * c);
+        }
+        E[at(i, l)] = e;
+    }
+    __syncthreads();
+}
+// decoder forms (opj_v8dwt_decode_step2): the boundary term is x + h * (c + c)
+template <typename Idx>
+__device__ inline void istep_lo(float *E, float *O, int sn, int dn, int lines, Idx at, float c, int tid, int nt)
+{
+    for (int t = tid; t < sn * lines; t += nt) {
+        int i = t / lines, l = t - i * lines;
+        float e = E[at(i, l)];
+        if (i < dn) {
+            float hl = i == 0 ? O[at(0, l)] : O[at(i - 1, l)];
+            e = e + ((hl + O[at(i, l)]) * c);
+        } else {
+            e = e + (O[at(i - 1, l)] * (c + c));
+        }
+        E[at(i, l)] = e;
+    }
+    __syncthreads();
+}
+template <typename Idx>
+__device__ inline void istep_hi(float *E, float *O, int sn, int dn, int lines, Idx at, float c, int tid, int nt)
+{
+    for (int t = tid; t < dn * lines; t += nt) {
+        int i = t / lines, l = t - i * lines;
+        float o = O[at(i, l)];
+        if (i + 1 < sn) o = o + ((E[at(i, l)] + E[at(i + 1, l)]) * c);
+        else            o = o + (E[at(i, l)] * (c + c));
+        O[at(i, l)] = o;
+    }
+    __syncthreads();
+}
+
+template <typename Idx>
+__device__ inline void fdwt_tile(float *E, float *O, int sn, int dn, int lines, Idx at, int tid, int nt)
+{
+    const float invK = (float) (1.0 / 1.230174105);
+    fstep_hi(E, O, sn, dn, lines, at, kA, tid, nt);
+    fstep_lo(E, O, sn, dn, lines, at, kB, tid, nt);
+    fstep_hi(E, O, sn, dn, lines, at, kG, tid, nt);
+    fstep_lo(E, O, sn, dn, lines, at, kD, tid, nt);
+    for (int t = tid; t < sn * lines; t += nt) { int i = t / lines, l = t - i * lines; E[at(i, l)] *= invK; }
+    for (int t = tid; t < dn * lines; t += nt) { int i = t / lines, l = t - i * lines; O[at(i, l)] *= kK; }
+    __syncthreads();
+}
+template <typename Idx>
+__device__ inline void idwt_tile(float *E, float *O, int sn, int dn, int lines, Idx at, int tid, int nt)
+{
+    for (int t = tid; t < sn * lines; t += nt) { int i = t / lines, l = t - i * lines; E[at(i, l)] = E[at(i, l)] * kK; }
+    for (int t = tid; t < dn * lines; t += nt) { int i = t / lines, l = t - i * lines; O[at(i, l)] = O[at(i, l)] * kTwoInvK; }
+    __syncthreads();
+    istep_lo(E, O, sn, dn, lines, at, -kD, tid, nt);
+    istep_hi(E, O, sn, dn, lines, at, -kG, tid, nt);
+    istep_lo(E, O, sn, dn, lines, at, -kB, tid, nt);
+    istep_hi(E, O, sn, dn, lines, at, -kA, tid, nt);
+}
+
+struct RowIdx { __device__ int operator()(int k, int) const { return k; } };
+template <int CW> struct ColIdx { __device__ int operator()(int k, int l) const { return k * CW + l; } };
+
+constexpr int kRowT = 256, kColT = 1024;
+
+// rows of the region [0,n) x [0,rows) of the tile buffer, in place
+template <bool FWD>
+__global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, int W, size_t frame_stride, int n, int sn,
+                                                     int rows, const FrameState *fs, const int *active)
+{
+    extern __shared__ float sm[];
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
+    const int dn = n - sn, tid = threadIdx.x;
+    float *E = sm, *O = sm + sn;
+    float *buf = B + (size_t) frame * frame_stride;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        float *r = buf + (size_t) row * W;
+        if (FWD) {
+            for (int i = tid; i < n; i += kRowT) { float v = r[i]; ((i & 1) ? O : E)[i >> 1] = v; }
+        } else {
+            for (int i = tid; i < sn; i += kRowT) E[i] = r[i];
+            for (int i = tid; i < dn; i += kRowT) O[i] = r[sn + i];
+        }
+        __syncthreads();
+        if (FWD) {
+            fdwt_tile(E, O, sn, dn, 1, RowIdx(), tid, kRowT);
+            for (int i = tid; i < sn; i += kRowT) r[i] = E[i];
+            for (int i = tid; i < dn; i += kRowT) r[sn + i] = O[i];
+        } else {
+            idwt_tile(E, O, sn, dn, 1, RowIdx(), tid, kRowT);
+            for (int i = tid; i < n; i += kRowT) r[i] = ((i & 1) ? O : E)[i >> 1];
+        }
+        __syncthreads();
+    }
+}
+
+// columns of the region [0,cols) x [0,n), CW columns per tile staged through LDS, in place
+template <bool FWD, int CW>
+__global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, int W, size_t frame_stride, int n, int sn,
+                                                     int cols, const FrameState *fs, const int *active)
+{
+    extern __shared__ float sm[];
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
+    const int dn = n - sn, tid = threadIdx.x;
+    float *E = sm, *O = sm + (size_t) sn * CW;
+    float *buf = B + (size_t) frame * frame_stride;
+    const int ntiles = (cols + CW - 1) / CW;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = tile * CW, w = min(CW, cols - x0);
+        for (int t = tid; t < n * CW; t += kColT) {
+            int y = t / CW, c = t - y * CW;
+            float v = c < w ? buf[(size_t) y * W + x0 + c] : 0.0f;
+            if (FWD) ((y & 1) ? O : E)[(y >> 1) * CW + c] = v;
+            else     (y < sn ? E : O)[(y < sn ? y : y - sn) * CW + c] = v;
+        }
+        __syncthreads();
+        if (FWD) fdwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT);
+        else     idwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT);
+        for (int t = tid; t < n * CW; t += kColT) {
+            int y = t / CW, c = t - y * CW;
+            if (c < w) {
+                float v;
+                if (FWD) v = (y < sn ? E : O)[(y < sn ? y : y - sn) * CW + c];
+                else     v = ((y & 1) ? O : E)[(y >> 1) * CW + c];
+                buf[(size_t) y * W + x0 + c] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename K>
+void big_lds(K k, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        EBCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int) bytes));
+}
+
+template <bool FWD>
+void dwt_cols(float *B, const J2kGeom &g, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+{
+    int n = g.rh[r], sn = g.rh[r - 1], cols = g.rw[r];
+    if (n <= 1) return;
+    if ((size_t) n * 32 * 4 <= 156 * 1024) {
+        size_t lds = (size_t) n * 32 * 4;
+        auto k = k_j2k_cols<FWD, 32>;
+        big_lds(k, lds);
+        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 32), n_frames), dim3(kColT), lds, s, B, g.W, (size_t) g.W * g.H, n, sn, cols,
+                           fs, active);
+    } else {
+        size_t lds = (size_t) n * 16 * 4;
+        auto k = k_j2k_cols<FWD, 16>;
+        big_lds(k, lds);
+        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 16), n_frames), dim3(kColT), lds, s, B, g.W, (size_t) g.W * g.H, n, sn, cols,
+                           fs, active);
+    }
+}
+template <bool FWD>
+void dwt_rows(float *B, const J2kGeom &g, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+{
+    int n = g.rw[r], sn = g.rw[r - 1], rows = g.rh[r];
+    if (n <= 1) return;
+    hipLaunchKernelGGL(k_j2k_rows<FWD>, dim3(min(rows, 96), n_frames), dim3(kRowT), (size_t) n * 4, s, B, g.W,
+                       (size_t) g.W * g.H, n, sn, rows, fs, active);
+}
+
+// ================================================================================================
+// quantisation -> Q6 + bit-plane row masks (one workgroup per code-block, one wave per row)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, int32_t *__restrict__ Q6,
+                                                   unsigned long long *__restrict__ BP, unsigned long long *__restrict__ SGN,
+                                                   int *__restrict__ blkmax, const J2kGeom *geom, const J2kBlock *blocks,
+                                                   const FrameState *fs)
+{
+    __shared__ int smax[4];
+    const int frame = blockIdx.y, bi = blockIdx.x;
+    if (fs[frame].const_field) return;
+    const J2kBlock blk = blocks[bi];
+    const float step = geom->bands[blk.band].step_enc;
+    const int W = geom->W;
+    const size_t n_pix = (size_t) W * geom->H;
+    const float *b = B + (size_t) frame * n_pix;
+    int32_t *q = Q6 + (size_t) frame * n_pix;
+    const int gid = frame * geom->nblocks + bi;
+    const size_t grp = (size_t) (gid >> 6);
+    const int gl = gid & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mx = 0;
+    for (int row = wave; row < 64; row += 4) {
+        const bool valid = row < blk.h && lane < blk.w;
+        int q6 = 0;
+        if (valid) {
+            size_t p = (size_t) (blk.y + row) * W + blk.x + lane;
+            q6 = __float2int_rn((b[p] / step) * 64.0f);             // lrintf((c / stepsize) * 64), opj_t1_encode_cblks
+            q[p] = q6;
+        }
+        int a6 = q6 < 0 ? -q6 : q6;
+        mx = a6 > mx ? a6 : mx;
+        unsigned long long sg = __ballot(q6 < 0);
+        if (lane == 0) SGN[(grp * 64 + row) * 64 + gl] = sg;
+        const int a = a6 >> 6;
+        for (int p = 0; p < kJ2kMaxPlanes; p++) {
+            unsigned long long m = __ballot((a >> p) & 1);
+            if (lane == 0) BP[((grp * kJ2kMaxPlanes + p) * 64 + row) * 64 + gl] = m;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    if (lane == 0) smax[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) blkmax[gid] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+}
+
+// ================================================================================================
+// tier-1 encoder: one code-block per lane (t1_core.hpp)
+// ================================================================================================
+struct DevStore {
+    unsigned long long *st;       // group base of the state words, lane offset already applied
+    const unsigned long long *bp; // group base of the bit-plane masks, lane offset applied
+    const unsigned long long *sg;
+    __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
+    __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
+    __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
+    __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
+    __device__ unsigned long long &SPS(int y) { return st[(size_t) (258 + y) * 64]; }
+    __device__ unsigned long long SGN(int y) const { return y < 64 ? sg[(size_t) y * 64] : 0ull; }
+    __device__ unsigned long long BP(int plane, int y) const { return y < 64 ? bp[((size_t) plane * 64 + y) * 64] : 0ull; }
+};
+struct DevSink {
+    uint8_t *p; int cap; int *overflow;
+    __device__ void put(int i, uint8_t b) { if (i < cap) p[i] = b; else *overflow = 1; }
+};
+struct DevAt {
+    const uint8_t *p; int cap;
+    __device__ uint8_t operator()(int i) const { return i < cap ? p[i] : (uint8_t) 0; }
+};
+
+__global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const unsigned long long *BP,
+                                                   const unsigned long long *SGN, const int *blkmax, int *numbps,
+                                                   int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes,
+                                                   const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
+                                                   J2kFrame *jf, int total)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= total) return;
+    const int nb = geom->nblocks;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if (fs[frame].const_field) return;
+    const J2kBlock blk = blocks[bi];
+    const int orient = geom->bands[blk.band].orient;
+    const int m = blkmax[gid];
+    int P = m ? (31 - __clz(m)) + 1 - 6 : 0;                         // opj_t1_encode_cblk: numbps
+    numbps[gid] = P;
+    if (P <= 0) { totalpasses[gid] = 0; cblk_len[gid] = 0; return; }
+    const size_t grp = (size_t) (gid >> 6);
+    const int gl = gid & 63;
+    DevStore st{T1S + grp * kT1StateWords * 64 + gl, BP + grp * kJ2kMaxPlanes * 64 * 64 + gl, SGN + grp * 64 * 64 + gl};
+    uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
+    t1::EncodeResult r = t1::encode_block(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
+                                          blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses);
+    totalpasses[gid] = r.totalpasses;
+    cblk_len[gid] = r.length;
+}
+
+// ================================================================================================
+// distortion tables: per-pass nmsedec sums are order-independent integers, so they are accumulated in
+// parallel from (q6, msb, "significant in a propagation pass") instead of inside the serial coder
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ Q6, const unsigned long long *__restrict__ T1S,
+                                                     const int *__restrict__ numbps, const int *__restrict__ totalpasses,
+                                                     double *__restrict__ disto, const short *__restrict__ luts,
+                                                     const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs)
+{
+    __shared__ int nms[kJ2kMaxPasses];
+    __shared__ short lut[4 * 128];
+    const int frame = blockIdx.y, bi = blockIdx.x;
+    if (fs[frame].const_field) return;
+    const int gid = frame * geom->nblocks + bi;
+    const int P = numbps[gid], np = totalpasses[gid];
+    if (np <= 0) return;
+    for (int i = threadIdx.x; i < kJ2kMaxPasses; i += 256) nms[i] = 0;
+    for (int i = threadIdx.x; i < 4 * 128; i += 256) lut[i] = luts[i];
+    __syncthreads();
+    const J2kBlock blk = blocks[bi];
+    const int W = geom->W;
+    const int32_t *q = Q6 + (size_t) frame * W * geom->H;
+    const size_t grp = (size_t) (gid >> 6);
+    const int gl = gid & 63;
+    const unsigned long long *sps = T1S + (grp * kT1StateWords + 258) * 64 + gl;
+    for (int t = threadIdx.x; t < blk.w * blk.h; t += 256) {
+        int y = t / blk.w, x = t - y * blk.w;
+        int q6 = q[(size_t) (blk.y + y) * W + blk.x + x];
+        unsigned int a6 = (unsigned int) (q6 < 0 ? -q6 : q6), a = a6 >> 6;
+        if (!a) continue;
+        int bs = 31 - __clz(a);
+        int from_sp = (int) ((sps[(size_t) y * 64] >> x) & 1ull);
+        int ps = bs == P - 1 ? 0 : 3 * (P - 1 - bs) - (from_sp ? 2 : 0);
+        // opj_t1_getnmsedec_sig / _ref: 7-bit index around the coded bit, separate tables for plane 0
+        int v = bs > 0 ? lut[0 * 128 + ((a6 >> bs) & 127)] : lut[1 * 128 + (a6 & 127)];
+        atomicAdd(&nms[ps], v);
+        for (int b = bs - 1; b >= 0; b--) {
+            int r = b > 0 ? lut[2 * 128 + ((a6 >> b) & 127)] : lut[3 * 128 + (a6 & 127)];
+            atomicAdd(&nms[3 * (P - 1 - b) - 1], r);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const J2kBand &bd = geom->bands[blk.band];
+        const int log2_gain = bd.orient == 0 ? 0 : (bd.orient == 3 ? 2 : 1);
+        const double st = (double) bd.step_enc / (double) (1 << log2_gain);   // opj_t1_getwmsedec: step without the gain
+        double cum = 0;
+        int bp = P - 1, passtype = 2;
+        for (int p = 0; p < np; p++) {
+            double wm = ((1.0 * bd.norm) * st) * (double) (1 << bp);
+            wm = wm * ((wm * (double) nms[p]) / 8192.0);
+            cum += wm;
+            disto[(size_t) gid * kJ2kMaxPasses + p] = cum;
+            if (++passtype == 3) { passtype = 0; bp--; }
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+void launch_input_stats(const float *data, int n_frames, size_t n_pix, FrameState *fs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_in_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, fs, n_frames);
+    hipLaunchKernelGGL(k_in_minmax, dim3(64, n_frames), dim3(256), 0, s, data, n_pix, fs);
+    hipLaunchKernelGGL(k_in_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, data, n_pix, fs, n_frames);
+}
+
+static short *g_luts = nullptr;
+static const short *nmsedec_luts(hipStream_t s)
+{
+    if (!g_luts) {
+        short h[4 * 128];
+        for (int i = 0; i < 128; i++) {                                // t1_generate_luts: T.800 J.14.4 estimates
+            double t = i / std::pow(2, 6), u, v;
+            int x;
+            u = t; v = t - 1.5;
+            x = (int) (std::floor((u * u - v * v) * std::pow(2, 6) + 0.5) / std::pow(2, 6) * 8192.0);
+            h[0 * 128 + i] = (short) std::max(0, x);
+            x = (int) (std::floor((u * u) * std::pow(2, 6) + 0.5) / std::pow(2, 6) * 8192.0);
+            h[1 * 128 + i] = (short) std::max(0, x);
+            u = t - 1.0;
+            v = (i & 64) ? t - 1.5 : t - 0.5;
+            x = (int) (std::floor((u * u - v * v) * std::pow(2, 6) + 0.5) / std::pow(2, 6) * 8192.0);
+            h[2 * 128 + i] = (short) std::max(0, x);
+            x = (int) (std::floor((u * u) * std::pow(2, 6) + 0.5) / std::pow(2, 6) * 8192.0);
+            h[3 * 128 + i] = (short) std::max(0, x);
+        }
+        EBCC_HIP_CHECK(hipMalloc(&g_luts, sizeof h));
+        EBCC_HIP_CHECK(hipMemcpyAsync(g_luts, h, sizeof h, hipMemcpyHostToDevice, s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return g_luts;
+}
+
+void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, hipStream_t s)
+{
+    const FrameState *fs = jb.fs;
+    const J2kGeom &g = jb.geom;
+    const size_t n_pix = (size_t) g.W * g.H;
+    const int total = n_frames * g.nblocks;
+    const size_t groups = ((size_t) total + 63) / 64;
+    hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
+    for (int r = kJ2kRes - 1; r >= 1; r--) {                           // opj_dwt_encode_procedure: vertical, then horizontal
+        dwt_cols<true>(jb.B, g, r, n_frames, fs, nullptr, s);
+        dwt_rows<true>(jb.B, g, r, n_frames, fs, nullptr, s);
+    }
+    hipLaunchKernelGGL(k_quantize, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.blkmax,
+                       jb.d_geom, jb.d_blocks, fs);
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_t1_encode, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.blkmax, jb.numbps,
+                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.d_geom, jb.d_blocks, fs, jb.jf, total);
+    hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.T1S, jb.numbps, jb.totalpasses,
+                       jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
+}
+
+// inverse transform of the tile buffers, used by both decode flavours (j2k_rate.hip)
+void j2k_inverse_dwt(float *B, const J2kGeom &g, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+{
+    for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
+        dwt_rows<false>(B, g, r, n_frames, fs, active, s);
+        dwt_cols<false>(B, g, r, n_frames, fs, active, s);
+    }
+}
+
+}  // namespace ebcc

@@ -1,0 +1,571 @@
+// j2k_rate.hip - rate-dependent half of the JPEG 2000 base layer on gfx950:
+//   PCRD rate allocation (OpenJPEG 2.4.0 opj_tcd_rateallocate / opj_tcd_makelayer), tier-2 packet
+//   headers (tag trees, T.800 B.10), codestream assembly, and the decoder (tier-1 MQ decoding with one
+//   code-block per lane, dequantisation, inverse 9/7, level shift).
+// Each of the reference's ~22 opj_encode+opj_decode probes per frame
+// (/root/reference/src/ebcc_codec.c:535-596) becomes one rate allocation over the tier-1 results that
+// were computed once, plus a decode of only the passes that allocation keeps, read in place from the
+// encoder's code-block slots (no codestream is assembled or parsed for a probe).
+#include <cfloat>
+#include <cmath>
+
+#include "j2k.hpp"
+#include "t1_core.hpp"
+
+namespace ebcc {
+
+void j2k_inverse_dwt(float *B, const J2kGeom &g, int n_frames, const FrameState *fs, const int *active, hipStream_t s);
+
+namespace {
+
+constexpr int kMainHeaderBytes = 135;
+constexpr int kRateThreads = 64;
+
+__device__ inline int floorlog2d(int a) { return a > 1 ? 31 - __clz(a) : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// packet-header bit writer (B.10.1): counts bytes; writes them when `out` is non-null
+// ------------------------------------------------------------------------------------------------
+struct Bio {
+    unsigned int buf;
+    int ct;
+    int n;
+    uint8_t *out;
+    __device__ void init(uint8_t *o) { buf = 0; ct = 8; n = 0; out = o; }
+    __device__ void byteout()
+    {
+        buf = (buf << 8) & 0xFFFFu;
+        ct = buf == 0xFF00u ? 7 : 8;
+        if (out) out[n] = (uint8_t) (buf >> 8);
+        n++;
+    }
+    __device__ void bit(int v)
+    {
+        if (ct == 0) byteout();
+        ct--;
+        buf |= (unsigned int) (v & 1) << ct;
+    }
+    __device__ void bits(unsigned int v, int nb) { for (int i = nb - 1; i >= 0; i--) bit((int) ((v >> i) & 1u)); }
+    __device__ void flush() { byteout(); if (ct == 7) byteout(); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// tag trees in LDS: node arrays of one band start at tree_off; level l node (i, j) at lvl_off[l] + j*lvl_w[l] + i
+// ------------------------------------------------------------------------------------------------
+struct Trees {
+    short *ival, *ilow, *mval, *mlow;       // inclusion / zero-bit-plane trees: value, low
+    unsigned char *iknown, *mknown;
+};
+
+__device__ inline void tgt_encode(Bio &bio, const J2kBand &bd, short *val, short *low, unsigned char *known, int cx, int cy,
+                                  int threshold)
+{
+    // walk root -> leaf (B.10.2); node of level l on the path is (cx >> l, cy >> l)
+    int lowv = 0;
+    for (int l = bd.tree_levels - 1; l >= 0; l--) {
+        int idx = bd.tree_off + bd.lvl_off[l] + (cy >> l) * bd.lvl_w[l] + (cx >> l);
+        if (lowv > low[idx]) low[idx] = (short) lowv; else lowv = low[idx];
+        const int v = val[idx];
+        while (lowv < threshold) {
+            if (lowv >= v) {
+                if (!known[idx]) { bio.bit(1); known[idx] = 1; }
+                break;
+            }
+            bio.bit(0);
+            ++lowv;
+        }
+        low[idx] = (short) lowv;
+    }
+}
+
+__device__ inline void put_numpasses(Bio &b, int n)
+{
+    if (n == 1) b.bits(0, 1);
+    else if (n == 2) b.bits(2, 2);
+    else if (n <= 5) b.bits(0xCu | (unsigned) (n - 3), 4);
+    else if (n <= 36) b.bits(0x1E0u | (unsigned) (n - 6), 9);
+    else b.bits(0xFF80u | (unsigned) (n - 37), 16);
+}
+
+// header of the packet of resolution r for the layer assignment npass[]; returns header bytes and adds the
+// body bytes to *body.  Trees must have been reset (and inclusion values set) by the caller.
+__device__ int packet_header(int r, const J2kGeom &g, const Trees &t, const short *npass, const int *rates, int gid0,
+                             uint8_t *out, int *body)
+{
+    Bio bio;
+    bio.init(out);
+    bio.bit(1);                                                      // OpenJPEG 2.4.0 never writes an empty-packet bit
+    int bytes = 0;
+    for (int bi = 0; bi < g.nbands; bi++) {
+        const J2kBand &bd = g.bands[bi];
+        if (bd.res != r || bd.ncw * bd.nch == 0) continue;
+        for (int cy = 0; cy < bd.nch; cy++)
+            for (int cx = 0; cx < bd.ncw; cx++) {
+                const int blk = bd.first_block + cy * bd.ncw + cx;
+                tgt_encode(bio, bd, t.ival, t.ilow, t.iknown, cx, cy, 1);
+                const int n = npass[blk];
+                if (!n) continue;
+                tgt_encode(bio, bd, t.mval, t.mlow, t.mknown, cx, cy, 999);
+                put_numpasses(bio, n);
+                const int seglen = rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
+                int inc = floorlog2d(seglen) + 1 - (3 + floorlog2d(n));
+                if (inc < 0) inc = 0;
+                for (int k = 0; k < inc; k++) bio.bit(1);
+                bio.bit(0);
+                bio.bits((unsigned) seglen, 3 + inc + floorlog2d(n));
+                bytes += seglen;
+            }
+    }
+    bio.flush();
+    *body = bytes;
+    return bio.n;
+}
+
+// LDS carve-up shared by the rate and write kernels
+struct RateLds {
+    short *npass;
+    Trees t;
+    short *mval0;        // static zero-bit-plane node minima
+    __device__ static size_t bytes(int nblocks, int nodes)
+    {
+        return (size_t) nblocks * 2 + (size_t) nodes * (2 * 5 + 2) + 64;
+    }
+    __device__ void carve(unsigned char *base, int nblocks, int nodes)
+    {
+        npass = (short *) base; base += (((size_t) nblocks * 2 + 7) / 8) * 8;
+        t.ival = (short *) base; base += (size_t) nodes * 2;
+        t.ilow = (short *) base; base += (size_t) nodes * 2;
+        t.mval = (short *) base; base += (size_t) nodes * 2;
+        t.mlow = (short *) base; base += (size_t) nodes * 2;
+        mval0 = (short *) base; base += (size_t) nodes * 2;
+        t.iknown = base; base += nodes;
+        t.mknown = base;
+    }
+};
+
+__device__ inline void tree_setmin(const J2kBand &bd, short *val, int cx, int cy, int v)
+{
+    for (int l = 0; l < bd.tree_levels; l++) {
+        int idx = bd.tree_off + bd.lvl_off[l] + (cy >> l) * bd.lvl_w[l] + (cx >> l);
+        if (val[idx] > v) val[idx] = (short) v; else break;
+    }
+}
+
+// static part: node minima of Mb - numbps over ALL code-blocks (opj_tgt_setvalue for every cblk)
+__device__ void trees_static(const J2kGeom &g, RateLds &L, const int *numbps, int gid0, int lane)
+{
+    for (int i = lane; i < g.tree_nodes; i += kRateThreads) L.mval0[i] = 999;
+    __syncthreads();
+    if (lane < g.nbands) {                                           // one lane per band: sequential min propagation
+        const J2kBand &bd = g.bands[lane];
+        for (int cy = 0; cy < bd.nch; cy++)
+            for (int cx = 0; cx < bd.ncw; cx++)
+                tree_setmin(bd, L.mval0, cx, cy, bd.numbps - numbps[gid0 + bd.first_block + cy * bd.ncw + cx]);
+    }
+    __syncthreads();
+}
+
+__device__ void trees_reset(const J2kGeom &g, RateLds &L, int lane)
+{
+    for (int i = lane; i < g.tree_nodes; i += kRateThreads) {
+        L.t.ival[i] = 999; L.t.ilow[i] = 0; L.t.iknown[i] = 0;
+        L.t.mval[i] = L.mval0[i]; L.t.mlow[i] = 0; L.t.mknown[i] = 0;
+    }
+    __syncthreads();
+    if (lane < g.nbands) {
+        const J2kBand &bd = g.bands[lane];
+        for (int cy = 0; cy < bd.nch; cy++)
+            for (int cx = 0; cx < bd.ncw; cx++)
+                if (L.npass[bd.first_block + cy * bd.ncw + cx]) tree_setmin(bd, L.t.ival, cx, cy, 0);
+    }
+    __syncthreads();
+}
+
+// opj_tcd_makelayer for one quality layer
+__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const int *rates, const double *disto,
+                           int gid0, double thresh, int lane)
+{
+    for (int b = lane; b < g.nblocks; b += kRateThreads) {
+        const int tp = totalpasses[gid0 + b];
+        const int *rt = rates + (size_t) (gid0 + b) * kJ2kMaxPasses;
+        const double *ds = disto + (size_t) (gid0 + b) * kJ2kMaxPasses;
+        int n = 0;
+        if (thresh < 0) n = tp;
+        else
+            for (int p = 0; p < tp; p++) {
+                unsigned int dr;
+                double dd;
+                if (n == 0) { dr = (unsigned int) rt[p]; dd = ds[p]; }
+                else { dr = (unsigned int) (rt[p] - rt[n - 1]); dd = ds[p] - ds[n - 1]; }
+                if (!dr) { if (dd != 0) n = p + 1; continue; }
+                if (thresh - (dd / dr) < DBL_EPSILON) n = p + 1;
+            }
+        L.npass[b] = (short) n;
+    }
+    __syncthreads();
+}
+
+// total packet bytes of the current assignment (one lane per resolution)
+__device__ int layer_bytes(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum)
+{
+    trees_reset(g, L, lane);
+    if (lane == 0) *s_sum = 0;
+    __syncthreads();
+    if (lane < kJ2kRes) {
+        int body = 0;
+        int hdr = packet_header(lane, g, L.t, L.npass, rates, gid0, nullptr, &body);
+        atomicAdd(s_sum, hdr + body);
+    }
+    __syncthreads();
+    return *s_sum;
+}
+
+// ================================================================================================
+// rate allocation kernel: one workgroup (one wave) per frame
+// ================================================================================================
+__global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ numbps, const int *__restrict__ totalpasses,
+                                                        const int *__restrict__ rates, const double *__restrict__ disto,
+                                                        int *__restrict__ npass_out, const J2kGeom *geom, J2kFrame *jf,
+                                                        const FrameState *fs, const int *active)
+{
+    extern __shared__ unsigned char lds_raw[];
+    __shared__ int s_sum;
+    __shared__ double s_min[kRateThreads], s_max[kRateThreads];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const J2kGeom &g = *geom;
+    const int gid0 = frame * g.nblocks;
+    RateLds L;
+    L.carve(lds_raw, g.nblocks, g.tree_nodes);
+    trees_static(g, L, numbps, gid0, lane);
+
+    // opj_j2k_setup_encoder / opj_j2k_update_rates: byte budget of the single layer
+    float rate = jf[frame].cr / 2;                                   // tcp_rates[0] = base_cr / 2, ebcc_codec.c:116
+    if (rate <= 1.0f) rate = 0.0f;                                   // "force lossless"
+    if (rate > 0.0f) {
+        rate = (float) (((double) 16 * (double) g.W * (double) g.H) / ((double) rate * (double) 8)) - 0.0f;
+        rate -= (float) kMainHeaderBytes / 1.0f;
+        if (rate < 30.0f) rate = 30.0f;
+    }
+
+    // slope range over consecutive passes (opj_tcd_rateallocate)
+    double mn = DBL_MAX, mx = 0;
+    for (int b = lane; b < g.nblocks; b += kRateThreads) {
+        const int tp = totalpasses[gid0 + b];
+        const int *rt = rates + (size_t) (gid0 + b) * kJ2kMaxPasses;
+        const double *ds = disto + (size_t) (gid0 + b) * kJ2kMaxPasses;
+        for (int p = 0; p < tp; p++) {
+            int dr; double dd;
+            if (p == 0) { dr = rt[0]; dd = ds[0]; } else { dr = rt[p] - rt[p - 1]; dd = ds[p] - ds[p - 1]; }
+            if (dr == 0) continue;
+            double sl = dd / dr;
+            if (sl < mn) mn = sl;
+            if (sl > mx) mx = sl;
+        }
+    }
+    s_min[lane] = mn; s_max[lane] = mx;
+    __syncthreads();
+    for (int i = 0; i < kRateThreads; i++) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
+
+    double good = -1;                                                // rate 0: every pass
+    if (rate > 0.0f) {
+        const long long maxlen = (long long) ceil((double) rate);
+        double lo = mn, hi = mx, thresh = 0, stable = 0, prev = -1;
+        for (int i = 0; i < 128; i++) {
+            thresh = (lo + hi) / 2;
+            if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
+            prev = thresh;
+            make_layer(g, L, totalpasses, rates, disto, gid0, thresh, lane);
+            const int bytes = layer_bytes(g, L, rates, gid0, lane, &s_sum);
+            if ((long long) bytes > maxlen) { lo = thresh; continue; }
+            hi = thresh;
+            stable = thresh;
+        }
+        good = stable == 0 ? thresh : stable;
+    }
+    make_layer(g, L, totalpasses, rates, disto, gid0, good, lane);
+    const int body = layer_bytes(g, L, rates, gid0, lane, &s_sum);
+    for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
+    if (lane == 0) {
+        jf[frame].body_bytes = body;
+        jf[frame].stream_bytes = kMainHeaderBytes + 12 + 2 + body + 2;
+        jf[frame].maxlen = (int) (rate > 0.0f ? ceil((double) rate) : 0);
+    }
+}
+
+// ================================================================================================
+// codestream writer: main header (A.5.1, A.6.1, A.6.4, A.9.2), SOT/SOD, packets, EOC
+// ================================================================================================
+__device__ inline void put16(uint8_t *&p, unsigned v) { *p++ = (uint8_t) (v >> 8); *p++ = (uint8_t) v; }
+__device__ inline void put32(uint8_t *&p, unsigned v) { put16(p, v >> 16); put16(p, v & 0xFFFFu); }
+
+__global__ __launch_bounds__(kRateThreads) void k_write(const int *__restrict__ numbps, const int *__restrict__ rates,
+                                                         const int *__restrict__ npass_in, const uint8_t *__restrict__ cblk_bytes,
+                                                         uint8_t *__restrict__ stream, size_t stream_cap, const J2kGeom *geom,
+                                                         J2kFrame *jf, const FrameState *fs, const int *active)
+{
+    extern __shared__ unsigned char lds_raw[];
+    __shared__ int s_hdr[kJ2kRes], s_body[kJ2kRes], s_off[kJ2kRes + 1];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const J2kGeom &g = *geom;
+    const int gid0 = frame * g.nblocks;
+    RateLds L;
+    L.carve(lds_raw, g.nblocks, g.tree_nodes);
+    trees_static(g, L, numbps, gid0, lane);
+    for (int b = lane; b < g.nblocks; b += kRateThreads) L.npass[b] = (short) npass_in[gid0 + b];
+    __syncthreads();
+    uint8_t *base = stream + (size_t) frame * stream_cap;
+
+    // pass 1: sizes
+    trees_reset(g, L, lane);
+    if (lane < kJ2kRes) { int body = 0; s_hdr[lane] = packet_header(lane, g, L.t, L.npass, rates, gid0, nullptr, &body); s_body[lane] = body; }
+    __syncthreads();
+    if (lane == 0) {
+        int off = kMainHeaderBytes + 14;
+        for (int r = 0; r < kJ2kRes; r++) { s_off[r] = off; off += s_hdr[r] + s_body[r]; }
+        s_off[kJ2kRes] = off;
+    }
+    __syncthreads();
+    // pass 2: headers
+    trees_reset(g, L, lane);
+    if (lane < kJ2kRes) { int body = 0; packet_header(lane, g, L.t, L.npass, rates, gid0, base + s_off[lane], &body); }
+    // bodies: every lane copies code-block segments; offsets by a serial walk per resolution (cheap)
+    __syncthreads();
+    if (lane < kJ2kRes) {
+        int off = s_off[lane] + s_hdr[lane];
+        for (int bi = 0; bi < g.nbands; bi++) {
+            const J2kBand &bd = g.bands[bi];
+            if (bd.res != lane) continue;
+            for (int k = 0; k < bd.ncw * bd.nch; k++) {
+                const int blk = bd.first_block + k, n = L.npass[blk];
+                if (!n) continue;
+                const int seglen = rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
+                const uint8_t *src = cblk_bytes + (size_t) (gid0 + blk) * kJ2kCblkBytes;
+                for (int i = 0; i < seglen; i++) base[off + i] = src[i];
+                off += seglen;
+            }
+        }
+    }
+    if (lane == 0) {
+        uint8_t *p = base;
+        put16(p, 0xFF4F);
+        put16(p, 0xFF51); put16(p, 41); put16(p, 0);
+        put32(p, g.W); put32(p, g.H); put32(p, 0); put32(p, 0); put32(p, g.W); put32(p, g.H); put32(p, 0); put32(p, 0);
+        put16(p, 1); *p++ = 15; *p++ = 1; *p++ = 1;
+        put16(p, 0xFF52); put16(p, 12); *p++ = 0; *p++ = 0; put16(p, 1); *p++ = 0; *p++ = kJ2kRes - 1; *p++ = 4; *p++ = 4; *p++ = 0; *p++ = 0;
+        put16(p, 0xFF5C); put16(p, 3 + 2 * kJ2kBands); *p++ = (uint8_t) (2 + (2 << 5));
+        for (int bi = 0; bi < kJ2kBands; bi++) put16(p, (unsigned) ((g.bands[bi].expn << 11) | g.bands[bi].mant));
+        const char com[] = "Created by OpenJPEG version 2.4.0";
+        put16(p, 0xFF64); put16(p, 4 + 33); put16(p, 1);
+        for (int i = 0; i < 33; i++) *p++ = (uint8_t) com[i];
+        const int body = s_off[kJ2kRes] - (kMainHeaderBytes + 14);
+        put16(p, 0xFF90); put16(p, 10); put16(p, 0); put32(p, (unsigned) (12 + 2 + body)); *p++ = 0; *p++ = 1;
+        put16(p, 0xFF93);
+        uint8_t *e = base + s_off[kJ2kRes];
+        put16(e, 0xFFD9);
+        jf[frame].stream_bytes = s_off[kJ2kRes] + 2;
+        jf[frame].body_bytes = body;
+    }
+}
+
+// DC level shift + rounding + clamp (opj_tcd_dc_level_shift_decode), u16 -> fp32 (ebcc_codec.c:1130), statistics
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_finish(const float *__restrict__ B, const float *__restrict__ data,
+                                                 float *__restrict__ DEC, size_t n_pix, const FrameState *fs, J2kFrame *jf,
+                                                 double *partial, unsigned long long *partial_u, const int *active)
+{
+    __shared__ double red[256];
+    __shared__ unsigned int redu[256];
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const float *b = B + (size_t) frame * n_pix;
+    const float *x = STATS ? data + (size_t) frame * n_pix : nullptr;
+    float *d = DEC + (size_t) frame * n_pix;
+    const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
+    const float target = STATS ? jf[frame].target : 0.0f;
+    const size_t chunk = (n_pix + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t) blockIdx.x * chunk, hi = lo + chunk < n_pix ? lo + chunk : n_pix;
+    double acc = 0;
+    unsigned int bad = 0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        float v = b[i];
+        long long s;
+        if (v > 2147483647.0f) s = 65535;
+        else if (v < -2147483648.0f) s = 0;
+        else {
+            s = (long long) __float2int_rn(v) + 32768;
+            s = s < 0 ? 0 : (s > 65535 ? 65535 : s);
+        }
+        float dv = ((float) (int) s / 65535.0f) * rng + mn;
+        d[i] = dv;
+        if (STATS) {
+            float t = x[i] - (dv + 0.0f);
+            acc += (double) t;                                           // get_mean_error, :494-501
+            if (fabsf(t) > target) bad++;                                // get_error_target_quantile, :503-513
+        }
+    }
+    if (!STATS) return;
+    red[threadIdx.x] = acc; redu[threadIdx.x] = bad;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int) threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; redu[threadIdx.x] += redu[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[(size_t) frame * kPartials + blockIdx.x] = red[0];
+        partial_u[(size_t) frame * kPartials + blockIdx.x] = redu[0];
+    }
+}
+
+__global__ void k_finish_reduce(const double *partial, const unsigned long long *partial_u, J2kFrame *jf, int n,
+                                const FrameState *fs, const int *active)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n || (active && !active[f]) || fs[f].const_field) return;
+    double s = 0;
+    unsigned long long b = 0;
+    for (int i = 0; i < kPartials; i++) { s += partial[(size_t) f * kPartials + i]; b += partial_u[(size_t) f * kPartials + i]; }
+    jf[f].err_sum = s;
+    jf[f].nbad = b;
+}
+
+// ================================================================================================
+// true decode: tier-1 MQ decoding, one code-block per lane, values scattered into V (half units)
+// ================================================================================================
+struct DecStore {
+    unsigned long long *st;
+    int32_t *v;        // tile-buffer position of the block's (0,0)
+    int W;
+    __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
+    __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
+    __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
+    __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
+    __device__ void set_sig(int x, int y, int neg, int plane)
+    {
+        int one = 1 << (plane + 1), val = one | (one >> 1);
+        v[(size_t) y * W + x] = neg ? -val : val;
+    }
+    __device__ void refine(int x, int y, int bit, int plane)
+    {
+        int half = 1 << plane;
+        int32_t &d = v[(size_t) y * W + x];
+        d += (bit ^ (d < 0)) ? half : -half;
+    }
+};
+struct DecSrc {
+    const uint8_t *p; int n;
+    __device__ uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; }
+};
+
+// PROBE = true: decode the first npass[gid] passes straight from the encoder's code-block slots (the rate
+// search needs exactly what OpenJPEG would decode from the truncated segment - including the rare
+// cases where the "+3 bytes" truncation heuristic makes the decoder mis-read the tail of the last pass,
+// so the result cannot be derived from the encoder's coefficients alone).
+// PROBE = false: decode the segments located by the host-side packet parser (dec_table).
+template <bool PROBE>
+__global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const uint8_t *bytes, size_t stream_cap,
+                                                   const int *dec_table, const int *numbps, const int *npass,
+                                                   const int *rates, int32_t *V, const J2kGeom *geom,
+                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= total) return;
+    const int nb = geom->nblocks;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    int len, P, np;
+    const uint8_t *src;
+    if (PROBE) {
+        np = npass[gid]; P = numbps[gid];
+        len = np > 0 ? rates[(size_t) gid * kJ2kMaxPasses + np - 1] : 0;
+        src = bytes + (size_t) gid * kJ2kCblkBytes;
+    } else {
+        const int *e = dec_table + (size_t) gid * 4;
+        len = e[1]; P = e[2]; np = e[3];
+        src = bytes + (size_t) frame * stream_cap + e[0];
+    }
+    if (np <= 0 || P <= 0) return;
+    const J2kBlock blk = blocks[bi];
+    const size_t grp = (size_t) (gid >> 6);
+    DecStore st{T1S + grp * kT1StateWords * 64 + (gid & 63),
+                V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
+    t1::decode_block(st, DecSrc{src, len}, blk.w, blk.h, geom->bands[blk.band].orient, P, np);
+}
+
+__global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, const std::uint16_t *__restrict__ blkmap,
+                                                  float *__restrict__ B, const J2kGeom *geom, const J2kBlock *blocks,
+                                                  const FrameState *fs, const int *active)
+{
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const size_t n_pix = (size_t) geom->W * geom->H;
+    const int32_t *v = V + (size_t) frame * n_pix;
+    float *b = B + (size_t) frame * n_pix;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x)
+        b[i] = (float) v[i] * (0.5f * geom->bands[blocks[blkmap[i]].band].step_dec);
+}
+
+size_t rate_lds(const J2kGeom &g)
+{
+    return (((size_t) g.nblocks * 2 + 7) / 8) * 8 + (size_t) g.tree_nodes * 12 + 64;
+}
+
+}  // namespace
+
+// ================================================================================================
+void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), rate_lds(jb.geom), s, jb.numbps, jb.totalpasses, jb.rates,
+                       jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active);
+}
+
+void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_write, dim3(n_frames), dim3(kRateThreads), rate_lds(jb.geom), s, jb.numbps, jb.rates, jb.npass,
+                       jb.cblk_bytes, jb.stream, jb.stream_cap, jb.d_geom, jb.jf, jb.fs, d_active);
+}
+
+static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s)
+{
+    const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
+    hipLaunchKernelGGL(k_dequant, dim3(128, n_frames), dim3(256), 0, s, jb.V, jb.d_blkmap, jb.B, jb.d_geom, jb.d_blocks, jb.fs,
+                       d_active);
+    j2k_inverse_dwt(jb.B, jb.geom, n_frames, jb.fs, d_active, s);
+    if (stats) {
+        hipLaunchKernelGGL(k_finish<true>, dim3(kPartials, n_frames), dim3(256), 0, s, jb.B, data, jb.DEC, n_pix, jb.fs, jb.jf,
+                           jb.partial, jb.partial_u, d_active);
+        hipLaunchKernelGGL(k_finish_reduce, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.partial, jb.partial_u, jb.jf,
+                           n_frames, jb.fs, d_active);
+    } else {
+        hipLaunchKernelGGL(k_finish<false>, dim3(kPartials, n_frames), dim3(256), 0, s, jb.B, (const float *) nullptr, jb.DEC,
+                           n_pix, jb.fs, jb.jf, jb.partial, jb.partial_u, d_active);
+    }
+}
+
+void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
+{
+    const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
+    const int total = n_frames * jb.geom.nblocks;
+    const size_t groups = ((size_t) total + 63) / 64;
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_t1_decode<true>, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.stream_cap,
+                       jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
+    decode_tail(data, jb, n_frames, d_active, true, s);
+}
+
+void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
+{
+    const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
+    const int total = n_frames * jb.geom.nblocks;
+    const size_t groups = ((size_t) total + 63) / 64;
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_t1_decode<false>, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
+                       jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, (const int *) nullptr,
+                       total);
+    decode_tail(nullptr, jb, n_frames, nullptr, false, s);
+}
+
+}  // namespace ebcc

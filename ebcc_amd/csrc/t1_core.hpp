@@ -1,0 +1,552 @@
+// t1_core.hpp - JPEG 2000 tier-1 (T.800 Annex C MQ coder + Annex D bit-plane coding passes) as scalar code
+// on 64-bit ROW MASKS, one code-block per lane.
+//
+// A code-block is at most 64x64, so one u64 holds one property of one row (bit x = column x):
+// significance S, sign NEG, "visited in this plane's significance-propagation pass" VIS, "already
+// refined once" REF and - encoder side - the bit-plane masks BP[plane][row] that a data-parallel
+// kernel extracts with wave ballots.  Neighbourhood tests become shifts of three row masks, columns
+// without candidates are skipped with ctz, and the only per-symbol work left is the context lookup and
+// the MQ coder itself.  Every lane of a wavefront runs this code on its own code-block; the state
+// arrays are interleaved across lanes (element i of lane l at [i * 64 + l]) so that lanes in lock-step
+// touch one contiguous 512-byte line.
+//
+// The same source compiles for the host (tests/t1_host_check.cpp checks it against the oracle) and for
+// gfx950.  Behaviour follows OpenJPEG 2.4.0's t1.c/mqc.c (the reference's dependency, called at
+// /root/reference/src/ebcc_codec.c:173,1116): pass order, run-length mode, contexts, pass-rate
+// conventions (+3 for unterminated passes, no 0xFF as last byte of a pass, final FLUSH).
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define T1_HD __host__ __device__ inline
+#else
+#define T1_HD inline
+#endif
+
+namespace ebcc {
+namespace t1 {
+
+typedef unsigned long long u64;
+
+enum { CTX_ZC0 = 0, CTX_SC0 = 9, CTX_MAG0 = 14, CTX_AGG = 17, CTX_UNI = 18, NCTX = 19 };
+constexpr int kMaxPasses = 3 * 30;
+
+// T.800 table C-2 packed: qe | nmps << 16 | nlps << 22 | switch << 28
+T1_HD uint32_t mq_entry(int i)
+{
+    constexpr uint32_t T[47] = {
+#define E(q, m, l, s) ((uint32_t) (q) | ((uint32_t) (m) << 16) | ((uint32_t) (l) << 22) | ((uint32_t) (s) << 28))
+        E(0x5601, 1, 1, 1),   E(0x3401, 2, 6, 0),   E(0x1801, 3, 9, 0),   E(0x0AC1, 4, 12, 0),  E(0x0521, 5, 29, 0),
+        E(0x0221, 38, 33, 0), E(0x5601, 7, 6, 1),   E(0x5401, 8, 14, 0),  E(0x4801, 9, 14, 0),  E(0x3801, 10, 14, 0),
+        E(0x3001, 11, 17, 0), E(0x2401, 12, 18, 0), E(0x1C01, 13, 20, 0), E(0x1601, 29, 21, 0), E(0x5601, 15, 14, 1),
+        E(0x5401, 16, 14, 0), E(0x5101, 17, 15, 0), E(0x4801, 18, 16, 0), E(0x3801, 19, 17, 0), E(0x3401, 20, 18, 0),
+        E(0x3001, 21, 19, 0), E(0x2801, 22, 19, 0), E(0x2401, 23, 20, 0), E(0x2201, 24, 21, 0), E(0x1C01, 25, 22, 0),
+        E(0x1801, 26, 23, 0), E(0x1601, 27, 24, 0), E(0x1401, 28, 25, 0), E(0x1201, 29, 26, 0), E(0x1101, 30, 27, 0),
+        E(0x0AC1, 31, 28, 0), E(0x09C1, 32, 29, 0), E(0x08A1, 33, 30, 0), E(0x0521, 34, 31, 0), E(0x0441, 35, 32, 0),
+        E(0x02A1, 36, 33, 0), E(0x0221, 37, 34, 0), E(0x0141, 38, 35, 0), E(0x0111, 39, 36, 0), E(0x0085, 40, 37, 0),
+        E(0x0049, 41, 38, 0), E(0x0025, 42, 39, 0), E(0x0015, 43, 40, 0), E(0x0009, 44, 41, 0), E(0x0005, 45, 42, 0),
+        E(0x0001, 45, 43, 0), E(0x5601, 46, 46, 0)};
+#undef E
+    return T[i];
+}
+
+// Context states: 19 contexts x (6-bit state index + mps) packed in two u64 words would need dynamic
+// bit-field updates; a small per-lane byte array in registers/scratch is simpler: state | mps << 7.
+struct Contexts {
+    // 19 contexts x 7 bits (6-bit state index | mps << 6) packed 9 per word: no dynamically indexed
+    // array, so the state stays in registers on the GPU.
+    u64 w0, w1, w2;
+    T1_HD void reset()
+    {
+        w0 = w1 = w2 = 0;
+        set(CTX_UNI, 46); set(CTX_AGG, 3); set(CTX_ZC0, 4);              // T.800 table D-7
+    }
+    T1_HD uint32_t get(int i) const
+    {
+        int k = i >= 18 ? i - 18 : (i >= 9 ? i - 9 : i);
+        u64 w = i >= 18 ? w2 : (i >= 9 ? w1 : w0);
+        return (uint32_t) (w >> (7 * k)) & 0x7Fu;
+    }
+    T1_HD void set(int i, uint32_t v)
+    {
+        int k = i >= 18 ? i - 18 : (i >= 9 ? i - 9 : i);
+        u64 m = 0x7Full << (7 * k), nv = (u64) (v & 0x7Fu) << (7 * k);
+        if (i >= 18) w2 = (w2 & ~m) | nv;
+        else if (i >= 9) w1 = (w1 & ~m) | nv;
+        else w0 = (w0 & ~m) | nv;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// MQ encoder (C.2).  Sink: void put(int index, uint8_t byte)
+// ------------------------------------------------------------------------------------------------
+template <class Sink>
+struct MqEncoder {
+    uint32_t a, c;
+    int ct;
+    int n;            // index of the byte being formed (== opj_mqc_numbytes)
+    uint32_t cur;     // its value; index -1 is the non-FF byte that precedes the segment
+    Contexts cx;
+    Sink sink;
+
+    T1_HD void init()
+    {
+        cx.reset();
+        a = 0x8000; c = 0; ct = 12; n = -1; cur = 0;
+    }
+    T1_HD void emit() { if (n >= 0) sink.put(n, (uint8_t) cur); }
+    T1_HD void byteout()
+    {
+        if (cur == 0xFF) {
+            emit(); n++; cur = c >> 20; c &= 0xFFFFF; ct = 7;
+        } else if ((c & 0x8000000) == 0) {
+            emit(); n++; cur = c >> 19; c &= 0x7FFFF; ct = 8;
+        } else {
+            cur++;
+            if (cur == 0xFF) {
+                c &= 0x7FFFFFF;
+                emit(); n++; cur = c >> 20; c &= 0xFFFFF; ct = 7;
+            } else {
+                emit(); n++; cur = c >> 19; c &= 0x7FFFF; ct = 8;
+            }
+        }
+    }
+    T1_HD void renorm()
+    {
+        do {
+            a <<= 1; c <<= 1; ct--;
+            if (ct == 0) byteout();
+        } while ((a & 0x8000) == 0);
+    }
+    T1_HD void encode(int ctx, int d)
+    {
+        uint32_t st = cx.get(ctx);
+        uint32_t e = mq_entry(st & 0x3F);
+        uint32_t qe = e & 0xFFFF;
+        int mps = st >> 6;
+        a -= qe;
+        if (d == mps) {
+            if ((a & 0x8000) == 0) {
+                if (a < qe) a = qe; else c += qe;
+                cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6));
+                renorm();
+            } else {
+                c += qe;
+            }
+        } else {
+            if (a < qe) c += qe; else a = qe;
+            if (e >> 28) mps ^= 1;
+            cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6));
+            renorm();
+        }
+    }
+    T1_HD int numbytes() const { return n; }
+    T1_HD void flush()
+    {
+        uint32_t tempc = c + a;                                           // SETBITS
+        c |= 0xFFFF;
+        if (c >= tempc) c -= 0x8000;
+        c <<= ct; byteout();
+        c <<= ct; byteout();
+        emit();
+        if (cur != 0xFF) n++;                                             // a trailing FF is not part of the segment
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// MQ decoder (C.3).  Source: uint32_t get(int index) returning 0xFF past the end
+// ------------------------------------------------------------------------------------------------
+template <class Source>
+struct MqDecoder {
+    uint32_t a, c;
+    int ct, pos;
+    Contexts cx;
+    Source src;
+
+    T1_HD void bytein()
+    {
+        uint32_t cur = src.get(pos), nxt = src.get(pos + 1);
+        if (cur == 0xFF) {
+            if (nxt > 0x8F) { c += 0xFF00; ct = 8; }
+            else { pos++; c += nxt << 9; ct = 7; }
+        } else {
+            pos++; c += nxt << 8; ct = 8;
+        }
+    }
+    T1_HD void init()
+    {
+        cx.reset();
+        pos = 0;
+        c = src.get(0) << 16;
+        bytein();
+        c <<= 7; ct -= 7; a = 0x8000;
+    }
+    T1_HD void renorm()
+    {
+        do {
+            if (ct == 0) bytein();
+            a <<= 1; c <<= 1; ct--;
+        } while ((a & 0x8000) == 0);
+    }
+    T1_HD int decode(int ctx)
+    {
+        uint32_t st = cx.get(ctx);
+        uint32_t e = mq_entry(st & 0x3F);
+        uint32_t qe = e & 0xFFFF;
+        int mps = st >> 6, d;
+        a -= qe;
+        if ((c >> 16) < qe) {
+            if (a < qe) { d = mps; cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6)); }
+            else { d = 1 - mps; if (e >> 28) mps ^= 1; cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6)); }
+            a = qe;
+            renorm();
+        } else {
+            c -= qe << 16;
+            if ((a & 0x8000) == 0) {
+                if (a < qe) { d = 1 - mps; if (e >> 28) mps ^= 1; cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6)); }
+                else { d = mps; cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6)); }
+                renorm();
+            } else {
+                d = mps;
+            }
+        }
+        return d;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// contexts from row masks
+// ------------------------------------------------------------------------------------------------
+// three bits {x-1, x, x+1} of a row mask, at bit positions 0..2
+T1_HD uint32_t tri(u64 m, int x) { return (uint32_t) ((x ? (m >> (x - 1)) : (m << 1)) & 7u); }
+
+// zero-coding context, T.800 table D-1.  up/mid/dn: tri() of significance of rows y-1, y, y+1.
+T1_HD int ctx_zc(uint32_t up, uint32_t mid, uint32_t dn, int orient)
+{
+    int h = (int) (mid & 1) + (int) ((mid >> 2) & 1);
+    int v = (int) ((up >> 1) & 1) + (int) ((dn >> 1) & 1);
+    int d = (int) (up & 1) + (int) ((up >> 2) & 1) + (int) (dn & 1) + (int) ((dn >> 2) & 1);
+    int n;
+    if (orient == 1) { int t = h; h = v; v = t; }
+    if (orient == 3) {
+        int hv = h + v;
+        if (d == 0) n = hv == 0 ? 0 : (hv == 1 ? 1 : 2);
+        else if (d == 1) n = hv == 0 ? 3 : (hv == 1 ? 4 : 5);
+        else if (d == 2) n = hv == 0 ? 6 : 7;
+        else n = 8;
+    } else {
+        if (h == 0) {
+            if (v == 0) n = d == 0 ? 0 : (d == 1 ? 1 : 2);
+            else if (v == 1) n = 3;
+            else n = 4;
+        } else if (h == 1) {
+            if (v == 0) n = d == 0 ? 5 : 6;
+            else n = 7;
+        } else n = 8;
+    }
+    return CTX_ZC0 + n;
+}
+
+// sign-coding context and XOR bit, tables D-2/D-3.  s*: tri() of significance, n*: tri() of sign masks
+T1_HD int ctx_sc(uint32_t sup, uint32_t smid, uint32_t sdn, uint32_t nup, uint32_t nmid, uint32_t ndn, int &xorbit)
+{
+    int hc = 0, vc = 0;
+    if (smid & 1) hc += (nmid & 1) ? -1 : 1;
+    if (smid & 4) hc += (nmid & 4) ? -1 : 1;
+    if (sup & 2) vc += (nup & 2) ? -1 : 1;
+    if (sdn & 2) vc += (ndn & 2) ? -1 : 1;
+    hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc);
+    vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
+    int n, xb = 0;
+    if (hc == 1) n = vc == 1 ? 4 : (vc == 0 ? 3 : 2);
+    else if (hc == 0) { if (vc == 1) n = 1; else if (vc == 0) n = 0; else { n = 1; xb = 1; } }
+    else { xb = 1; n = vc == 1 ? 2 : (vc == 0 ? 3 : 4); }
+    xorbit = xb;
+    return CTX_SC0 + n;
+}
+
+T1_HD int ctz64(u64 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long) v) - 1;
+#else
+    return __builtin_ctzll(v);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Code-block state accessors (a "Store" provides these; indices are logical)
+//   u64 &S(int y)    y in [-1, 64]          significance
+//   u64 &NEG(int y), &VIS(int y), &REF(int y)   y in [0, 64)
+// Encoder store additionally:  u64 BP(int plane, int y) (bit-plane masks), u64 SGN(int y) (sign of every
+//   coefficient), u64 &SPS(int y) (output: became significant in a significance-propagation pass)
+// Decoder store additionally:  void set_sig(int x, int y, int neg, int plane), void refine(int x, int y, int bit, int plane)
+// ------------------------------------------------------------------------------------------------
+
+// One stripe worth of state held in locals (fully unrolled accesses keep it in registers).
+struct Stripe {
+    u64 s[6];        // significance rows y0-1 .. y0+4
+    u64 neg[6];      // signs of those rows
+    u64 vis[4];
+    u64 valid[4];
+};
+
+template <bool ENC, class Store, class Coder>
+struct Passes {
+    Store &st;
+    Coder &mq;
+    int w, h, orient;
+
+    T1_HD Passes(Store &s, Coder &c, int w_, int h_, int o) : st(s), mq(c), w(w_), h(h_), orient(o) {}
+
+    T1_HD void load(Stripe &sp, int y0)
+    {
+        const u64 wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            int y = y0 - 1 + r;
+            sp.s[r] = st.S(y);
+            sp.neg[r] = (y >= 0 && y < 64) ? st.NEG(y) : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            sp.vis[r] = st.VIS(y0 + r);
+            sp.valid[r] = (y0 + r < h) ? wmask : 0ull;
+        }
+    }
+    T1_HD void store(const Stripe &sp, int y0)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            st.S(y0 + r) = sp.s[r + 1];
+            st.NEG(y0 + r) = sp.neg[r + 1];
+            st.VIS(y0 + r) = sp.vis[r];
+        }
+    }
+
+    // sign coding of (x, row r) and state update; returns nothing.  R is a compile-time row.
+    template <int R>
+    T1_HD void code_sign(Stripe &sp, int x, int y0, int plane, bool from_sigprop)
+    {
+        int xb;
+        int cx = ctx_sc(tri(sp.s[R], x), tri(sp.s[R + 1], x), tri(sp.s[R + 2], x), tri(sp.neg[R], x), tri(sp.neg[R + 1], x),
+                        tri(sp.neg[R + 2], x), xb);
+        int neg;
+        if constexpr (ENC) {
+            neg = (int) ((st.SGN(y0 + R) >> x) & 1);
+            mq.encode(cx, neg ^ xb);
+        } else {
+            neg = mq.decode(cx) ^ xb;
+        }
+        sp.s[R + 1] |= 1ull << x;
+        if (neg) sp.neg[R + 1] |= 1ull << x;
+        if constexpr (ENC) { if (from_sigprop) st.SPS(y0 + R) |= 1ull << x; }
+        else st.set_sig(x, y0 + R, neg, plane);
+    }
+
+    // ---------------- significance propagation pass over one stripe
+    template <int R>
+    T1_HD bool sigprop_cell(Stripe &sp, int x, int y0, int plane, u64 bp)
+    {
+        const u64 bit = 1ull << x;
+        if (!(sp.valid[R] & bit) || (sp.s[R + 1] & bit)) return false;
+        uint32_t up = tri(sp.s[R], x), mid = tri(sp.s[R + 1], x), dn = tri(sp.s[R + 2], x);
+        if ((up | (mid & 5u) | dn) == 0) return false;
+        int cx = ctx_zc(up, mid, dn, orient);
+        int v;
+        if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
+        else v = mq.decode(cx);
+        sp.vis[R] |= bit;
+        if (v) { code_sign<R>(sp, x, y0, plane, true); return true; }
+        return false;
+    }
+
+    T1_HD void sigprop(int plane)
+    {
+        for (int y0 = 0; y0 < h; y0 += 4) {
+            Stripe sp;
+            load(sp, y0);
+            u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
+            // columns that can hold a candidate given the significance known so far
+            u64 nb = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) nb |= sp.s[r];
+            u64 pending = (nb | (nb << 1) | (nb >> 1)) & (sp.valid[0]);
+            while (pending) {
+                int x = ctz64(pending);
+                pending &= pending - 1;
+                bool grew = false;
+                grew |= sigprop_cell<0>(sp, x, y0, plane, b0);
+                grew |= sigprop_cell<1>(sp, x, y0, plane, b1);
+                grew |= sigprop_cell<2>(sp, x, y0, plane, b2);
+                grew |= sigprop_cell<3>(sp, x, y0, plane, b3);
+                if (grew && x + 1 < w) pending |= 1ull << (x + 1);       // a new neighbour to the right
+            }
+            store(sp, y0);
+        }
+    }
+
+    // ---------------- magnitude refinement pass
+    template <int R>
+    T1_HD void refine_cell(Stripe &sp, u64 &ref, int x, int y0, int plane, u64 bp)
+    {
+        const u64 bit = 1ull << x;
+        if (!(sp.s[R + 1] & bit) || (sp.vis[R] & bit) || !(sp.valid[R] & bit)) return;
+        int cx;
+        if (ref & bit) cx = CTX_MAG0 + 2;
+        else {
+            uint32_t up = tri(sp.s[R], x), mid = tri(sp.s[R + 1], x), dn = tri(sp.s[R + 2], x);
+            cx = CTX_MAG0 + ((up | (mid & 5u) | dn) ? 1 : 0);
+        }
+        int v;
+        if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
+        else { v = mq.decode(cx); st.refine(x, y0 + R, v, plane); }
+        ref |= bit;
+    }
+
+    T1_HD void refine(int plane)
+    {
+        for (int y0 = 0; y0 < h; y0 += 4) {
+            Stripe sp;
+            load(sp, y0);
+            u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
+            u64 r0 = st.REF(y0), r1 = st.REF(y0 + 1), r2 = st.REF(y0 + 2), r3 = st.REF(y0 + 3);
+            u64 pending = (sp.s[1] & ~sp.vis[0] & sp.valid[0]) | (sp.s[2] & ~sp.vis[1] & sp.valid[1]) |
+                          (sp.s[3] & ~sp.vis[2] & sp.valid[2]) | (sp.s[4] & ~sp.vis[3] & sp.valid[3]);
+            while (pending) {
+                int x = ctz64(pending);
+                pending &= pending - 1;
+                refine_cell<0>(sp, r0, x, y0, plane, b0);
+                refine_cell<1>(sp, r1, x, y0, plane, b1);
+                refine_cell<2>(sp, r2, x, y0, plane, b2);
+                refine_cell<3>(sp, r3, x, y0, plane, b3);
+            }
+            st.REF(y0) = r0; st.REF(y0 + 1) = r1; st.REF(y0 + 2) = r2; st.REF(y0 + 3) = r3;
+        }
+    }
+
+    // ---------------- cleanup pass
+    template <int R>
+    T1_HD void cleanup_cell(Stripe &sp, int x, int y0, int plane, u64 bp, bool skip_zc)
+    {
+        const u64 bit = 1ull << x;
+        if (!skip_zc) {
+            if (!(sp.valid[R] & bit) || (sp.s[R + 1] & bit) || (sp.vis[R] & bit)) return;
+        }
+        int v = 1;
+        if (!skip_zc) {
+            int cx = ctx_zc(tri(sp.s[R], x), tri(sp.s[R + 1], x), tri(sp.s[R + 2], x), orient);
+            if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
+            else v = mq.decode(cx);
+        }
+        if (v) code_sign<R>(sp, x, y0, plane, false);
+    }
+
+    T1_HD void cleanup(int plane)
+    {
+        for (int y0 = 0; y0 < h; y0 += 4) {
+            Stripe sp;
+            load(sp, y0);
+            u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
+            const bool full = y0 + 3 < h;
+            u64 pending = (~sp.s[1] & ~sp.vis[0] & sp.valid[0]) | (~sp.s[2] & ~sp.vis[1] & sp.valid[1]) |
+                          (~sp.s[3] & ~sp.vis[2] & sp.valid[2]) | (~sp.s[4] & ~sp.vis[3] & sp.valid[3]);
+            while (pending) {
+                int x = ctz64(pending);
+                pending &= pending - 1;
+                const u64 bit = 1ull << x;
+                // run-length mode: the whole column is insignificant, unvisited and has an all-zero neighbourhood
+                bool agg = false;
+                if (full && !((sp.vis[0] | sp.vis[1] | sp.vis[2] | sp.vis[3]) & bit)) {
+                    uint32_t any = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) any |= tri(sp.s[r], x);
+                    agg = any == 0;
+                }
+                int start = 0;
+                if (agg) {
+                    if constexpr (ENC) {
+                        int run = (b0 >> x) & 1 ? 0 : ((b1 >> x) & 1 ? 1 : ((b2 >> x) & 1 ? 2 : ((b3 >> x) & 1 ? 3 : 4)));
+                        mq.encode(CTX_AGG, run != 4);
+                        if (run == 4) continue;
+                        mq.encode(CTX_UNI, run >> 1);
+                        mq.encode(CTX_UNI, run & 1);
+                        start = run;
+                    } else {
+                        if (!mq.decode(CTX_AGG)) continue;
+                        start = mq.decode(CTX_UNI);
+                        start = (start << 1) | mq.decode(CTX_UNI);
+                    }
+                }
+                if (start <= 0) cleanup_cell<0>(sp, x, y0, plane, b0, agg && start == 0);
+                if (start <= 1) cleanup_cell<1>(sp, x, y0, plane, b1, agg && start == 1);
+                if (start <= 2) cleanup_cell<2>(sp, x, y0, plane, b2, agg && start == 2);
+                if (start <= 3) cleanup_cell<3>(sp, x, y0, plane, b3, agg && start == 3);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) sp.vis[r] = 0;                   // the visited flags die with the plane
+            store(sp, y0);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// whole code-block drivers
+// ------------------------------------------------------------------------------------------------
+struct EncodeResult {
+    int totalpasses;
+    int length;                 // bytes in the segment
+};
+
+// Encodes every pass of a code-block with `numbps` magnitude bit-planes (numbps >= 1).
+// rates[p] follow OpenJPEG: bytes completed + 3 for unterminated passes, clipped to be non-decreasing,
+// never ending on 0xFF (needs read access to the bytes: ByteAt(int) -> uint8_t).
+template <class Store, class Sink, class ByteAt>
+T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates)
+{
+    MqEncoder<Sink> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink};
+    mq.init();
+    Passes<true, Store, MqEncoder<Sink>> ps(st, mq, w, h, orient);
+    int passno = 0, passtype = 2;
+    for (int bp = numbps - 1; bp >= 0; passno++) {
+        if (passtype == 0) ps.sigprop(bp);
+        else if (passtype == 1) ps.refine(bp);
+        else ps.cleanup(bp);
+        if (passtype == 2 && bp == 0) { mq.flush(); rates[passno] = mq.numbytes(); }
+        else rates[passno] = (int) ((uint32_t) mq.numbytes() + 3u);
+        if (++passtype == 3) { passtype = 0; bp--; }
+    }
+    int last = mq.numbytes();
+    for (int p = passno; p > 0;) {
+        --p;
+        if (rates[p] > last) rates[p] = last; else last = rates[p];
+    }
+    for (int p = 0; p < passno; p++)
+        if (rates[p] > 0 && bytes(rates[p] - 1) == 0xFF) rates[p]--;
+    EncodeResult r;
+    r.totalpasses = passno;
+    r.length = mq.numbytes();
+    return r;
+}
+
+template <class Store, class Source>
+T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses)
+{
+    MqDecoder<Source> mq{0, 0, 0, 0, {0, 0, 0}, src};
+    mq.init();
+    Passes<false, Store, MqDecoder<Source>> ps(st, mq, w, h, orient);
+    int passtype = 2, bp = numbps - 1;
+    for (int p = 0; p < npasses && bp >= 0; p++) {
+        if (passtype == 0) ps.sigprop(bp);
+        else if (passtype == 1) ps.refine(bp);
+        else ps.cleanup(bp);
+        if (++passtype == 3) { passtype = 0; bp--; }
+    }
+}
+
+}  // namespace t1
+}  // namespace ebcc

@@ -1074,15 +1074,14 @@ static void make_layer(tile_t *t, double thresh)
         }
 }
 
-size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
+/* everything of the encoder that does not depend on the rate: transform, quantisation, tier-1 */
+static void j2k_analyse(const uint16_t *img, int H, int W, tile_t *tp, int *expn, int *mant)
 {
     init_luts();
-    const int W = (int) width, H = (int) height, prec = 16, guard = 2;
-    tile_t t;
-    tile_init(&t, W, H);
+    const int prec = 16, guard = 2;
+    tile_init(tp, W, H);
 
     /* QCD step sizes: opj_dwt_calc_explicit_stepsizes + encode_stepsize */
-    int expn[3 * J2K_NRES - 2], mant[3 * J2K_NRES - 2];
     for (int bi = 0; bi < 3 * J2K_NRES - 2; bi++) {
         int resno = bi == 0 ? 0 : (bi - 1) / 3 + 1, orient = bi == 0 ? 0 : (bi - 1) % 3 + 1;
         int level = J2K_NRES - 1 - resno;
@@ -1093,8 +1092,8 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
         expn[bi] = prec - p;
     }
     for (int r = 0; r < J2K_NRES; r++)
-        for (int b = 0; b < t.res[r].nbands; b++) {
-            band_t *bd = &t.res[r].bands[b];
+        for (int b = 0; b < tp->res[r].nbands; b++) {
+            band_t *bd = &tp->res[r].bands[b];
             int bi = r == 0 ? 0 : 3 * (r - 1) + b + 1;
             band_set_quant(bd, expn[bi], mant[bi], prec, guard);
             /* encoder-side step carries the sub-band gain (OpenJPEG pairs this with its 2/K synthesis scaling) */
@@ -1105,12 +1104,12 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
     /* DC level shift to float, forward transform */
     float *buf = (float *) malloc((size_t) W * H * sizeof(float));
     for (size_t i = 0; i < (size_t) W * H; i++) buf[i] = (float) ((int) img[i] - (1 << (prec - 1)));
-    fdwt97_tile(buf, &t);
+    fdwt97_tile(buf, tp);
 
     /* tier-1 */
     for (int r = 0; r < J2K_NRES; r++)
-        for (int b = 0; b < t.res[r].nbands; b++) {
-            band_t *bd = &t.res[r].bands[b];
+        for (int b = 0; b < tp->res[r].nbands; b++) {
+            band_t *bd = &tp->res[r].bands[b];
             for (int ci = 0; ci < bd->ncw * bd->nch; ci++) {
                 cblk_t *cb = &bd->cblks[ci];
                 t1e_t e;
@@ -1130,6 +1129,15 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
             }
         }
     free(buf);
+
+}
+
+size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
+{
+    const int W = (int) width, H = (int) height, prec = 16, guard = 2;
+    tile_t t;
+    int expn[3 * J2K_NRES - 2], mant[3 * J2K_NRES - 2];
+    j2k_analyse(img, H, W, &t, expn, mant);
 
     /* main header (A.5.1, A.6.1, A.6.4, A.9.2) */
     static const char comment[] = "Created by OpenJPEG version 2.4.0";
@@ -1205,4 +1213,64 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
     tile_free(&t);
     *out = o;
     return (size_t) (p - o);
+}
+
+/* ================================================================================================
+ * unit-level entry points used by the tests to pin the product's tier-1 coder block by block
+ * ============================================================================================== */
+/* q: w*h quantised coefficients WITH 6 fractional bits (what lrintf((c/step)*64) yields) */
+int orc_j2k_t1_encode(const int32_t *q, int w, int h, int orient, int level, float stepsize, uint8_t *out, int out_cap,
+                      int *numbps, int *rates, double *disto)
+{
+    init_luts();
+    t1e_t e;
+    cblk_t cb;
+    memset(&cb, 0, sizeof cb);
+    t1_alloc(&e.t, w, h);
+    e.mag = (uint32_t *) malloc((size_t) w * h * sizeof(uint32_t));
+    for (int i = 0; i < w * h; i++) { e.t.data[i] = q[i]; e.mag[i] = (uint32_t) (q[i] < 0 ? -q[i] : q[i]); }
+    t1_encode_cblk(&e, &cb, orient, level, stepsize);
+    *numbps = cb.numbps;
+    for (int p = 0; p < cb.totalpasses; p++) { rates[p] = cb.rate[p]; disto[p] = cb.disto[p]; }
+    int n = cb.len < out_cap ? cb.len : out_cap;
+    if (cb.data) memcpy(out, cb.data, (size_t) n);
+    free(cb.data); free(e.mag); t1_free(&e.t);
+    return cb.totalpasses;
+}
+
+/* decode `npasses` passes of a code-block; out: w*h values in OpenJPEG's half-unit convention */
+void orc_j2k_t1_decode(const uint8_t *data, int len, int numbps, int npasses, int w, int h, int orient, int32_t *out)
+{
+    t1_t t;
+    cblk_t cb;
+    memset(&cb, 0, sizeof cb);
+    cb.data = (uint8_t *) data; cb.len = len; cb.numbps = numbps; cb.npasses = npasses;
+    t1_alloc(&t, w, h);
+    t1_decode_cblk(&t, &cb, orient);
+    memcpy(out, t.data, (size_t) w * h * sizeof(int32_t));
+    t1_free(&t);
+}
+
+/* per-code-block tier-1 results in packet order (resolution, band, raster): for pinning the device analysis */
+int orc_j2k_analysis(const uint16_t *img, size_t height, size_t width, int *numbps, int *totalpasses, int *lens,
+                     int *rates /* [nb][100] */, double *disto /* [nb][100] */, unsigned *hashes)
+{
+    tile_t t;
+    int expn[3 * J2K_NRES - 2], mant[3 * J2K_NRES - 2];
+    j2k_analyse(img, (int) height, (int) width, &t, expn, mant);
+    int nb = 0;
+    for (int r = 0; r < J2K_NRES; r++)
+        for (int b = 0; b < t.res[r].nbands; b++) {
+            band_t *bd = &t.res[r].bands[b];
+            for (int ci = 0; ci < bd->ncw * bd->nch; ci++, nb++) {
+                cblk_t *cb = &bd->cblks[ci];
+                numbps[nb] = cb->numbps; totalpasses[nb] = cb->totalpasses; lens[nb] = cb->len;
+                for (int p = 0; p < cb->totalpasses; p++) { rates[nb * 100 + p] = cb->rate[p]; disto[nb * 100 + p] = cb->disto[p]; }
+                unsigned hsh = 0;
+                for (int k = 0; k < cb->len; k++) hsh = hsh * 131 + cb->data[k];
+                hashes[nb] = hsh;
+            }
+        }
+    tile_free(&t);
+    return nb;
 }

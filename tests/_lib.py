@@ -175,6 +175,13 @@ def product():
         lib.ebcc_hip_spiht_coeffs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                               ctypes.c_void_p]
         lib.ebcc_hip_last_error.restype = ctypes.c_char_p
+        if hasattr(lib, "ebcc_hip_j2k_encode"):
+            lib.ebcc_hip_j2k_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, c_void_pp,
+                                                c_size_p, ctypes.c_void_p]
+            lib.ebcc_hip_j2k_emulated_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            lib.ebcc_hip_j2k_decode.argtypes = [ctypes.c_void_p, c_void_pp, c_size_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                ctypes.c_void_p]
         lib.free_buffer.argtypes = [ctypes.c_void_p]
         if hasattr(lib, "ebcc_hip_encode_frames"):
             lib.ebcc_hip_encode_frames.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
@@ -294,6 +301,51 @@ class Context:
         d.free()
         return c, dc
 
+    # ---- JPEG 2000 base layer
+    def j2k_encode(self, frames, cr, keep_device=False):
+        frames = np.ascontiguousarray(frames, np.float32)
+        n = frames.shape[0]
+        d = DeviceArray(frames)
+        crs = np.ascontiguousarray(cr, np.float32)
+        outs = (ctypes.c_void_p * n)()
+        sizes = (ctypes.c_size_t * n)()
+        mm = np.zeros(2 * n, np.float32)
+        rc = self.lib.ebcc_hip_j2k_encode(self.ptr, d.ptr, n, crs.ctypes.data, outs, sizes, mm.ctypes.data)
+        assert rc == 0, self.lib.ebcc_hip_last_error()
+        res = []
+        for f in range(n):
+            res.append(ctypes.string_at(outs[f], sizes[f]))
+            self.lib.free_buffer(outs[f])
+        if keep_device:
+            return res, mm.reshape(n, 2), d
+        d.free()
+        return res, mm.reshape(n, 2)
+
+    def j2k_emulated_decode(self, d_frames, n, target):
+        tg = np.ascontiguousarray(target, np.float32)
+        out = DeviceArray(nbytes=n * self.h * self.w * 4)
+        nbad = np.zeros(n, np.uint64)
+        esum = np.zeros(n, np.float64)
+        rc = self.lib.ebcc_hip_j2k_emulated_decode(self.ptr, d_frames.ptr, n, tg.ctypes.data, out.ptr, nbad.ctypes.data,
+                                                   esum.ctypes.data)
+        assert rc == 0, self.lib.ebcc_hip_last_error()
+        res = out.get(np.float32, (n, self.h, self.w))
+        out.free()
+        return res, nbad, esum
+
+    def j2k_decode(self, streams, minmax):
+        n = len(streams)
+        bufs = [ctypes.create_string_buffer(bytes(s), len(s)) for s in streams]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(b, ctypes.c_void_p).value for b in bufs])
+        sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
+        mm = np.ascontiguousarray(minmax, np.float32)
+        out = DeviceArray(nbytes=n * self.h * self.w * 4)
+        rc = self.lib.ebcc_hip_j2k_decode(self.ptr, ptrs, sizes, n, mm.ctypes.data, out.ptr)
+        assert rc == 0, self.lib.ebcc_hip_last_error()
+        res = out.get(np.float32, (n, self.h, self.w))
+        out.free()
+        return res
+
     # ---- frame codec
     def encode_frames(self, frames, cfg):
         frames = np.ascontiguousarray(frames, np.float32)
@@ -324,6 +376,39 @@ class Context:
 
 
 # ------------------------------------------------------------------------------------------ inputs
+def scale_u16(field):
+    """ebcc_codec.c:686-689 in float32 arithmetic."""
+    field = np.ascontiguousarray(field, np.float32)
+    mn, mx = field.min(), field.max()
+    return (((field - mn) / (mx - mn)) * np.float32(65535)).astype(np.uint16), mn, mx
+
+
+def orc_j2k_encode(img_u16, cr):
+    lib = oracle()
+    img = np.ascontiguousarray(img_u16, np.uint16)
+    out = ctypes.c_void_p()
+    n = lib.orc_j2k_encode(img.ctypes.data, img.shape[0], img.shape[1], ctypes.c_float(cr), ctypes.byref(out))
+    s = ctypes.string_at(out.value, n)
+    lib.orc_free(out)
+    return s
+
+
+def orc_j2k_decode(stream):
+    lib = oracle()
+    b = ctypes.create_string_buffer(bytes(stream), len(stream))
+    out, h, w = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+    n = lib.orc_j2k_decode(b, len(stream), ctypes.byref(out), ctypes.byref(h), ctypes.byref(w))
+    assert n
+    a = np.frombuffer(ctypes.string_at(out.value, 4 * n), np.int32).reshape(h.value, w.value).copy()
+    lib.orc_free(out)
+    return a
+
+
+def map_decoded(samples, mn, mx):
+    """ebcc_codec.c:1130 in float32 arithmetic."""
+    return (samples.astype(np.float32) / np.float32(65535)) * (np.float32(mx) - np.float32(mn)) + np.float32(mn)
+
+
 def kat_image(h, w):
     """a[y,x] = float32((7x+13y) mod 97) / float32(96)."""
     y, x = np.mgrid[0:h, 0:w]

@@ -199,7 +199,7 @@ static void run_spiht_encode(ebcc_hip_ctx *ctx, size_t n, const size_t *trunc_bi
     }
     push_frame_states(ctx, n);
     EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, s);
+    launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, nullptr, s);
 }
 
 static int collect_streams(ebcc_hip_ctx *ctx, size_t n, uint8_t **out_streams, size_t *out_sizes)
@@ -230,7 +230,7 @@ int ebcc_hip_spiht_encode(ebcc_hip_ctx *ctx, const float *d_images, size_t n_fra
     }
     hipStream_t s = ctx->stream;
     launch_pad_and_dc_from_image(d_images, ctx->rb, (int) n_frames, s);
-    launch_analysis(ctx->rb, (int) n_frames, s);
+    launch_analysis(ctx->rb, (int) n_frames, nullptr, s);
     run_spiht_encode(ctx, n_frames, trunc_bits);
     return collect_streams(ctx, n_frames, out_streams, out_sizes);
 }
@@ -240,7 +240,7 @@ int ebcc_hip_spiht_coeffs(ebcc_hip_ctx *ctx, const float *d_images, size_t n_fra
     if (check_batch(ctx, n_frames, "ebcc_hip_spiht_coeffs")) return 1;
     hipStream_t s = ctx->stream;
     launch_pad_and_dc_from_image(d_images, ctx->rb, (int) n_frames, s);
-    launch_analysis(ctx->rb, (int) n_frames, s);
+    launch_analysis(ctx->rb, (int) n_frames, nullptr, s);
     EBCC_HIP_CHECK(hipMemcpyAsync(coeffs, ctx->rb.C, n_frames * ctx->rb.np * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     fetch_frame_states(ctx, n_frames);
     for (size_t f = 0; f < n_frames; f++) dc[f] = (int) ctx->h_fs[f].dc;

@@ -1,6 +1,988 @@
-// host_codec.hip - placeholder
-#include "engine.hpp"
+// host_codec.hip - the reference's C API (include/ebcc_codec.h) and HDF5 filter glue on top of the
+// MI355X engine: frame-codec orchestration (/root/reference/src/ebcc_codec.c:607-918 encode,
+// :1215-1320 decode), the EBCK chunk container (:920-1090, :1322-1449) and the filter plugin
+// (/root/reference/src/h5z_ebcc.c).  The host only steers: per-frame scalars come back from the device
+// after every probe, every per-sample operation runs in the kernels.  There is no CPU fallback: without
+// a HIP device every entry point fails loudly.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "../../include/ebcc_hip.h"
-extern "C" {
-__attribute__((visibility("default"))) void free_buffer(void *p) { if (p) free(p); }
+#include "engine.hpp"
+#include "j2k.hpp"
+
+namespace ebcc {
+bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table);
 }
+using namespace ebcc;
+
+// ================================================================================================
+// logging (reference src/log/, level from EBCC_LOG_LEVEL, default WARN; src/ebcc_codec.c:431-448)
+// ================================================================================================
+namespace {
+int g_log_level = 3;
+const char *kLevelNames[] = {"TRACE", "DEBUG", "INFO", "WARN", "ERROR", "FATAL"};
+void log_at(int level, const char *fmt, ...)
+{
+    if (level < g_log_level) return;
+    char tb[16];
+    time_t t = time(nullptr);
+    struct tm lt;
+    localtime_r(&t, &lt);
+    strftime(tb, sizeof tb, "%H:%M:%S", &lt);
+    fprintf(stderr, "%s %-5s ebcc-mi355x: ", tb, kLevelNames[level]);
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+#define log_trace(...) log_at(0, __VA_ARGS__)
+#define log_info(...) log_at(2, __VA_ARGS__)
+#define log_warn(...) log_at(3, __VA_ARGS__)
+#define log_fatal(...) log_at(5, __VA_ARGS__)
+
+// ================================================================================================
+// zstd stays on the host (north star); dlopen'd so the library has no link-time dependency
+// ================================================================================================
+struct Zstd {
+    size_t (*bound)(size_t) = nullptr;
+    size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+    size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    bool ok = false;
+    Zstd()
+    {
+        const char *names[] = {"/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", nullptr};
+        void *h = nullptr;
+        for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        bound = (size_t(*)(size_t)) dlsym(h, "ZSTD_compressBound");
+        compress = (size_t(*)(void *, size_t, const void *, size_t, int)) dlsym(h, "ZSTD_compress");
+        decompress = (size_t(*)(void *, size_t, const void *, size_t)) dlsym(h, "ZSTD_decompress");
+        is_error = (unsigned (*)(size_t)) dlsym(h, "ZSTD_isError");
+        ok = bound && compress && decompress;
+    }
+};
+Zstd &zstd()
+{
+    static Zstd z;
+    return z;
+}
+
+// ================================================================================================
+// stream headers (src/ebcc_codec.c:190-213)
+// ================================================================================================
+#pragma pack(push, 1)
+struct FrameHeader {
+    uint8_t magic[4]; uint8_t version; uint8_t flags; uint16_t reserved;
+    uint32_t minval_bits, maxval_bits; uint64_t coeffs_size;
+    uint32_t rmin_bits, rmax_bits; uint64_t compressed_size; uint64_t tail_size;
+};
+struct ChunkHeader {
+    uint8_t magic[4]; uint32_t version, ndims, reserved;
+    uint64_t dims[3], chunk_dims[3], num_chunks, chunk_size;
+};
+#pragma pack(pop)
+static_assert(sizeof(FrameHeader) == 48, "EBCC header must be 48 bytes");
+static_assert(sizeof(ChunkHeader) == 80, "EBCK header must be 80 bytes");
+uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+bool dims_are_valid(const size_t d[3])
+{
+    // :286-297
+    if (d[0] == 0 || d[1] == 0) return false;
+    size_t hh = d[0] * d[1];
+    if (hh / d[0] != d[1]) return false;
+    return hh >= EBCC_MIN_INTERNAL_IMAGE_DIM && hh <= EBCC_MAX_INTERNAL_IMAGE_DIM && d[2] >= EBCC_MIN_INTERNAL_IMAGE_DIM &&
+           d[2] <= EBCC_MAX_INTERNAL_IMAGE_DIM;
+}
+
+// ================================================================================================
+// rate search of src/ebcc_codec.c:545-596 as a resumable state machine (one probe per step)
+// ================================================================================================
+struct RateSearch {
+    float lo = 0, hi = 0, cr = 0, result = 0;
+    double q = 0, q0 = 0, qt = 0;
+    int phase = 4;           // 0 halving, 1 doubling, 2 bisect, 3 final probe, 4 done
+    float pending = 0;
+    void start(float cr0, double q_init, double q_target)
+    {
+        lo = hi = cr = cr0; q = q0 = q_init; qt = q_target; phase = 0;
+    }
+    bool done() const { return phase == 4; }
+    // returns true and sets `out` if a probe at rate `out` is needed next
+    bool next(float &out)
+    {
+        for (;;) {
+            if (phase == 0) {
+                if (q < qt && lo >= 1. / 2) { lo /= 2; out = pending = lo; return true; }      // :559-563
+                q = q0; phase = 1;
+            } else if (phase == 1) {
+                if (q >= qt && hi <= 1000) { hi *= 2; out = pending = hi; return true; }       // :565-569
+                if (q >= qt) { result = hi; phase = 4; return false; }                         // :571-574
+                q = q0; phase = 2;
+            } else if (phase == 2) {
+                const double eps = 1e-8;
+                if ((std::fabs(q - qt) > eps || q == 1.0) && hi - lo > 1.) {                   // :579-588
+                    cr = (lo + hi) / 2; out = pending = cr; return true;
+                }
+                phase = 3; out = pending = lo; return true;                                    // :590
+            } else {
+                return false;
+            }
+        }
+    }
+    void feed(double quantile)
+    {
+        q = quantile;
+        if (phase == 2) { if (q < qt) hi = cr; else lo = cr; }
+        else if (phase == 3) { result = lo; phase = 4; }
+    }
+};
+
+// ================================================================================================
+// context cache: one engine per (device, frame geometry), grown on demand
+// ================================================================================================
+std::mutex g_mutex;
+std::map<std::pair<int, int>, ebcc_hip_ctx *> g_ctx;
+
+ebcc_hip_ctx *get_context(int H, int W, size_t frames)
+{
+    auto key = std::make_pair(H, W);
+    auto it = g_ctx.find(key);
+    if (it != g_ctx.end() && it->second->max_frames >= frames) return it->second;
+    if (it != g_ctx.end()) { ebcc_hip_destroy(it->second); g_ctx.erase(it); }
+    ebcc_hip_ctx *c = ebcc_hip_create(0, frames, (size_t) H, (size_t) W);
+    if (c) g_ctx[key] = c;
+    return c;
+}
+
+size_t batch_capacity()
+{
+    const char *e = getenv("EBCC_HIP_MAX_BATCH");
+    size_t v = e ? strtoul(e, nullptr, 10) : 256;
+    return v ? v : 256;
+}
+
+struct EncodeEnv {
+    double base_error_quantile = 1e-6;
+    bool no_fallback = false, no_consistency = false, no_mean_adjust = false;
+    EncodeEnv()
+    {
+        // :634-649
+        if (const char *e = getenv("EBCC_INIT_BASE_ERROR_QUANTILE")) base_error_quantile = strtod(e, nullptr);
+        no_fallback = getenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK") != nullptr;
+        no_consistency = getenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK_CONSISTENCY") != nullptr;
+        no_mean_adjust = getenv("EBCC_DISABLE_MEAN_ADJUSTMENT") != nullptr;
+    }
+};
+
+struct Job {                     // host-side state of one frame being encoded
+    bool const_field = false;
+    float minv = 0, maxv = 0, target = -1, cr = -1;
+    double mean_err = 0, q = 0;
+    float rmin = 0, rmax = 0;
+    bool skip = true, need_pure = false;
+    float best_err = -1;
+    size_t coeffs_orig = 0, coeffs_size = 0, len1 = 0;
+    double t_hi = 0, t_lo = 0, t_best = 0;
+    bool trunc_active = false;
+    std::vector<uint8_t> tail, zbytes;
+    RateSearch rs;
+};
+
+struct Batch {
+    ebcc_hip_ctx *ctx;
+    J2kBuffers &jb;
+    const float *d_frames;
+    size_t n;
+    std::vector<J2kFrame> jf;
+    hipStream_t s;
+    Batch(ebcc_hip_ctx *c, const float *d, size_t n_) : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), jf(n_), s(c->stream) {}
+    void fetch_jf()
+    {
+        EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    void push_jf() { EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n, hipMemcpyHostToDevice, s)); }
+    void push_active()
+    {
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    }
+    // one probe of the base layer for the active frames: rate allocation at jf[f].cr (+ decode and statistics)
+    void probe(bool decode)
+    {
+        push_jf();
+        push_active();
+        launch_j2k_rate(jb, (int) n, ctx->d_active, s);
+        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) n, ctx->d_active, s);
+        fetch_jf();
+    }
+    // drive one rate search (per-frame state machines in jobs[f].rs) to completion
+    void run_searches(std::vector<Job> &jobs)
+    {
+        for (;;) {
+            bool any = false;
+            for (size_t f = 0; f < n; f++) {
+                float cr;
+                ctx->h_active[f] = 0;
+                if (!jobs[f].rs.done() && jobs[f].rs.next(cr)) {
+                    ctx->h_active[f] = 1;
+                    jf[f].cr = cr;
+                    any = true;
+                }
+            }
+            if (!any) break;
+            probe(true);
+            for (size_t f = 0; f < n; f++)
+                if (ctx->h_active[f]) {
+                    jobs[f].q = 1. - ((double) jf[f].nbad / (double) ctx->n_pix);              // :512
+                    jobs[f].rs.feed(jobs[f].q);
+                    log_trace("frame %zu: cr %f 1-quantile %.1e jp2_length %d", f, jf[f].cr, 1 - jobs[f].q, jf[f].stream_bytes);
+                }
+        }
+    }
+    // codestream of the current layer assignment of the active frames -> jobs[f].tail
+    void collect_tails(std::vector<Job> &jobs)
+    {
+        push_active();
+        launch_j2k_write(jb, (int) n, ctx->d_active, s);
+        fetch_jf();
+        for (size_t f = 0; f < n; f++)
+            if (ctx->h_active[f]) {
+                jobs[f].tail.resize((size_t) jf[f].stream_bytes);
+                EBCC_HIP_CHECK(hipMemcpyAsync(jobs[f].tail.data(), jb.stream + f * jb.stream_cap, jobs[f].tail.size(),
+                                              hipMemcpyDeviceToHost, s));
+            }
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// ebcc_encode for a batch of device-resident single-frame chunks.  Returns 0, 1 (error) or 2 (NaN/Inf).
+// ------------------------------------------------------------------------------------------------
+int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
+{
+    const EncodeEnv env;
+    const double q_target = 1 - env.base_error_quantile;
+    const int mode = (int) cfg->residual_compression_type;
+    const bool searching = mode == MAX_ERROR || mode == RELATIVE_ERROR;
+    const size_t n_pix = ctx->n_pix;
+    Batch b(ctx, d_frames, n);
+    J2kBuffers &jb = b.jb;
+    hipStream_t s = b.s;
+    std::vector<Job> jobs(n);
+
+    // ---- statistics, scaling, transform, tier-1: once per frame
+    launch_input_stats(d_frames, (int) n, n_pix, ctx->rb.fs, s);
+    launch_j2k_analysis(d_frames, jb, (int) n, s);
+    fetch_frame_states(ctx, n);
+    b.fetch_jf();
+    for (size_t f = 0; f < n; f++) {
+        if (ctx->h_fs[f].has_nonfinite) { log_fatal("NaN or Inf found in data of frame %zu", f); return 2; }
+        if (b.jf[f].overflow) { log_fatal("code-block byte slot overflow in frame %zu", f); return 1; }
+        jobs[f].const_field = ctx->h_fs[f].const_field != 0;
+        jobs[f].minv = ctx->h_fs[f].minv;
+        jobs[f].maxv = ctx->h_fs[f].maxv;
+        b.jf[f].cr = cfg->base_cr;
+        b.jf[f].target = 0;
+        ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
+    }
+    const bool need_decode = mode != NONE;
+    if (need_decode)
+        for (size_t f = 0; f < n; f++) {
+            float target = cfg->error;                                                        // :723-726
+            if (mode == RELATIVE_ERROR) target *= jobs[f].maxv - jobs[f].minv;
+            jobs[f].target = target;
+            b.jf[f].target = target;
+        }
+    // ---- first encode at base_cr (:693) and, unless NONE, its decode (:707-709)
+    b.probe(need_decode);
+    if (mode == NONE) {
+        b.collect_tails(jobs);
+    } else {
+        for (size_t f = 0; f < n; f++) {
+            if (jobs[f].const_field) continue;
+            jobs[f].mean_err = b.jf[f].err_sum / (double) n_pix;                              // :709
+            jobs[f].q = 1. - ((double) b.jf[f].nbad / (double) n_pix);
+            jobs[f].cr = cfg->base_cr;
+        }
+        // residual range of the first decode: only the header fields survive when no search runs (:716)
+        launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, ctx->rb.fs, s);
+        fetch_frame_states(ctx, n);
+        for (size_t f = 0; f < n; f++) { jobs[f].rmin = ctx->h_fs[f].rmin; jobs[f].rmax = ctx->h_fs[f].rmax; }
+        if (!searching) {                       // stale enum values fall through to a base-only stream (quirk Q2)
+            for (size_t f = 0; f < n; f++) ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
+            b.collect_tails(jobs);
+        }
+    }
+
+    if (searching) {
+        // ---- rate search #1 (:728)
+        for (size_t f = 0; f < n; f++)
+            if (!jobs[f].const_field) jobs[f].rs.start(cfg->base_cr, jobs[f].q, q_target);
+        b.run_searches(jobs);
+        for (size_t f = 0; f < n; f++) {
+            ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
+            if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs.result; jobs[f].len1 = (size_t) b.jf[f].stream_bytes; }
+        }
+        b.collect_tails(jobs);                                                                // base layer of search #1
+        launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, ctx->rb.fs, s);               // :730-733
+        fetch_frame_states(ctx, n);
+        bool any_resid = false;
+        for (size_t f = 0; f < n; f++) {
+            Job &j = jobs[f];
+            ctx->h_active[f] = 0;
+            if (j.const_field) continue;
+            j.rmin = ctx->h_fs[f].rmin; j.rmax = ctx->h_fs[f].rmax;
+            float cur = fmaxf(fabsf(j.rmin), fabsf(j.rmax));                                  // :735
+            j.skip = cur <= j.target;                                                         // :737
+            if (!j.skip) { ctx->h_active[f] = 1; any_resid = true; }
+        }
+        const bool pure_done = q_target == 1.0;                                               // :738
+
+        if (any_resid) {
+            // ---- residual layer: SPIHT with a budget of the base layer's size (:744-754)
+            b.push_active();
+            launch_pad_and_dc(d_frames, jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
+            launch_analysis(ctx->rb, (int) n, ctx->d_active, s);
+            fetch_frame_states(ctx, n);
+            for (size_t f = 0; f < n; f++) {
+                unsigned long long bits0 = (unsigned long long) jobs[f].len1 * 8 + 128;       // trunc_bits + 128
+                ctx->h_u64a[f] = bits0;
+                ctx->h_fs[f].budget = bits0 - 128;
+            }
+            push_frame_states(ctx, n);
+            EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+            launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, ctx->d_active, s);
+            fetch_frame_states(ctx, n);
+            for (size_t f = 0; f < n; f++) {
+                if (!ctx->h_active[f]) continue;
+                jobs[f].coeffs_orig = ctx->h_fs[f].stream_bytes;
+                jobs[f].coeffs_size = jobs[f].coeffs_orig;
+                ctx->h_u64b[f] = (unsigned long long) jobs[f].coeffs_orig * 8;                // full decode, :749
+                ctx->h_fs[f].dec_dc = (int) ctx->h_fs[f].dc;
+            }
+            auto probe_residual = [&]() {
+                EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+                b.push_active();
+                launch_reconstruct(ctx->rb, (int) n, ctx->d_u64b, ctx->d_active, s);
+                launch_synthesis(ctx->rb, (int) n, ctx->d_active, s);
+                launch_probe_stats(d_frames, jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
+                fetch_frame_states(ctx, n);
+            };
+            probe_residual();
+            for (size_t f = 0; f < n; f++) {
+                Job &j = jobs[f];
+                if (!ctx->h_active[f]) continue;
+                float cur = u2f(ctx->h_fs[f].maxerr_bits);                                    // :754
+                if (cur > j.target) {                                                         // :755-759
+                    log_info("frame %zu: could not reach error target %f (%f instead); retry with pure base compression", f, j.target, cur);
+                    j.skip = true; j.need_pure = true;
+                } else {
+                    j.best_err = cur;
+                    j.mean_err = ctx->h_fs[f].err_sum / (double) n_pix;                       // :762
+                    j.t_hi = (double) j.coeffs_size * 8; j.t_lo = 112.0; j.t_best = j.t_hi;   // :766-776
+                    j.trunc_active = true;
+                }
+            }
+            // ---- truncation bisection (:777-795): all frames advance one probe per round
+            for (;;) {
+                const double eps = 1e-8;
+                bool any = false;
+                for (size_t f = 0; f < n; f++) {
+                    Job &j = jobs[f];
+                    ctx->h_active[f] = 0;
+                    if (!j.trunc_active) continue;
+                    if (((j.target - j.best_err) / j.target > eps) && (j.t_hi - j.t_lo > 8 * 4)) {
+                        size_t tb = ((size_t) ceill((long double) ((j.t_hi + j.t_lo) / 2 / 8))) * 8;
+                        ctx->h_u64b[f] = tb;
+                        ctx->h_active[f] = 1;
+                        any = true;
+                    } else {
+                        j.trunc_active = false;
+                    }
+                }
+                if (!any) break;
+                probe_residual();
+                for (size_t f = 0; f < n; f++) {
+                    Job &j = jobs[f];
+                    if (!ctx->h_active[f]) continue;
+                    const double tb = (double) ctx->h_u64b[f];
+                    float cur = u2f(ctx->h_fs[f].maxerr_bits);
+                    if (cur > j.target) j.t_lo = tb;
+                    else {
+                        j.t_hi = tb;
+                        if (cur >= j.best_err) { j.best_err = cur; j.t_best = tb; j.mean_err = ctx->h_fs[f].err_sum / (double) n_pix; }
+                    }
+                    log_trace("frame %zu: trunc_lo %.1f trunc_hi %.1f max error %f", f, j.t_lo, j.t_hi, cur);
+                }
+            }
+            for (size_t f = 0; f < n; f++) {
+                Job &j = jobs[f];
+                if (j.const_field || j.skip) { if (j.need_pure) j.coeffs_size = j.coeffs_orig; else j.coeffs_size = 0; }
+                else j.coeffs_size = (size_t) (j.t_best / 8.);                                // :796
+            }
+        }
+        // ---- entropy stage of the kept SPIHT prefix on host cores (:811-817)
+        if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+        for (size_t f = 0; f < n; f++) {
+            Job &j = jobs[f];
+            if (j.coeffs_size <= 16) j.coeffs_size = 0;
+            if (j.coeffs_size > 0) {
+                std::vector<uint8_t> coeffs(j.coeffs_size);
+                EBCC_HIP_CHECK(hipMemcpyAsync(coeffs.data(), ctx->rb.stream + f * ctx->rb.stream_words, j.coeffs_size,
+                                              hipMemcpyDeviceToHost, s));
+                EBCC_HIP_CHECK(hipStreamSynchronize(s));
+                j.zbytes.resize(zstd().bound(j.coeffs_size));
+                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeffs.data(), j.coeffs_size, 22);
+                j.zbytes.resize(z);
+            }
+        }
+        // ---- pure base-layer fallback (:819-854)
+        if (!pure_done && !env.no_fallback) {
+            if (!env.no_consistency) {
+                for (size_t f = 0; f < n; f++) { ctx->h_active[f] = jobs[f].const_field ? 0 : 1; b.jf[f].cr = cfg->base_cr; }
+                b.probe(true);                                                                // :829-833
+                for (size_t f = 0; f < n; f++)
+                    if (!jobs[f].const_field) { jobs[f].q = 1. - ((double) b.jf[f].nbad / (double) n_pix); jobs[f].cr = cfg->base_cr; }
+            }
+            for (size_t f = 0; f < n; f++)
+                if (!jobs[f].const_field) jobs[f].rs.start(jobs[f].cr, jobs[f].q, 1.0);
+            b.run_searches(jobs);                                                             // :836
+            for (size_t f = 0; f < n; f++) {
+                Job &j = jobs[f];
+                ctx->h_active[f] = 0;
+                if (j.const_field) continue;
+                const size_t len2 = (size_t) b.jf[f].stream_bytes;
+                if (len2 < j.zbytes.size() + j.len1 || j.need_pure) {                         // :838
+                    if (len2 < j.zbytes.size() + j.len1)
+                        log_info("frame %zu: pure base compression (%zu) beats base (%zu) + residual (%zu)", f, len2, j.len1, j.zbytes.size());
+                    j.mean_err = b.jf[f].err_sum / (double) n_pix;                            // :843
+                    j.zbytes.clear(); j.coeffs_size = 0;
+                    ctx->h_active[f] = 1;
+                }
+            }
+            b.collect_tails(jobs);
+        }
+    }
+
+    // ---- assemble (:863-907)
+    for (size_t f = 0; f < n; f++) {
+        Job &j = jobs[f];
+        float minv = j.minv, maxv = j.maxv;
+        log_info("frame %zu: mean of compression error %e", f, j.mean_err);
+        if (!env.no_mean_adjust && std::fabs(j.mean_err) > 1e-18) {
+            minv += j.mean_err;
+            maxv += j.mean_err;
+        }
+        const size_t codec_size = j.const_field ? sizeof(uint64_t) : j.tail.size();
+        const size_t total = sizeof(FrameHeader) + j.zbytes.size() + codec_size;
+        uint8_t *o = (uint8_t *) malloc(total), *p = o;
+        if (!o) { log_fatal("out of memory"); return 1; }
+        FrameHeader hd;
+        memset(&hd, 0, sizeof hd);
+        memcpy(hd.magic, EBCC_HEADER_MAGIC, 4);
+        hd.version = EBCC_HEADER_VERSION;
+        if (j.const_field) hd.flags |= EBCC_HEADER_FLAG_CONST_FIELD;
+        hd.minval_bits = f2u(minv); hd.maxval_bits = f2u(maxv);
+        hd.coeffs_size = j.coeffs_size;
+        hd.rmin_bits = f2u(j.const_field ? 0.0f : j.rmin); hd.rmax_bits = f2u(j.const_field ? 0.0f : j.rmax);
+        hd.compressed_size = j.zbytes.size(); hd.tail_size = codec_size;
+        memcpy(p, &hd, sizeof hd); p += sizeof hd;
+        if (!j.zbytes.empty()) { memcpy(p, j.zbytes.data(), j.zbytes.size()); p += j.zbytes.size(); }
+        if (j.const_field) { uint64_t cnt = n_pix; memcpy(p, &cnt, 8); }
+        else memcpy(p, j.tail.data(), j.tail.size());
+        log_info("frame %zu: coeffs_size %zu compressed_size %zu jp2_length %zu ratio %f", f, j.coeffs_size, j.zbytes.size(),
+                 codec_size, (double) (n_pix * 4) / (double) total);
+        outs[f] = o;
+        sizes[f] = total;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ebcc_decode for a batch of single-frame EBCC streams -> device buffer d_out [n][H*W]
+// ------------------------------------------------------------------------------------------------
+int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n, float *d_out)
+{
+    J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
+    hipStream_t s = ctx->stream;
+    const size_t n_pix = ctx->n_pix;
+    const J2kGeom &g = jb.geom;
+    std::vector<int> table(n * (size_t) g.nblocks * 4, 0);
+    std::vector<std::vector<uint8_t>> coeffs(n);
+    fetch_frame_states(ctx, n);
+    bool any_resid = false;
+    for (size_t f = 0; f < n; f++) {
+        const uint8_t *d = streams[f];
+        const size_t len = sizes[f];
+        ctx->h_active[f] = 0;
+        if (len < sizeof(FrameHeader) || memcmp(d, EBCC_HEADER_MAGIC, 4) != 0) {
+            log_fatal("legacy header-less EBCC streams are not supported by the MI355X build");
+            return 1;
+        }
+        FrameHeader hd;
+        memcpy(&hd, d, sizeof hd);
+        if (hd.version != EBCC_HEADER_VERSION) { log_fatal("Unsupported EBCC header version: %u", hd.version); return 1; }
+        size_t used = sizeof hd;
+        if (hd.compressed_size > len - used) { log_fatal("Invalid encoded data: truncated payload"); return 1; }   // :1249
+        used += hd.compressed_size;
+        if (hd.tail_size > len - used) { log_fatal("Invalid encoded data: truncated payload"); return 1; }         // :1254
+        used += hd.tail_size;
+        if (used != len) { log_fatal("Invalid encoded data: payload size mismatch"); return 1; }                  // :1314
+        FrameState &fs = ctx->h_fs[f];
+        fs.minv = u2f(hd.minval_bits); fs.maxv = u2f(hd.maxval_bits);
+        fs.rmin = u2f(hd.rmin_bits); fs.rmax = u2f(hd.rmax_bits);
+        fs.const_field = (hd.flags & EBCC_HEADER_FLAG_CONST_FIELD) ? 1 : 0;
+        const uint8_t *z = d + sizeof hd, *tail = z + hd.compressed_size;
+        if (fs.const_field) {
+            uint64_t cnt = 0;
+            if (hd.tail_size != sizeof(uint64_t)) { log_fatal("Invalid encoded data: const-field payload must contain uint64_t length"); return 1; }
+            memcpy(&cnt, tail, 8);
+            if (cnt != n_pix) { log_fatal("const-field length %llu does not match the frame", (unsigned long long) cnt); return 1; }
+            if (hd.compressed_size > 0 && hd.coeffs_size > 0) { log_fatal("Invalid encoded data: residual data cannot be applied to const field"); return 1; }
+        } else {
+            if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return 1; }
+            if (!j2k_parse_codestream(tail, hd.tail_size, g, table.data() + f * g.nblocks * 4)) return 1;
+            EBCC_HIP_CHECK(hipMemcpyAsync(jb.stream + f * jb.stream_cap, tail, hd.tail_size, hipMemcpyHostToDevice, s));
+            if (hd.compressed_size > 0 && hd.coeffs_size > 0) {                                                    // :1294-1304
+                if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+                if (hd.coeffs_size > ctx->rb.stream_words * 4 - 64) { log_fatal("residual stream larger than the device slot"); return 1; }
+                coeffs[f].assign(hd.coeffs_size, 0);
+                zstd().decompress(coeffs[f].data(), hd.coeffs_size, z, hd.compressed_size);
+                ctx->h_active[f] = 1;
+                any_resid = true;
+            }
+        }
+    }
+    push_frame_states(ctx, n);
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_j2k_decode(jb, (int) n, s);
+    if (any_resid) {
+        const size_t slot = ctx->rb.stream_words * 4;
+        for (size_t f = 0; f < n; f++) {
+            ctx->h_u64a[f] = coeffs[f].size();
+            ctx->h_u64b[f] = coeffs[f].size() * 8;
+            if (ctx->h_active[f])
+                EBCC_HIP_CHECK(hipMemcpyAsync((uint8_t *) ctx->rb.stream + f * slot, coeffs[f].data(), coeffs[f].size(),
+                                              hipMemcpyHostToDevice, s));
+        }
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, n * sizeof(int), hipMemcpyHostToDevice, s));
+        launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n, ctx->d_active, s);
+        launch_synthesis(ctx->rb, (int) n, ctx->d_active, s);
+        launch_add_residual(jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
+    }
+    EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // constant fields: fill on the host side of the copy (rare path)
+    for (size_t f = 0; f < n; f++)
+        if (ctx->h_fs[f].const_field) {
+            std::vector<float> v(n_pix, ctx->h_fs[f].minv);
+            EBCC_HIP_CHECK(hipMemcpyAsync(d_out + f * n_pix, v.data(), n_pix * sizeof(float), hipMemcpyHostToDevice, s));
+            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// host-pointer convenience used by the reference-compatible entry points
+size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const size_t cap = std::min(n, batch_capacity());
+    ebcc_hip_ctx *ctx = get_context(H, W, cap);
+    if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+    const size_t n_pix = (size_t) H * W;
+    float *d = nullptr;
+    EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * n_pix * sizeof(float)));
+    size_t done = 0;
+    while (done < n) {
+        size_t k = std::min(cap, n - done);
+        EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
+        int rc = encode_batch(ctx, d, k, cfg, outs + done, sizes + done);
+        if (rc == 2) { hipFree(d); exit(1); }                                                  // check_nan_inf, :598-605
+        if (rc) { hipFree(d); return 0; }
+        done += k;
+    }
+    hipFree(d);
+    return n;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C API
+// ================================================================================================
+extern "C" {
+
+void free_buffer(void *p) { if (p) free(p); }
+
+void log_set_level_from_env(void)
+{
+    g_log_level = 3;
+    if (const char *e = getenv("EBCC_LOG_LEVEL")) {
+        char *end;
+        long v = strtol(e, &end, 10);
+        if (*end != '\0') log_warn("Ignore log level: %s, should be in [0, 5]", e);
+        else g_log_level = (int) v;
+    }
+}
+
+void print_config(codec_config_t *c)
+{
+    static const char *names[] = {"NONE", "MAX_ERROR", "RELATIVE_ERROR"};
+    log_info("dimensions:\t(%lu, %lu, %lu)", c->dims[0], c->dims[1], c->dims[2]);
+    log_info("chunk dimensions:\t(%lu, %lu, %lu)", c->chunk_dims[0], c->chunk_dims[1], c->chunk_dims[2]);
+    log_info("base_cr:\t%f", c->base_cr);
+    unsigned t = (unsigned) c->residual_compression_type;
+    log_info("residual type:\t%s", t < 3 ? names[t] : "?");
+    if (t == MAX_ERROR) log_info("max error:\t%f", c->error);
+    if (t == RELATIVE_ERROR) log_info("relative error:\t%f", c->error);
+}
+
+int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
+                           uint8_t **out_streams, size_t *out_sizes)
+{
+    if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_encode_frames: bad batch"); return 1; }
+    if (config->dims[0] != 1 || (int) config->dims[1] != ctx->height || (int) config->dims[2] != ctx->width) {
+        set_error("ebcc_hip_encode_frames: config dims must be (1, %d, %d)", ctx->height, ctx->width);
+        return 1;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    log_set_level_from_env();
+    return encode_batch(ctx, d_frames, n_frames, config, out_streams, out_sizes);
+}
+
+int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
+                           float *d_frames_out)
+{
+    if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_decode_frames: bad batch"); return 1; }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    return decode_batch(ctx, streams, sizes, n_frames, d_frames_out);
+}
+
+size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
+{
+    log_set_level_from_env();
+    if (!dims_are_valid(config->dims)) {
+        log_fatal("Invalid EBCC dimensions: product(dims[0..1]) and dims[2] must be between %d and %d",
+                  EBCC_MIN_INTERNAL_IMAGE_DIM, EBCC_MAX_INTERNAL_IMAGE_DIM);
+        return 0;
+    }
+    print_config(config);
+    if (config->dims[0] != 1) {
+        // the reference codes such a chunk as one tiled JPEG 2000 image (src/ebcc_codec.c:121-125,167-171)
+        log_fatal("chunks holding %lu frames (tiled JPEG 2000) are not supported by the MI355X build yet; use one frame per chunk",
+                  config->dims[0]);
+        return 0;
+    }
+    size_t size = 0;
+    uint8_t *o = nullptr;
+    if (encode_host_frames(data, 1, (int) config->dims[1], (int) config->dims[2], config, &o, &size) != 1) return 0;
+    *out_buffer = o;
+    return size;
+}
+
+static int peek_j2k_dims(const uint8_t *d, size_t n, int *H, int *W)
+{
+    // SIZ follows SOC immediately in every stream the codec writes (T.800 A.5.1)
+    if (n < 2 + 4 + 38 || d[0] != 0xFF || d[1] != 0x4F || d[2] != 0xFF || d[3] != 0x51) return 0;
+    auto be32 = [](const uint8_t *p) { return ((unsigned) p[0] << 24) | ((unsigned) p[1] << 16) | ((unsigned) p[2] << 8) | p[3]; };
+    *W = (int) (be32(d + 8) - be32(d + 16));
+    *H = (int) (be32(d + 12) - be32(d + 20));
+    return 1;
+}
+
+size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
+{
+    if (data_size < sizeof(FrameHeader) || memcmp(data, EBCC_HEADER_MAGIC, 4) != 0) {
+        log_fatal("legacy header-less EBCC streams are not supported by the MI355X build");
+        return 0;
+    }
+    FrameHeader hd;
+    memcpy(&hd, data, sizeof hd);
+    if (hd.version != EBCC_HEADER_VERSION) { log_fatal("Unsupported EBCC header version: %u", hd.version); return 0; }
+    if (hd.compressed_size > data_size - sizeof hd || hd.tail_size > data_size - sizeof hd - hd.compressed_size) {
+        log_fatal("Invalid encoded data: truncated payload");
+        return 0;
+    }
+    const uint8_t *tail = data + sizeof hd + hd.compressed_size;
+    if (hd.flags & EBCC_HEADER_FLAG_CONST_FIELD) {                                             // :1265-1281, no device work
+        if (hd.tail_size != sizeof(uint64_t)) { log_fatal("Invalid encoded data: const-field payload must contain uint64_t length"); return 0; }
+        uint64_t cnt;
+        memcpy(&cnt, tail, 8);
+        if (hd.compressed_size > 0 && hd.coeffs_size > 0) { log_fatal("Invalid encoded data: residual data cannot be applied to const field"); return 0; }
+        if (sizeof hd + hd.compressed_size + hd.tail_size != data_size) { log_fatal("Invalid encoded data: payload size mismatch"); return 0; }
+        float *o = (float *) malloc(cnt * sizeof(float));
+        float v = u2f(hd.minval_bits);
+        for (uint64_t i = 0; i < cnt; i++) o[i] = v;
+        *out_buffer = o;
+        return (size_t) cnt;
+    }
+    int H = 0, W = 0;
+    if (!peek_j2k_dims(tail, hd.tail_size, &H, &W) || H < 1 || W < 1 || H > 2047 || W > 2047) {
+        log_fatal("Invalid encoded data: no JPEG 2000 codestream in the tail");
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    ebcc_hip_ctx *ctx = get_context(H, W, 1);
+    if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+    const size_t n_pix = (size_t) H * W;
+    float *d = nullptr;
+    EBCC_HIP_CHECK(hipMalloc((void **) &d, n_pix * sizeof(float)));
+    const uint8_t *sp = data;
+    int rc = decode_batch(ctx, &sp, &data_size, 1, d);
+    if (rc) { hipFree(d); return 0; }
+    // :1126-1128: honour a caller-provided buffer
+    float *o = *out_buffer ? *out_buffer : (float *) malloc(n_pix * sizeof(float));
+    EBCC_HIP_CHECK(hipMemcpy(o, d, n_pix * sizeof(float), hipMemcpyDeviceToHost));
+    hipFree(d);
+    *out_buffer = o;
+    return n_pix;
+}
+
+// ---- EBCK chunk container (:920-1052) -------------------------------------------------------------
+static size_t cdiv(size_t a, size_t b) { return a / b + (a % b != 0); }
+
+size_t ebcc_encode_chunking(float *data, codec_config_t *config, uint8_t **out_buffer)
+{
+    log_set_level_from_env();
+    size_t cd[3];
+    bool all_zero = true;
+    for (int i = 0; i < 3; i++) { cd[i] = config->chunk_dims[i]; if (cd[i]) all_zero = false; }
+    if (all_zero) for (int i = 0; i < 3; i++) cd[i] = config->dims[i];
+    if (!dims_are_valid(cd)) {
+        log_fatal("Invalid chunking dimensions: product(chunk_dims[0..1]) and chunk_dims[2] must be between %d and %d",
+                  EBCC_MIN_INTERNAL_IMAGE_DIM, EBCC_MAX_INTERNAL_IMAGE_DIM);
+        return 0;
+    }
+    size_t cnt[3];
+    for (int i = 0; i < 3; i++) {
+        if (config->dims[i] == 0 || cd[i] == 0) { log_fatal("Invalid chunking dimensions: dims and chunk_dims must be non-zero"); return 0; }
+        cnt[i] = cdiv(config->dims[i], cd[i]);
+    }
+    if (cd[0] != 1) {
+        log_fatal("chunks holding %lu frames (tiled JPEG 2000) are not supported by the MI355X build yet; use chunk_dims[0] = 1", cd[0]);
+        return 0;
+    }
+    const size_t csize = cd[0] * cd[1] * cd[2], nchunks = cnt[0] * cnt[1] * cnt[2];
+    const size_t total = config->dims[0] * config->dims[1] * config->dims[2];
+    const size_t padded = csize * nchunks;
+    if (padded > total && padded - total > total / 10)
+        log_warn("Chunk padding adds %lu values over %lu real values (%.2f%%)", padded - total, total,
+                 ((double) (padded - total) / (double) total) * 100.0);
+    // gather the chunks in C order of chunk index (:311-318), edge chunks padded by index clamping (:339-351)
+    std::vector<float> gathered(nchunks * csize);
+    for (size_t cl = 0; cl < nchunks; cl++) {
+        size_t org[3], t = cl;
+        for (int d = 3; d-- > 0;) { org[d] = (t % cnt[d]) * cd[d]; t /= cnt[d]; }
+        float *dst = gathered.data() + cl * csize;
+        for (size_t li = 0; li < csize; li++) {
+            size_t rem = li, idx[3];
+            for (int d = 3; d-- > 0;) {
+                size_t k = org[d] + rem % cd[d];
+                idx[d] = k < config->dims[d] - 1 ? k : config->dims[d] - 1;
+                rem /= cd[d];
+            }
+            dst[li] = data[(idx[0] * config->dims[1] + idx[1]) * config->dims[2] + idx[2]];
+        }
+    }
+    codec_config_t cc = *config;
+    for (int i = 0; i < 3; i++) { cc.dims[i] = cd[i]; cc.chunk_dims[i] = 0; }
+    std::vector<uint8_t *> outs(nchunks, nullptr);
+    std::vector<size_t> sizes(nchunks, 0);
+    if (encode_host_frames(gathered.data(), nchunks, (int) cd[1], (int) cd[2], &cc, outs.data(), sizes.data()) != nchunks) {
+        for (auto p : outs) free(p);
+        return 0;
+    }
+    size_t len = sizeof(ChunkHeader);
+    for (size_t c = 0; c < nchunks; c++) len += 8 + sizes[c];
+    uint8_t *o = (uint8_t *) malloc(len), *p = o;
+    ChunkHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, EBCC_CHUNKING_HEADER_MAGIC, 4);
+    hd.version = EBCC_CHUNKING_HEADER_VERSION; hd.ndims = NDIMS;
+    for (int i = 0; i < 3; i++) { hd.dims[i] = config->dims[i]; hd.chunk_dims[i] = cd[i]; }
+    hd.num_chunks = nchunks; hd.chunk_size = csize;
+    memcpy(p, &hd, sizeof hd); p += sizeof hd;
+    for (size_t c = 0; c < nchunks; c++) {
+        uint64_t nb = sizes[c];
+        memcpy(p, &nb, 8); p += 8;
+        memcpy(p, outs[c], sizes[c]); p += sizes[c];
+        free(outs[c]);
+    }
+    *out_buffer = o;
+    return len;
+}
+
+size_t ebcc_encode_chunking_compat(float *data, codec_config_t *config, uint8_t **out_buffer)
+{
+    // :1054-1090
+    log_set_level_from_env();
+    codec_config_t c = *config;
+    if (!c.chunk_dims[0] && !c.chunk_dims[1] && !c.chunk_dims[2]) {
+        c.chunk_dims[0] = 1;
+        c.chunk_dims[1] = c.dims[1] > EBCC_MAX_INTERNAL_IMAGE_DIM ? 1024 : c.dims[1];
+        c.chunk_dims[2] = c.dims[2] > EBCC_MAX_INTERNAL_IMAGE_DIM ? 1024 : c.dims[2];
+        log_info("ebcc_encode_chunking_compat chunk dimensions: (%lu, %lu, %lu)", c.chunk_dims[0], c.chunk_dims[1], c.chunk_dims[2]);
+    }
+    if (c.residual_compression_type == RELATIVE_ERROR) {
+        size_t total = c.dims[0] * c.dims[1] * c.dims[2];
+        if (total == 0) { log_fatal("Invalid EBCC dimensions: size overflow or zero-sized data"); return 0; }
+        float mn = data[0], mx = data[0];
+        for (size_t i = 0; i < total; i++) {
+            if (std::isnan(data[i]) || std::isinf(data[i])) { log_fatal("NaN or Inf found in data at index %lu", i); exit(1); }
+            if (data[i] > mx) mx = data[i];
+            if (data[i] < mn) mn = data[i];
+        }
+        c.error *= mx - mn;                                                                    // global range, :1085
+        c.residual_compression_type = MAX_ERROR;
+    }
+    return ebcc_encode_chunking(data, &c, out_buffer);
+}
+
+size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
+{
+    // :1322-1449
+    log_set_level_from_env();
+    if (data_size < sizeof(ChunkHeader) || memcmp(data, EBCC_CHUNKING_HEADER_MAGIC, 4) != 0) return ebcc_decode(data, data_size, out_buffer);
+    ChunkHeader hd;
+    memcpy(&hd, data, sizeof hd);
+    if (hd.version != EBCC_CHUNKING_HEADER_VERSION) { log_fatal("Unsupported EBCC chunking header version: %u", hd.version); return 0; }
+    if (hd.ndims != NDIMS) { log_fatal("Unsupported EBCC chunking dimensionality: %u", hd.ndims); return 0; }
+    size_t dims[3], cd[3], cnt[3];
+    for (int i = 0; i < 3; i++) { dims[i] = hd.dims[i]; cd[i] = hd.chunk_dims[i]; }
+    if (!dims_are_valid(cd)) { log_fatal("Invalid chunked EBCC data: bad chunk dimensions"); return 0; }
+    for (int i = 0; i < 3; i++) {
+        if (!dims[i] || !cd[i]) { log_fatal("Invalid chunked EBCC data: dims and chunk_dims must be non-zero"); return 0; }
+        cnt[i] = cdiv(dims[i], cd[i]);
+    }
+    const size_t csize = cd[0] * cd[1] * cd[2], nchunks = cnt[0] * cnt[1] * cnt[2], total = dims[0] * dims[1] * dims[2];
+    if (hd.chunk_size != csize || hd.num_chunks != nchunks) { log_fatal("Invalid chunked EBCC data: inconsistent chunk metadata"); return 0; }
+    if (cd[0] != 1) { log_fatal("chunks holding %lu frames are not supported by the MI355X build yet", cd[0]); return 0; }
+    std::vector<const uint8_t *> ptrs(nchunks);
+    std::vector<size_t> lens(nchunks);
+    const uint8_t *p = data + sizeof hd, *end = data + data_size;
+    for (size_t c = 0; c < nchunks; c++) {
+        uint64_t nb;
+        if ((size_t) (end - p) < 8) { log_fatal("Invalid chunked EBCC data: missing chunk size"); return 0; }
+        memcpy(&nb, p, 8); p += 8;
+        if (nb > (size_t) (end - p)) { log_fatal("Invalid chunked EBCC data: truncated chunk payload"); return 0; }
+        ptrs[c] = p; lens[c] = nb; p += nb;
+    }
+    if (p != end) { log_fatal("Invalid chunked EBCC data: trailing payload bytes"); return 0; }
+    const int H = (int) cd[1], W = (int) cd[2];
+    std::vector<float> chunks(nchunks * csize);
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        const size_t cap = std::min(nchunks, batch_capacity());
+        ebcc_hip_ctx *ctx = get_context(H, W, cap);
+        if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+        float *d = nullptr;
+        EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * csize * sizeof(float)));
+        for (size_t done = 0; done < nchunks;) {
+            size_t k = std::min(cap, nchunks - done);
+            if (decode_batch(ctx, ptrs.data() + done, lens.data() + done, k, d)) { hipFree(d); return 0; }
+            EBCC_HIP_CHECK(hipMemcpy(chunks.data() + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
+            done += k;
+        }
+        hipFree(d);
+    }
+    float *o = (float *) malloc(total * sizeof(float));
+    if (!o) { log_fatal("Failed to allocate chunked EBCC decode output"); return 0; }
+    for (size_t cl = 0; cl < nchunks; cl++) {
+        size_t org[3], t = cl;
+        for (int d = 3; d-- > 0;) { org[d] = (t % cnt[d]) * cd[d]; t /= cnt[d]; }
+        const float *src = chunks.data() + cl * csize;
+        for (size_t li = 0; li < csize; li++) {                                                // :353-370
+            size_t rem = li, idx[3];
+            bool inb = true;
+            for (int d = 3; d-- > 0;) { idx[d] = org[d] + rem % cd[d]; if (idx[d] >= dims[d]) inb = false; rem /= cd[d]; }
+            if (inb) o[(idx[0] * dims[1] + idx[1]) * dims[2] + idx[2]] = src[li];
+        }
+    }
+    *out_buffer = o;
+    return total;
+}
+
+// ---- HDF5 filter plugin, /root/reference/src/h5z_ebcc.c ---------------------------------------------
+#define H5Z_FLAG_REVERSE 0x0100
+typedef size_t (*H5Z_func_t)(unsigned int, size_t, const unsigned int[], size_t, size_t *, void **);
+struct H5Z_class2_t {
+    int version; int id; unsigned encoder_present; unsigned decoder_present; const char *name;
+    void *can_apply; void *set_local; H5Z_func_t filter;
+};
+
+void populate_config(codec_config_t *config, size_t cd_nelmts, const unsigned int cd_values[], size_t buf_size)
+{
+    // h5z_ebcc.c:38-93, including exit(1) on invalid parameters
+    if (cd_nelmts < 4) { log_fatal("EBCC filter requires at least 4 configuration values, got %lu", cd_nelmts); exit(1); }
+    for (int i = 0; i < NDIMS; i++) config->chunk_dims[i] = 0;
+    size_t th = cd_values[0], tw = cd_values[1];
+    if (th < EBCC_MIN_INTERNAL_IMAGE_DIM || tw < EBCC_MIN_INTERNAL_IMAGE_DIM || th > EBCC_MAX_INTERNAL_IMAGE_DIM ||
+        tw > EBCC_MAX_INTERNAL_IMAGE_DIM) {
+        log_fatal("Tile size %lu x %lu is invalid, each dimension must be between %d and %d", th, tw,
+                  EBCC_MIN_INTERNAL_IMAGE_DIM, EBCC_MAX_INTERNAL_IMAGE_DIM);
+        exit(1);
+    }
+    size_t tile = th * tw;
+    config->dims[0] = buf_size / sizeof(float);
+    if (config->dims[0] < tile) { log_fatal("Buffer size %lu is smaller than the tile size %lu x %lu = %lu", config->dims[0], th, tw, tile); exit(1); }
+    if (config->dims[0] % tile != 0) { log_fatal("Buffer size %lu is not divisible by the tile size %lu x %lu = %lu", config->dims[0], th, tw, tile); exit(1); }
+    for (size_t i = 0; i < 2; i++) {
+        size_t cur = cd_values[i];
+        config->dims[0] /= cur;
+        config->dims[i + 1] = cur;
+    }
+    if (config->dims[1] != 0 && config->dims[0] > EBCC_MAX_INTERNAL_IMAGE_DIM / config->dims[1]) {
+        log_fatal("Flattened EBCC image height %lu x %lu exceeds the limit of %d", config->dims[0], config->dims[1],
+                  EBCC_MAX_INTERNAL_IMAGE_DIM);
+        exit(1);
+    }
+    config->base_cr = u2f(cd_values[2]);
+    config->residual_compression_type = (residual_t) cd_values[3];
+    if (config->residual_compression_type == MAX_ERROR || config->residual_compression_type == RELATIVE_ERROR) {
+        if (cd_nelmts != 5) { log_fatal("EBCC filter: modes 1 and 2 need 5 configuration values"); exit(1); }
+        config->error = u2f(cd_values[4]);
+    }
+}
+
+static size_t H5Z_filter_ebcc(unsigned int flags, size_t cd_nelmts, const unsigned int cd_values[], size_t nbytes,
+                              size_t *buf_size, void **buf)
+{
+    if (flags & H5Z_FLAG_REVERSE) {
+        float *out = nullptr;
+        *buf_size = ebcc_decode((uint8_t *) *buf, nbytes, &out);                               // element count (quirk Q1)
+        free_buffer(*buf);
+        *buf = out;
+        return *buf_size;
+    }
+    codec_config_t config;
+    memset(&config, 0, sizeof config);
+    populate_config(&config, cd_nelmts, cd_values, *buf_size);
+    uint8_t *out = nullptr;
+    *buf_size = ebcc_encode((float *) *buf, &config, &out);
+    free_buffer(*buf);
+    *buf = out;
+    return *buf_size;
+}
+
+static const H5Z_class2_t H5Z_EBCC[1] = {{1, 308, 1, 1, "HDF5 EBCC filter L&L", nullptr, nullptr, H5Z_filter_ebcc}};
+
+int H5PLget_plugin_type(void) { return 0; }            // H5PL_TYPE_FILTER
+const void *H5PLget_plugin_info(void) { return H5Z_EBCC; }
+
+}  // extern "C"

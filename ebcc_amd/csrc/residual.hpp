@@ -63,17 +63,18 @@ void launch_residual_minmax(const float *data, const float *decoded, int n_frame
 
 // load_image + sub_dc prologue: A = mirror-pad(((r - rmin) / (rmax - rmin)) * 255), fs.dc  (dwt.h:41-78,319-334)
 void launch_pad_and_dc(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
-                       hipStream_t s);
+                       const int *d_active, hipStream_t s);
 
 // same but from an already normalised [0,1] image (unit tests / spiht_encode entry point)
 void launch_pad_and_dc_from_image(const float *image, const ResidualBuffers &rb, int n_frames, hipStream_t s);
 
 // dwt2full + normalize: A (minus dc) -> C, fs.cmax, D, G   (dwt.h:293-303,355-368; spiht_re.c:54-60,160-206)
-void launch_analysis(const ResidualBuffers &rb, int n_frames, hipStream_t s);
+void launch_analysis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
 
 // spiht_encode_process + IMS header -> rb.stream, fs.emitted/stream_bytes, sigord/lspidx  (spiht_re.c:208-317,448-464)
 // fs[f].budget must be set (bits0 - 128) and bits0 per frame is passed for the header.
-void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, hipStream_t s);
+void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, const int *d_active,
+                         hipStream_t s);
 
 // Decoder state after the first `trunc_bits[f]` stream bits, rebuilt from the encoder's bookkeeping:
 // A = coefficient grid as spiht_decode_process would leave it  (spiht_re.c:319-430 semantics)

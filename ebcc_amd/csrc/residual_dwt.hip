@@ -325,10 +325,11 @@ __global__ void k_residual_minmax_finish(const float *data, const float *decoded
 template <bool FROM_IMAGE>
 __global__ __launch_bounds__(256) void k_pad_load(const float *__restrict__ data, const float *__restrict__ decoded,
                                                    float *__restrict__ A, Grid g, size_t n_pix, size_t np,
-                                                   const FrameState *fs, double *partial)
+                                                   const FrameState *fs, double *partial, const int *active)
 {
     __shared__ double red[256];
     const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
     const float *x = data + (size_t) frame * n_pix;
     const float *d = FROM_IMAGE ? nullptr : decoded + (size_t) frame * n_pix;
     float *a = A + (size_t) frame * np;
@@ -368,10 +369,10 @@ __global__ __launch_bounds__(256) void k_pad_load(const float *__restrict__ data
     if (threadIdx.x == 0) partial[(size_t) frame * kPartials + blockIdx.x] = red[0];
 }
 
-__global__ void k_dc_finish(const double *partial, int n_partials, size_t np, FrameState *fs, int n_frames)
+__global__ void k_dc_finish(const double *partial, int n_partials, size_t np, FrameState *fs, int n_frames, const int *active)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
+    if (f >= n_frames || (active && !active[f])) return;
     double s = 0;
     for (int i = 0; i < n_partials; i++) s += partial[(size_t) f * kPartials + i];
     // The reference sums sequentially in double (dwt.h:324-329); only floor(mean) survives.  Both
@@ -385,10 +386,10 @@ __global__ void k_dc_finish(const double *partial, int n_partials, size_t np, Fr
 }
 
 // rare fallback: exact reference order, one lane per frame
-__global__ void k_dc_sequential(const float *A, size_t np, FrameState *fs, int n_frames)
+__global__ void k_dc_sequential(const float *A, size_t np, FrameState *fs, int n_frames, const int *active)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames || !fs[f].dc_uncertain) return;
+    if (f >= n_frames || (active && !active[f]) || !fs[f].dc_uncertain) return;
     const float *a = A + (size_t) f * np;
     double s = 0;
     for (size_t i = 0; i < np; i++) s += a[i];
@@ -407,9 +408,10 @@ __global__ void k_cmax_init(FrameState *fs, int n_frames)
 }
 
 __global__ __launch_bounds__(256) void k_truncate(const float *__restrict__ A, int32_t *__restrict__ C, size_t np,
-                                                   FrameState *fs)
+                                                   FrameState *fs, const int *active)
 {
     const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
     const float *a = A + (size_t) frame * np;
     int32_t *c = C + (size_t) frame * np;
     int m = 0;
@@ -458,9 +460,10 @@ __device__ inline int first_child(const Grid &g, int x, int y)
 
 __global__ __launch_bounds__(256) void k_descmax(const int32_t *__restrict__ C, int32_t *__restrict__ D,
                                                   int32_t *__restrict__ G, Grid g, size_t np, int rx, int ry,
-                                                  int ex, int ey, int child_has_d)
+                                                  int ex, int ey, int child_has_d, const int *active)
 {
     const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
     const int32_t *c = C + (size_t) frame * np;
     int32_t *dd = D + (size_t) frame * np;
     int32_t *gg = G + (size_t) frame * np;
@@ -645,27 +648,28 @@ void launch_residual_minmax(const float *data, const float *decoded, int n_frame
                        fs, n_frames);
 }
 
-static void finish_dc(const ResidualBuffers &rb, int n_frames, hipStream_t s)
+static void finish_dc(const ResidualBuffers &rb, int n_frames, const int *active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_dc_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, kPartials, rb.np, rb.fs,
-                       n_frames);
-    hipLaunchKernelGGL(k_dc_sequential, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.A, rb.np, rb.fs, n_frames);
+                       n_frames, active);
+    hipLaunchKernelGGL(k_dc_sequential, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.A, rb.np, rb.fs, n_frames, active);
 }
 
-void launch_pad_and_dc(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames, hipStream_t s)
+void launch_pad_and_dc(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
+                       const int *d_active, hipStream_t s)
 {
     size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
     hipLaunchKernelGGL(k_pad_load<false>, dim3(kPartials, n_frames), dim3(256), 0, s, data, decoded, rb.A, rb.g, n_pix,
-                       rb.np, rb.fs, rb.partial);
-    finish_dc(rb, n_frames, s);
+                       rb.np, rb.fs, rb.partial, d_active);
+    finish_dc(rb, n_frames, d_active, s);
 }
 
 void launch_pad_and_dc_from_image(const float *image, const ResidualBuffers &rb, int n_frames, hipStream_t s)
 {
     size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
     hipLaunchKernelGGL(k_pad_load<true>, dim3(kPartials, n_frames), dim3(256), 0, s, image, (const float *) nullptr,
-                       rb.A, rb.g, n_pix, rb.np, rb.fs, rb.partial);
-    finish_dc(rb, n_frames, s);
+                       rb.A, rb.g, n_pix, rb.np, rb.fs, rb.partial, (const int *) nullptr);
+    finish_dc(rb, n_frames, nullptr, s);
 }
 
 static int *g_step_table = nullptr;   // device copy of floor(log(2^k)/log(2.0)) evaluated by the host libm
@@ -685,25 +689,25 @@ static const int *step_table(hipStream_t s)
     return g_step_table;
 }
 
-void launch_analysis(const ResidualBuffers &rb, int n_frames, hipStream_t s)
+void launch_analysis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
 {
     const Grid &g = rb.g;
     int nx = g.nx, ny = g.ny;
     for (int lv = 0; lv < g.stages; lv++) {                         // dwt.h:297-301
-        rows_fwd(rb.A, rb.T, rb, nx, ny, n_frames, lv == 0, nullptr, s);
-        cols_pass<true>(rb.T, rb.A, rb, ny, nx, n_frames, nullptr, s);
+        rows_fwd(rb.A, rb.T, rb, nx, ny, n_frames, lv == 0, d_active, s);
+        cols_pass<true>(rb.T, rb.A, rb, ny, nx, n_frames, d_active, s);
         nx >>= 1; ny >>= 1;
     }
     hipLaunchKernelGGL(k_cmax_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames);
-    hipLaunchKernelGGL(k_truncate, dim3(128, n_frames), dim3(256), 0, s, rb.A, rb.C, rb.np, rb.fs);
+    hipLaunchKernelGGL(k_truncate, dim3(128, n_frames), dim3(256), 0, s, rb.A, rb.C, rb.np, rb.fs, d_active);
     hipLaunchKernelGGL(k_top_step, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, step_table(s));
     for (int lv = 1; lv < g.stages; lv++) {
         int rx = g.nx >> lv, ry = g.ny >> lv;
         hipLaunchKernelGGL(k_descmax, dim3(ceil_div(rx * ry, 256), n_frames), dim3(256), 0, s, rb.C, rb.D, rb.G, g,
-                           rb.np, rx, ry, rx >> 1, ry >> 1, lv > 1 ? 1 : 0);
+                           rb.np, rx, ry, rx >> 1, ry >> 1, lv > 1 ? 1 : 0, d_active);
     }
     hipLaunchKernelGGL(k_descmax, dim3(ceil_div(g.lx * g.ly, 256), n_frames), dim3(256), 0, s, rb.C, rb.D, rb.G, g,
-                       rb.np, g.lx, g.ly, 0, 0, g.stages > 1 ? 1 : 0);
+                       rb.np, g.lx, g.ly, 0, 0, g.stages > 1 ? 1 : 0, d_active);
 }
 
 void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)

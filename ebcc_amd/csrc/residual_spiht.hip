@@ -128,12 +128,13 @@ __device__ inline void window_flush(const BitWindow &bw, unsigned int *stream, s
 __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
     const int32_t *__restrict__ Cb, const int32_t *__restrict__ Db, const int32_t *__restrict__ Gb, uint32_t *lipb,
     uint32_t *lspb, uint32_t *lis0b, uint32_t *lis1b, uint32_t *sigordb, uint32_t *lspidxb, uint32_t *streamb,
-    size_t stream_words, Grid g, size_t np, FrameState *fsb, const unsigned long long *bits0)
+    size_t stream_words, Grid g, size_t np, FrameState *fsb, const unsigned long long *bits0, const int *active)
 {
     __shared__ unsigned long long wave_tot[kEncWaves];
     __shared__ unsigned int window[kWindowWords];
 
     const int frame = blockIdx.x;
+    if (active && !active[frame]) return;
     const int tid = threadIdx.x;
     const int32_t *C = Cb + (size_t) frame * np;
     const int32_t *D = Db + (size_t) frame * np;
@@ -712,12 +713,13 @@ __global__ __launch_bounds__(256) void k_int_to_float(const int32_t *__restrict_
 }  // namespace
 
 // ================================================================================================
-void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, hipStream_t s)
+void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, const int *d_active,
+                         hipStream_t s)
 {
     EBCC_HIP_CHECK(hipMemsetAsync(rb.sigord, 0xFF, (size_t) n_frames * rb.np * sizeof(uint32_t), s));
     EBCC_HIP_CHECK(hipMemsetAsync(rb.stream, 0, (size_t) n_frames * rb.stream_words * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_spiht_encode, dim3(n_frames), dim3(kEncThreads), 0, s, rb.C, rb.D, rb.G, rb.lip, rb.lsp,
-                       rb.lis0, rb.lis1, rb.sigord, rb.lspidx, rb.stream, rb.stream_words, rb.g, rb.np, rb.fs, d_bits0);
+                       rb.lis0, rb.lis1, rb.sigord, rb.lspidx, rb.stream, rb.stream_words, rb.g, rb.np, rb.fs, d_bits0, d_active);
 }
 
 void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,

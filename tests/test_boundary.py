@@ -1,0 +1,80 @@
+"""CPU tests of the drop-in boundary: the shared library loads (no GPU needed for dlopen) and exports
+every symbol include/*.h declares; struct layouts match the reference's."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests import _lib as L
+
+ROOT = L.ROOT
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(\w+)\s*\(", txt))
+    skip = {"defined", "__attribute__", "visibility", "sizeof", "push", "dims", "height"}
+    return {n for n in names if n not in skip and not n.isupper()}
+
+
+@pytest.fixture(scope="module")
+def exported():
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built (run __graft_entry__.build())")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.PRODUCT_SO]).decode()
+    return {l.split()[-1] for l in out.splitlines() if " T " in l}
+
+
+def test_reference_api_symbols_exported(exported):
+    # /root/reference/src/ebcc_codec.h:41-49, src/h5z_ebcc.c:27-28,38
+    for name in ["ebcc_encode", "ebcc_decode", "ebcc_encode_chunking", "ebcc_encode_chunking_compat",
+                 "ebcc_decode_chunking", "free_buffer", "print_config", "log_set_level_from_env", "populate_config",
+                 "H5PLget_plugin_type", "H5PLget_plugin_info"]:
+        assert name in exported, name
+
+
+def test_every_declared_symbol_is_exported(exported):
+    declared = _declared("ebcc_codec.h") | _declared("ebcc_hip.h")
+    missing = sorted(n for n in declared if n not in exported)
+    assert not missing, missing
+
+
+def test_config_struct_layout():
+    assert ctypes.sizeof(L.CodecConfig) == 64                  # verified sizeof(codec_config_t) on LP64
+
+
+def test_plugin_descriptor():
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    lib = ctypes.CDLL(L.PRODUCT_SO)
+
+    class H5ZClass(ctypes.Structure):                          # /root/reference/src/hdf5_stub.h:34-43
+        _fields_ = [("version", ctypes.c_int), ("id", ctypes.c_int), ("encoder_present", ctypes.c_uint),
+                    ("decoder_present", ctypes.c_uint), ("name", ctypes.c_char_p), ("can_apply", ctypes.c_void_p),
+                    ("set_local", ctypes.c_void_p), ("filter", ctypes.c_void_p)]
+
+    lib.H5PLget_plugin_info.restype = ctypes.POINTER(H5ZClass)
+    lib.H5PLget_plugin_type.restype = ctypes.c_int
+    assert lib.H5PLget_plugin_type() == 0
+    info = lib.H5PLget_plugin_info().contents
+    assert (info.version, info.id, info.encoder_present, info.decoder_present) == (1, 308, 1, 1)
+    assert info.name == b"HDF5 EBCC filter L&L" and info.filter
+
+
+def test_populate_config_matches_reference_packing():
+    """cd_values layout of /root/reference/ebcc/filter_wrapper.py:22,32-40."""
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    import struct
+    lib = ctypes.CDLL(L.PRODUCT_SO)
+    lib.populate_config.argtypes = [ctypes.POINTER(L.CodecConfig), ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint),
+                                    ctypes.c_size_t]
+    f2u = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+    cd = (ctypes.c_uint * 5)(721, 1440, f2u(30.0), 1, f2u(0.5))
+    cfg = L.CodecConfig()
+    lib.populate_config(ctypes.byref(cfg), 5, cd, 2 * 721 * 1440 * 4)
+    assert tuple(cfg.dims) == (2, 721, 1440) and cfg.base_cr == 30.0 and cfg.residual_compression_type == 1
+    assert abs(cfg.error - 0.5) < 1e-7 and tuple(cfg.chunk_dims) == (0, 0, 0)

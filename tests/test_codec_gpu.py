@@ -1,0 +1,139 @@
+"""GPU parity of the whole frame codec through the reference's own C API (ebcc_encode / ebcc_decode /
+chunking) against golden streams produced by the reference build and against the CPU oracle."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def api_encode(data, cfg, fn="ebcc_encode"):
+    lib = L.product()
+    data = np.ascontiguousarray(data, np.float32)
+    out = ctypes.c_void_p()
+    n = getattr(lib, fn)(data.ctypes.data, ctypes.byref(cfg), ctypes.byref(out))
+    assert n > 0 and out
+    s = ctypes.string_at(out.value, n)
+    lib.free_buffer(out)
+    return s
+
+
+def api_decode(stream, fn="ebcc_decode"):
+    lib = L.product()
+    b = ctypes.create_string_buffer(bytes(stream), len(stream))
+    out = ctypes.c_void_p()
+    n = getattr(lib, fn)(b, len(stream), ctypes.byref(out))
+    assert n > 0 and out
+    a = np.frombuffer(ctypes.string_at(out.value, 4 * n), np.float32).copy()
+    lib.free_buffer(out)
+    return a
+
+
+_streams = json.load(open(os.path.join(L.GOLDEN, "codec_streams.json")))
+_inputs = np.load(os.path.join(L.GOLDEN, "codec_inputs.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(_streams), ids=str)
+def test_golden_streams_bit_exact(name, monkeypatch):
+    c = _streams[name]
+    if c["quantile"] is None:
+        monkeypatch.delenv("EBCC_INIT_BASE_ERROR_QUANTILE", raising=False)
+    else:
+        monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", c["quantile"])
+    cfg = L.make_config((1, c["h"], c["w"]), base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+    want = bytes.fromhex(c["stream_hex"])
+    got = api_encode(_inputs[c["input"]], cfg)
+    assert len(got) == len(want)
+    assert got == want
+    dec = api_decode(want)
+    assert sha(dec.tobytes()) == c["decoded_sha256"]          # 0 ULP against the reference decoder
+
+
+def _make_data(shape):
+    idx = np.indices(shape, dtype=np.float32)
+    return np.ascontiguousarray(idx[0] * 100.0 + idx[1] * 1.5 + idx[2] * 0.25, dtype=np.float32)
+
+
+_ebck = json.load(open(os.path.join(L.GOLDEN, "ebck.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_ebck), ids=str)
+def test_ebck_containers_bit_exact(name):
+    c = _ebck[name]
+    shape, chunk = tuple(c["shape"]), tuple(c["chunk"])
+    cfg = L.make_config(shape, chunk if any(chunk) else None, base_cr=2.0, error=c["error"], residual_type=c["mode"])
+    data = _make_data(shape)
+    s = api_encode(data, cfg, c["fn"])
+    assert len(s) == c["n"] and sha(s) == c["stream_sha256"]
+    d = api_decode(s, "ebcc_decode_chunking")
+    assert sha(d.tobytes()) == c["decoded_sha256"]
+    if c["mode"] == 1:                                         # reference tests/test_c_api.py:168-171
+        assert np.allclose(d.reshape(shape), data, atol=0.02)
+
+
+def test_full_size_formula_frames_bit_exact():
+    big = json.load(open(os.path.join(L.GOLDEN, "codec_big.json")))
+    y, x = np.mgrid[0:721, 0:1440]
+    f1 = (250.0 + ((x * 3 + y * 5) % 1024).astype(np.float32) / np.float32(64.0)
+          + (((x // 16) * 7 + (y // 16) * 13) % 97).astype(np.float32)).astype(np.float32)
+    for key, c in big.items():
+        cfg = L.make_config((1, 721, 1440), base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+        s = api_encode(f1, cfg)
+        assert len(s) == c["n"] and sha(s) == c["stream_sha256"], key
+        assert sha(api_decode(s).tobytes()) == c["decoded_sha256"], key
+
+
+@pytest.mark.parametrize("mode,err", [(L.MAX_ERROR, 0.5), (L.RELATIVE_ERROR, 1e-3)])
+def test_era5_like_batch_matches_oracle(mode, err):
+    """BASELINE configs 2/3 shape: 721x1440 synthetic frames through the batch API, oracle on the same inputs."""
+    frames = np.stack([L.era5_like(721, 1440, s) for s in (0, 1)] + [L.era5_like(721, 1440, 7, 1.0, 0.7)])
+    cfg = L.make_config((1, 721, 1440), base_cr=30.0, error=err, residual_type=mode)
+    L.oracle().orc_set_j2k_backend(0)
+    with L.Context(len(frames), 721, 1440) as ctx:
+        got = ctx.encode_frames(frames, cfg)
+        dec = ctx.decode_frames(got)
+    for f in range(len(frames)):
+        want = L.orc_encode(frames[f], cfg)
+        assert len(got[f]) == len(want) and got[f] == want, f
+        ref = L.orc_decode(want).reshape(721, 1440)
+        assert np.array_equal(dec[f], ref), f
+        tgt = err if mode == L.MAX_ERROR else err * float(frames[f].max() - frames[f].min())
+        assert np.abs(dec[f] - frames[f]).max() <= 1.01 * tgt + 1e-3
+
+
+def test_constant_and_zero_fields():
+    for v in (3.25, 0.0):
+        data = np.full((64, 64), v, np.float32)
+        cfg = L.make_config((1, 64, 64), base_cr=10, error=0.1, residual_type=L.MAX_ERROR)
+        s = api_encode(data, cfg)
+        assert len(s) == 56 and s[5] == 1                      # const-field flag, 8-byte count tail
+        assert np.array_equal(api_decode(s), data.ravel())
+
+
+def test_malformed_streams_are_rejected():
+    lib = L.product()
+    data = L.era5_like(64, 96, 64)
+    cfg = L.make_config((1, 64, 96), base_cr=10, residual_type=L.NONE)
+    s = api_encode(data, cfg)
+    for bad in (s[:40], s[:-1], s + b"\0", b"EBCC" + b"\x07" + s[5:]):
+        b = ctypes.create_string_buffer(bad, len(bad))
+        out = ctypes.c_void_p()
+        assert lib.ebcc_decode(b, len(bad), ctypes.byref(out)) == 0
+
+
+def test_invalid_dims_return_zero():
+    lib = L.product()
+    data = np.zeros((16, 16), np.float32)
+    cfg = L.make_config((1, 16, 16))
+    out = ctypes.c_void_p()
+    assert lib.ebcc_encode(data.ctypes.data, ctypes.byref(cfg), ctypes.byref(out)) == 0

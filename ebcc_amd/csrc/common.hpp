@@ -66,4 +66,13 @@ __host__ __device__ inline uint32_t float_order_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Optional per-kernel timing with HIP events recorded on the launching stream (bench.py's roofline leg).
+void timing_begin(const char *name, hipStream_t s);
+void timing_end(const char *name, hipStream_t s);
+struct ScopedTiming {
+    const char *name; hipStream_t s;
+    ScopedTiming(const char *n, hipStream_t st) : name(n), s(st) { timing_begin(name, s); }
+    ~ScopedTiming() { timing_end(name, s); }
+};
+
 }  // namespace ebcc

@@ -55,6 +55,28 @@ void push_frame_states(ebcc_hip_ctx *ctx, size_t n)
     EBCC_HIP_CHECK(hipMemcpyAsync(ctx->rb.fs, ctx->h_fs, n * sizeof(FrameState), hipMemcpyHostToDevice, ctx->stream));
 }
 
+// ---- optional kernel timing -------------------------------------------------------------------------
+struct TimedSpan { std::string name; hipEvent_t a, b; };
+static bool g_timing = false;
+static std::vector<TimedSpan> g_spans;
+static std::vector<hipEvent_t> g_open;
+
+void timing_begin(const char *name, hipStream_t s)
+{
+    if (!g_timing) return;
+    TimedSpan t{name, nullptr, nullptr};
+    EBCC_HIP_CHECK(hipEventCreate(&t.a));
+    EBCC_HIP_CHECK(hipEventCreate(&t.b));
+    EBCC_HIP_CHECK(hipEventRecord(t.a, s));
+    g_spans.push_back(t);
+}
+void timing_end(const char *name, hipStream_t s)
+{
+    if (!g_timing) return;
+    for (size_t i = g_spans.size(); i-- > 0;)
+        if (g_spans[i].name == name) { EBCC_HIP_CHECK(hipEventRecord(g_spans[i].b, s)); return; }
+}
+
 }  // namespace ebcc
 
 using namespace ebcc;
@@ -68,6 +90,31 @@ void j2k_destroy(ebcc_hip_ctx *ctx);
 extern "C" {
 
 const char *ebcc_hip_last_error(void) { return g_last_error.c_str(); }
+
+void ebcc_hip_timing_enable(ebcc_hip_ctx *ctx, int on)
+{
+    (void) ctx;
+    if (on) {
+        for (auto &t : g_spans) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+        g_spans.clear();
+    }
+    g_timing = on != 0;
+}
+
+int ebcc_hip_timing_read(ebcc_hip_ctx *ctx, const char *name, double *total_ms, long *launches)
+{
+    if (ctx) EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    long n = 0;
+    for (auto &t : g_spans)
+        if (t.name == name) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { tot += ms; n++; }
+        }
+    *total_ms = tot;
+    *launches = n;
+    return 0;
+}
 
 int ebcc_hip_device_count(void)
 {

@@ -561,15 +561,19 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     const int total = n_frames * g.nblocks;
     const size_t groups = ((size_t) total + 63) / 64;
     hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
+    timing_begin("j2k_dwt_fwd", s);
     for (int r = kJ2kRes - 1; r >= 1; r--) {                           // opj_dwt_encode_procedure: vertical, then horizontal
         dwt_cols<true>(jb.B, g, r, n_frames, fs, nullptr, s);
         dwt_rows<true>(jb.B, g, r, n_frames, fs, nullptr, s);
     }
+    timing_end("j2k_dwt_fwd", s);
     hipLaunchKernelGGL(k_quantize, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.blkmax,
                        jb.d_geom, jb.d_blocks, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+    timing_begin("t1_encode", s);
     hipLaunchKernelGGL(k_t1_encode, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.blkmax, jb.numbps,
                        jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.d_geom, jb.d_blocks, fs, jb.jf, total);
+    timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.T1S, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
 }

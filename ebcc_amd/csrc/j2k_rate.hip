@@ -516,6 +516,7 @@ size_t rate_lds(const J2kGeom &g)
 // ================================================================================================
 void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
+    ScopedTiming t("rate_alloc", s);
     hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), rate_lds(jb.geom), s, jb.numbps, jb.totalpasses, jb.rates,
                        jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active);
 }
@@ -550,8 +551,10 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
     const size_t groups = ((size_t) total + 63) / 64;
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
+    timing_begin("t1_probe_decode", s);
     hipLaunchKernelGGL(k_t1_decode<true>, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.stream_cap,
                        jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
+    timing_end("t1_probe_decode", s);
     decode_tail(data, jb, n_frames, d_active, true, s);
 }
 
@@ -562,9 +565,11 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     const size_t groups = ((size_t) total + 63) / 64;
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
+    timing_begin("t1_decode", s);
     hipLaunchKernelGGL(k_t1_decode<false>, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
                        jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, (const int *) nullptr,
                        total);
+    timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);
 }
 

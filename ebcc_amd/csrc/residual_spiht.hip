@@ -718,6 +718,7 @@ void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned
 {
     EBCC_HIP_CHECK(hipMemsetAsync(rb.sigord, 0xFF, (size_t) n_frames * rb.np * sizeof(uint32_t), s));
     EBCC_HIP_CHECK(hipMemsetAsync(rb.stream, 0, (size_t) n_frames * rb.stream_words * sizeof(uint32_t), s));
+    ScopedTiming t("spiht_encode", s);
     hipLaunchKernelGGL(k_spiht_encode, dim3(n_frames), dim3(kEncThreads), 0, s, rb.C, rb.D, rb.G, rb.lip, rb.lsp,
                        rb.lis0, rb.lis1, rb.sigord, rb.lspidx, rb.stream, rb.stream_words, rb.g, rb.np, rb.fs, d_bits0, d_active);
 }

@@ -67,6 +67,20 @@ int ebcc_hip_spiht_decode_prefix(ebcc_hip_ctx *ctx, size_t n_frames, const size_
 int ebcc_hip_spiht_coeffs(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, int32_t *coeffs, int *dc);
 size_t ebcc_hip_padded_pixels(const ebcc_hip_ctx *ctx);
 
+/* ---- JPEG 2000 base layer (unit level) ----------------------------------------------------------
+ * Batch forms of j2k_encode_internal / j2k_decode_internal, /root/reference/src/ebcc_codec.c:105-180,
+ * :1092-1136 (the reference reaches OpenJPEG there).  Frames are scaled to u16 with their own min/max as
+ * ebcc_encode does (:675-689) and coded at rate cr[f]; minmax (host, [n][2], may be NULL) returns them. */
+int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const float *cr, uint8_t **out_streams,
+                        size_t *out_sizes, float *minmax);
+/* After ebcc_hip_j2k_encode: the field j2k_decode_internal would return for those codestreams, decoded in
+ * place from the encoder's code-block slots; nbad[f] = count(|x - d| > target[f]), err_sum[f] = sum(x - d). */
+int ebcc_hip_j2k_emulated_decode(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const float *target,
+                                 float *d_out, unsigned long long *nbad, double *err_sum);
+/* j2k_decode_internal for a batch of codestreams with (minval, maxval) pairs in minmax [n][2] */
+int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
+                        const float *minmax, float *d_out);
+
 /* ---- frame codec -----------------------------------------------------------------------------
  * Batch forms of ebcc_encode / ebcc_decode (src/ebcc_codec.h:41-42) for frames resident in HBM.
  * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
@@ -75,6 +89,11 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
                            uint8_t **out_streams, size_t *out_sizes);
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                            float *d_frames_out);
+
+/* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).  Names: "t1_encode",
+ * "t1_probe_decode", "t1_decode", "rate_alloc", "j2k_dwt_fwd", "spiht_encode".  Process-wide switch. */
+void ebcc_hip_timing_enable(ebcc_hip_ctx *ctx, int on);
+int ebcc_hip_timing_read(ebcc_hip_ctx *ctx, const char *name, double *total_ms, long *launches);
 
 /* last error text of the calling thread ("" if none) */
 const char *ebcc_hip_last_error(void);

@@ -62,7 +62,7 @@ struct Zstd {
     {
         const char *names[] = {"/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", nullptr};
         void *h = nullptr;
-        for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);   // DEEPBIND: never mix with another zstd already in the process
         if (!h) return;
         bound = (size_t(*)(size_t)) dlsym(h, "ZSTD_compressBound");
         compress = (size_t(*)(void *, size_t, const void *, size_t, int)) dlsym(h, "ZSTD_compress");

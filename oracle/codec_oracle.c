@@ -40,7 +40,7 @@ static int zstd_load(void)
     if (z_comp) return 1;
     const char *names[] = { "/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", NULL };
     void *h = NULL;
-    for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);   // DEEPBIND: never mix with another zstd already in the process
     if (!h) { fprintf(stderr, "oracle: libzstd not found\n"); return 0; }
     z_bound = (zstd_bound_fn) dlsym(h, "ZSTD_compressBound");
     z_comp = (zstd_comp_fn) dlsym(h, "ZSTD_compress");

@@ -41,6 +41,7 @@ struct J2kBlock {
 struct J2kGeom {
     int W, H, nblocks, nbands, tree_nodes;
     int rw[kJ2kRes], rh[kJ2kRes];
+    int res_first[kJ2kRes + 1];   // first code-block of every resolution (packet order)
     J2kBand bands[kJ2kBands];
 };
 

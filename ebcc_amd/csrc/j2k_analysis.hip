@@ -37,6 +37,7 @@ J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
     blocks.clear();
     int bi = 0, nodes = 0;
     for (int r = 0; r < kJ2kRes; r++) {
+        g.res_first[r] = (int) blocks.size();
         int lv = kJ2kRes - 1 - r;
         int nb = r == 0 ? 1 : 3;
         for (int b = 0; b < nb; b++, bi++) {
@@ -95,6 +96,7 @@ J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
     }
     g.nbands = bi;
     g.nblocks = (int) blocks.size();
+    g.res_first[kJ2kRes] = g.nblocks;
     g.tree_nodes = nodes;
     return g;
 }

@@ -126,6 +126,11 @@ struct RateLds {
     short *npass;
     Trees t;
     short *mval0;        // static zero-bit-plane node minima
+    // parallel size evaluation
+    short *prev;         // previous layer assignment (unchanged assignment => unchanged size)
+    int *firstinc;       // per tree node: raster index of the first included leaf below it (INT_MAX = none)
+    unsigned int *raw;   // unstuffed header bits, 128 bits per code-block, per-resolution regions
+    int *leafbits;       // per code-block header bit count (scratch of the scan)
     __device__ static size_t bytes(int nblocks, int nodes)
     {
         return (size_t) nblocks * 2 + (size_t) nodes * (2 * 5 + 2) + 64;
@@ -139,7 +144,12 @@ struct RateLds {
         t.mlow = (short *) base; base += (size_t) nodes * 2;
         mval0 = (short *) base; base += (size_t) nodes * 2;
         t.iknown = base; base += nodes;
-        t.mknown = base;
+        t.mknown = base; base += nodes;
+        base = (unsigned char *) ((((size_t) base) + 7) & ~(size_t) 7);
+        prev = (short *) base; base += (((size_t) nblocks * 2 + 7) / 8) * 8;
+        firstinc = (int *) base; base += (size_t) nodes * 4;
+        raw = (unsigned int *) base; base += (size_t) nblocks * 16;
+        leafbits = (int *) base;
     }
 };
 
@@ -220,6 +230,153 @@ __device__ int layer_bytes(const J2kGeom &g, RateLds &L, const int *rates, int g
     return *s_sum;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Parallel evaluation of the packet sizes (what opj_t2_encode_packets(THRESH_CALC) returns).
+// Tag-tree coding in closed form (B.10.2 with every leaf visited in raster order):
+//   inclusion tree, threshold 1: a node emits ONE bit - "some leaf below me is included" - when its top-left
+//     leaf is visited, provided every ancestor has an included leaf (otherwise the walk stopped above);
+//   zero-bit-plane tree: a node emits (value - parent's value) zeros and a one when the FIRST INCLUDED leaf
+//     below it is visited; node values are static minima over all leaves.
+// So every code-block derives its header bits independently; offsets come from a scan, the bits are OR-ed
+// into LDS, and the B.10.1 bit stuffing (7 bits after a 0xFF byte) is counted by a ballot search for the
+// next 0xFF byte.  Byte-for-byte equal to the serial writer (packet_header) that k_write uses.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void raw_put(unsigned int *raw, int pos, unsigned long long v, int n)
+{
+    // n <= 64 bits of v (right-aligned), MSB first, at bit position pos
+    while (n > 0) {
+        int take = n > 32 ? n - 32 : n;                              // leading chunk first
+        if (n <= 32) take = n;
+        unsigned int chunk = (unsigned int) ((v >> (n - take)) & (take == 32 ? 0xFFFFFFFFull : ((1ull << take) - 1)));
+        int w = pos >> 5, sh = pos & 31;
+        unsigned long long x = (unsigned long long) chunk << (64 - take - sh);
+        unsigned int hi = (unsigned int) (x >> 32), lo = (unsigned int) x;
+        if (hi) atomicOr(&raw[w], hi);
+        if (lo) atomicOr(&raw[w + 1], lo);
+        pos += take; n -= take;
+    }
+}
+
+__device__ inline unsigned int raw_byte(const unsigned int *raw, int pos)
+{
+    int w = pos >> 5, sh = pos & 31;
+    unsigned long long x = ((unsigned long long) raw[w] << 32) | raw[w + 1];
+    return (unsigned int) ((x << sh) >> 56);
+}
+
+__device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum, int *s_tmp)
+{
+    const int INF = 0x7FFFFFFF;
+    for (int i = lane; i < g.tree_nodes; i += kRateThreads) L.firstinc[i] = INF;
+    for (int i = lane; i < g.nblocks * 4 + 4; i += kRateThreads) L.raw[i] = 0;
+    if (lane == 0) *s_sum = 0;
+    __syncthreads();
+    // first included leaf below every node
+    for (int b = lane; b < g.nblocks; b += kRateThreads) {
+        if (!L.npass[b]) continue;
+        // band of the block: bands are few, find by first_block
+        int bi = 0;
+        while (bi + 1 < g.nbands && g.bands[bi + 1].first_block <= b) bi++;
+        const J2kBand &bd = g.bands[bi];
+        const int k = b - bd.first_block, cy = k / bd.ncw, cx = k - cy * bd.ncw;
+        for (int l = 0; l < bd.tree_levels; l++)
+            atomicMin(&L.firstinc[bd.tree_off + bd.lvl_off[l] + (cy >> l) * bd.lvl_w[l] + (cx >> l)], k);
+    }
+    __syncthreads();
+    // per-leaf header bits: A = inclusion + zero-bit-plane bits, B = passes + Lblock comma code + length
+    int body = 0;
+    for (int base = 0; base < g.nblocks; base += kRateThreads) {
+        const int b = base + lane;
+        unsigned long long A = 0, B = 0;
+        int na = 0, nbb = 0, res = 0;
+        if (b < g.nblocks) {
+            int bi = 0;
+            while (bi + 1 < g.nbands && g.bands[bi + 1].first_block <= b) bi++;
+            const J2kBand &bd = g.bands[bi];
+            res = bd.res;
+            const int k = b - bd.first_block, cy = k / bd.ncw, cx = k - cy * bd.ncw;
+            bool alive = true;
+            for (int l = bd.tree_levels - 1; l >= 0 && alive; l--) {
+                const int node = bd.tree_off + bd.lvl_off[l] + (cy >> l) * bd.lvl_w[l] + (cx >> l);
+                const bool has = L.firstinc[node] != INF;
+                const int mask = (1 << l) - 1;
+                if (((cx & mask) | (cy & mask)) == 0) { A = (A << 1) | (has ? 1ull : 0ull); na++; }
+                if (!has) alive = false;
+            }
+            const int n = L.npass[b];
+            if (n) {
+                int prevm = 0;
+                for (int l = bd.tree_levels - 1; l >= 0; l--) {
+                    const int node = bd.tree_off + bd.lvl_off[l] + (cy >> l) * bd.lvl_w[l] + (cx >> l);
+                    const int m = L.mval0[node];
+                    if (L.firstinc[node] == k) { const int z = m - prevm; A = ((A << z) << 1) | 1ull; na += z + 1; }
+                    prevm = m;
+                }
+                // number of passes (table B.4)
+                if (n == 1) { B = 0; nbb = 1; }
+                else if (n == 2) { B = 2; nbb = 2; }
+                else if (n <= 5) { B = 0xCull | (unsigned) (n - 3); nbb = 4; }
+                else if (n <= 36) { B = 0x1E0ull | (unsigned) (n - 6); nbb = 9; }
+                else { B = 0xFF80ull | (unsigned) (n - 37); nbb = 16; }
+                const int seglen = rates[(size_t) (gid0 + b) * kJ2kMaxPasses + n - 1];
+                int inc = floorlog2d(seglen) + 1 - (3 + floorlog2d(n));
+                if (inc < 0) inc = 0;
+                B = (B << (inc + 1)) | (((1ull << inc) - 1) << 1);                 // inc ones, then a zero
+                nbb += inc + 1;
+                const int lb = 3 + inc + floorlog2d(n);
+                B = (B << lb) | ((unsigned long long) seglen & ((1ull << lb) - 1));
+                nbb += lb;
+                body += seglen;
+            }
+            L.leafbits[b] = na + nbb;
+        }
+        __syncthreads();
+        // exclusive offsets inside the resolution: leaves are in packet order, resolutions are contiguous
+        if (b < g.nblocks) {
+            int off = 1;                                                           // the leading "packet present" bit
+            for (int j = g.res_first[res]; j < b; j++) off += L.leafbits[j];
+            const int region = g.res_first[res] * 128;
+            raw_put(L.raw, region + off, A, na);
+            raw_put(L.raw, region + off + na, B, nbb);
+        }
+        __syncthreads();
+    }
+    for (int d = 32; d >= 1; d >>= 1) body += __shfl_xor(body, d);
+    // stuffing-aware byte count per resolution
+    int total = body;
+    for (int r = 0; r < kJ2kRes; r++) {
+        const int region = g.res_first[r] * 128;
+        if (lane == 0) {
+            atomicOr(&L.raw[region >> 5], 0x80000000u);                            // leading bit = 1
+            int T = 1;
+            for (int j = g.res_first[r]; j < g.res_first[r + 1]; j++) T += L.leafbits[j];
+            *s_tmp = T;
+        }
+        __syncthreads();
+        const int T = *s_tmp;
+        int p = 0, count = 0;
+        for (;;) {
+            // first full byte == 0xFF at or after bit p (8-bit groups)
+            const int groups = (T - p) >> 3;                                       // full bytes available
+            int found = -1;
+            for (int j0 = 0; j0 < groups && found < 0; j0 += kRateThreads) {
+                const int j = j0 + lane;
+                const bool hit = j < groups && raw_byte(L.raw, region + p + 8 * j) == 0xFFu;
+                const unsigned long long m = __ballot(hit);
+                if (m) found = j0 + (__ffsll((long long) m) - 1);
+            }
+            if (found < 0) { count += (T - p + 7) >> 3; break; }
+            count += found + 1 + 1;                                                // bytes up to the FF, plus the 7-bit byte / flush byte after it
+            p += 8 * (found + 1) + 7;
+            if (p >= T) break;
+        }
+        total += count;
+        __syncthreads();
+    }
+    return total;
+}
+
 // ================================================================================================
 // rate allocation kernel: one workgroup (one wave) per frame
 // ================================================================================================
@@ -229,7 +386,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                                                         const FrameState *fs, const int *active)
 {
     extern __shared__ unsigned char lds_raw[];
-    __shared__ int s_sum;
+    __shared__ int s_sum, s_tmp, s_changed;
     __shared__ double s_min[kRateThreads], s_max[kRateThreads];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
@@ -238,6 +395,28 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     RateLds L;
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
     trees_static(g, L, numbps, gid0, lane);
+    for (int b = lane; b < g.nblocks; b += kRateThreads) L.prev[b] = -1;
+    int prev_bytes = 0;
+    // size of the current assignment; identical assignments (late bisection steps) reuse the previous result
+    auto sized = [&]() -> int {
+        if (lane == 0) s_changed = 0;
+        __syncthreads();
+        int ch = 0;
+        for (int b = lane; b < g.nblocks; b += kRateThreads) { if (L.prev[b] != L.npass[b]) ch = 1; L.prev[b] = L.npass[b]; }
+        if (ch) s_changed = 1;
+        __syncthreads();
+        if (s_changed) {
+#ifdef EBCC_RATE_CHECK
+            const int ref = layer_bytes(g, L, rates, gid0, lane, &s_sum);
+            prev_bytes = layer_bytes_fast(g, L, rates, gid0, lane, &s_sum, &s_tmp);
+            if (ref != prev_bytes && lane == 0) { printf("rate check: frame %d fast %d serial %d\n", frame, prev_bytes, ref); }
+            prev_bytes = ref;
+#else
+            prev_bytes = layer_bytes_fast(g, L, rates, gid0, lane, &s_sum, &s_tmp);
+#endif
+        }
+        return prev_bytes;
+    };
 
     // opj_j2k_setup_encoder / opj_j2k_update_rates: byte budget of the single layer
     float rate = jf[frame].cr / 2;                                   // tcp_rates[0] = base_cr / 2, ebcc_codec.c:116
@@ -276,7 +455,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
             make_layer(g, L, totalpasses, rates, disto, gid0, thresh, lane);
-            const int bytes = layer_bytes(g, L, rates, gid0, lane, &s_sum);
+            const int bytes = sized();
             if ((long long) bytes > maxlen) { lo = thresh; continue; }
             hi = thresh;
             stable = thresh;
@@ -284,7 +463,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         good = stable == 0 ? thresh : stable;
     }
     make_layer(g, L, totalpasses, rates, disto, gid0, good, lane);
-    const int body = layer_bytes(g, L, rates, gid0, lane, &s_sum);
+    const int body = sized();
     for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
     if (lane == 0) {
         jf[frame].body_bytes = body;
@@ -508,7 +687,7 @@ __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, 
 
 size_t rate_lds(const J2kGeom &g)
 {
-    return (((size_t) g.nblocks * 2 + 7) / 8) * 8 + (size_t) g.tree_nodes * 12 + 64;
+    return 2 * ((((size_t) g.nblocks * 2 + 7) / 8) * 8) + (size_t) g.tree_nodes * 16 + (size_t) g.nblocks * 20 + 128;
 }
 
 }  // namespace

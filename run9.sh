@@ -1,0 +1,2 @@
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step','encode_GBps','decode_GBps','kernels')})"

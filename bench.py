@@ -188,7 +188,7 @@ def main():
         tms, launches = ctypes.c_double(), ctypes.c_long()
         lib.ebcc_hip_timing_read(ctx, b"t1_encode", ctypes.byref(tms), ctypes.byref(launches))
         kern = {}
-        for name in (b"t1_encode", b"t1_probe_decode", b"rate_alloc", b"j2k_dwt_fwd", b"spiht_encode", b"t1_decode"):
+        for name in (b"t1_encode", b"t1_checkpoints", b"t1_probe_decode", b"rate_alloc", b"j2k_dwt_fwd", b"spiht_encode", b"t1_decode"):
             a, c = ctypes.c_double(), ctypes.c_long()
             lib.ebcc_hip_timing_read(ctx, name, ctypes.byref(a), ctypes.byref(c))
             if c.value:

@@ -67,6 +67,9 @@ struct J2kBuffers {
     float *DEC;                   // [frames][H*W] last decoded field (fp32, de-normalised)
     unsigned long long *BP;       // [groups][planes][64][64] bit-plane row masks, lane-interleaved
     unsigned long long *SGN;      // [groups][64][64] sign row masks
+    unsigned long long *SUF;      // [groups][planes+2][64][64] suffix-OR of BP over planes >= p (significance above a plane)
+    void *ckpt;                   // [frames*nblocks][planes] MQ-decoder checkpoints at every bit-plane start
+    int *qplane;                  // [frames*nblocks] bit-plane at which the current probe's decode restarts (-1: nothing)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
     int *blkmax;                  // [frames*nblocks] max |q6|
     int *numbps;                  // [frames*nblocks]

@@ -368,7 +368,7 @@ void dwt_rows(float *B, const J2kGeom &g, int r, int n_frames, const FrameState 
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, int32_t *__restrict__ Q6,
                                                    unsigned long long *__restrict__ BP, unsigned long long *__restrict__ SGN,
-                                                   int *__restrict__ blkmax, const J2kGeom *geom, const J2kBlock *blocks,
+                                                   unsigned long long *__restrict__ SUF, int *__restrict__ blkmax, const J2kGeom *geom, const J2kBlock *blocks,
                                                    const FrameState *fs)
 {
     __shared__ int smax[4];
@@ -398,9 +398,18 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
         unsigned long long sg = __ballot(q6 < 0);
         if (lane == 0) SGN[(grp * 64 + row) * 64 + gl] = sg;
         const int a = a6 >> 6;
-        for (int p = 0; p < kJ2kMaxPlanes; p++) {
+        unsigned long long suf = 0;                                 // OR of the planes >= p: "some bit at or above p"
+        if (lane == 0) {
+            SUF[((grp * (kJ2kMaxPlanes + 2) + kJ2kMaxPlanes + 1) * 64 + row) * 64 + gl] = 0;
+            SUF[((grp * (kJ2kMaxPlanes + 2) + kJ2kMaxPlanes) * 64 + row) * 64 + gl] = 0;
+        }
+        for (int p = kJ2kMaxPlanes - 1; p >= 0; p--) {
             unsigned long long m = __ballot((a >> p) & 1);
-            if (lane == 0) BP[((grp * kJ2kMaxPlanes + p) * 64 + row) * 64 + gl] = m;
+            suf |= m;
+            if (lane == 0) {
+                BP[((grp * kJ2kMaxPlanes + p) * 64 + row) * 64 + gl] = m;
+                SUF[((grp * (kJ2kMaxPlanes + 2) + p) * 64 + row) * 64 + gl] = suf;
+            }
         }
     }
     for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
@@ -518,6 +527,50 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
     }
 }
 
+
+// ================================================================================================
+// MQ-decoder checkpoints: decode every code-block's complete segment once and save the decoder registers at
+// the start of every bit-plane.  A rate probe then restarts at the last plane it keeps (j2k_rate.hip)
+// instead of decoding all kept passes.
+// ================================================================================================
+struct CkStore {
+    unsigned long long *st;
+    __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
+    __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
+    __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
+    __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
+    __device__ void set_sig(int, int, int, int) {}
+    __device__ void refine(int, int, int, int) {}
+};
+struct CkObserver {
+    t1::MqCheckpoint *ck;
+    template <class Mq>
+    __device__ void plane_start(int bp, const Mq &m) { ck[bp] = t1::MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+};
+struct CkSrc {
+    const uint8_t *p; int n;
+    __device__ uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; }
+};
+
+__global__ __launch_bounds__(64) void k_t1_checkpoints(unsigned long long *T1S, const uint8_t *cblk_bytes, const int *numbps,
+                                                        const int *totalpasses, const int *cblk_len, t1::MqCheckpoint *ckpt,
+                                                        const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
+                                                        int total)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= total) return;
+    const int nb = geom->nblocks;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if (fs[frame].const_field) return;
+    const int P = numbps[gid], np = totalpasses[gid];
+    if (np <= 0 || P <= 0) return;
+    const J2kBlock blk = blocks[bi];
+    CkStore st{T1S + (size_t) (gid >> 6) * kT1StateWords * 64 + (gid & 63)};
+    CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPlanes};
+    t1::decode_block_observed(st, CkSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, cblk_len[gid]}, blk.w, blk.h,
+                              geom->bands[blk.band].orient, P, np, obs);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -569,7 +622,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
         dwt_rows<true>(jb.B, g, r, n_frames, fs, nullptr, s);
     }
     timing_end("j2k_dwt_fwd", s);
-    hipLaunchKernelGGL(k_quantize, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.blkmax,
+    hipLaunchKernelGGL(k_quantize, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
                        jb.d_geom, jb.d_blocks, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_encode", s);
@@ -578,6 +631,12 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.T1S, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
+    // decoder checkpoints for the rate probes (the encoder's SPS masks in T1S are no longer needed)
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+    timing_begin("t1_checkpoints", s);
+    hipLaunchKernelGGL(k_t1_checkpoints, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.numbps,
+                       jb.totalpasses, jb.cblk_len, (t1::MqCheckpoint *) jb.ckpt, jb.d_geom, jb.d_blocks, fs, total);
+    timing_end("t1_checkpoints", s);
 }
 
 // inverse transform of the tile buffers, used by both decode flavours (j2k_rate.hip)

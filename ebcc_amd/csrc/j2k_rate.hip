@@ -672,6 +672,96 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
     t1::decode_block(st, DecSrc{src, len}, blk.w, blk.h, geom->bands[blk.band].orient, P, np);
 }
 
+
+// ================================================================================================
+// rate-probe decode, restarted at the last bit-plane the layer keeps
+//   k_probe_plan : per code-block, the restart plane q (last coded plane, or an earlier one if the checkpoint
+//                  there was taken after the decoder had already consumed a byte at/after the truncation point)
+//   k_probe_init : per sample, the value the decoder holds at the start of plane q (all planes above q are
+//                  complete, so it follows from the quantised coefficient) - replaces zero-filling V
+//   k_t1_resume  : one code-block per lane: state masks from the suffix-OR bit-plane masks, MQ registers from
+//                  the checkpoint, then the (at most three) passes of the remaining planes on the truncated bytes
+// ================================================================================================
+__global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restrict__ npass, const int *__restrict__ rates,
+                             const t1::MqCheckpoint *__restrict__ ckpt, int *__restrict__ qplane, const J2kGeom *geom,
+                             const FrameState *fs, const int *active, int total)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int frame = gid / geom->nblocks;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const int n = npass[gid], P = numbps[gid];
+    int q = -1;
+    if (n > 0 && P > 0) {
+        const int len = rates[(size_t) gid * kJ2kMaxPasses + n - 1];
+        q = t1::plane_of_pass(P, n - 1);
+        while (q < P - 1 && ckpt[(size_t) gid * kJ2kMaxPlanes + q].pos + 1 >= len) q++;
+    }
+    qplane[gid] = q;
+}
+
+__global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ Q6, const int *__restrict__ qplane,
+                                                     const std::uint16_t *__restrict__ blkmap, int32_t *__restrict__ V,
+                                                     const J2kGeom *geom, const FrameState *fs, const int *active)
+{
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const size_t n_pix = (size_t) geom->W * geom->H;
+    const int32_t *q = Q6 + (size_t) frame * n_pix;
+    int32_t *v = V + (size_t) frame * n_pix;
+    const int gid0 = frame * geom->nblocks;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
+        const int qp = qplane[gid0 + blkmap[i]];
+        const int q6 = q[i];
+        const unsigned int a = (unsigned int) (q6 < 0 ? -q6 : q6) >> 6;
+        int out = 0;
+        if (qp >= 0 && a) {
+            const int bs = 31 - __clz(a);
+            if (bs > qp) {
+                out = 3 << bs;                                          // 1.5 * 2^bs in half units, then the refinements
+                for (int pl = bs - 1; pl > qp; pl--) out += ((a >> pl) & 1u) ? (1 << pl) : -(1 << pl);
+                if (q6 < 0) out = -out;
+            }
+        }
+        v[i] = out;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const unsigned long long *SUF,
+                                                   const unsigned long long *SGN, const uint8_t *cblk_bytes,
+                                                   const int *numbps, const int *npass, const int *rates, const int *qplane,
+                                                   const t1::MqCheckpoint *ckpt, int32_t *V, const J2kGeom *geom,
+                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= total) return;
+    const int nb = geom->nblocks;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if ((active && !active[frame]) || fs[frame].const_field) return;
+    const int q = qplane[gid];
+    if (q < 0) return;
+    const int np = npass[gid], P = numbps[gid];
+    const int len = rates[(size_t) gid * kJ2kMaxPasses + np - 1];
+    const J2kBlock blk = blocks[bi];
+    const size_t grp = (size_t) (gid >> 6);
+    const int gl = gid & 63;
+    DecStore st{T1S + grp * kT1StateWords * 64 + gl, V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x,
+                geom->W};
+    // state at the start of plane q: significant = some bit above q, refined = some bit at least two planes above q
+    const unsigned long long *suf1 = SUF + ((grp * (kJ2kMaxPlanes + 2) + q + 1) * 64) * 64 + gl;
+    const unsigned long long *suf2 = SUF + ((grp * (kJ2kMaxPlanes + 2) + q + 2) * 64) * 64 + gl;
+    const unsigned long long *sg = SGN + grp * 64 * 64 + gl;
+    for (int y = 0; y < 64; y++) {
+        const unsigned long long s1 = y < blk.h ? suf1[(size_t) y * 64] : 0ull;
+        st.S(y) = s1;
+        st.NEG(y) = y < blk.h ? (sg[(size_t) y * 64] & s1) : 0ull;
+        st.REF(y) = y < blk.h ? suf2[(size_t) y * 64] : 0ull;
+        st.VIS(y) = 0ull;
+    }
+    t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
+                      np, q, ckpt[(size_t) gid * kJ2kMaxPlanes + q]);
+}
+
 __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, const std::uint16_t *__restrict__ blkmap,
                                                   float *__restrict__ B, const J2kGeom *geom, const J2kBlock *blocks,
                                                   const FrameState *fs, const int *active)
@@ -725,14 +815,16 @@ static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, c
 
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
-    const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
     const int total = n_frames * jb.geom.nblocks;
     const size_t groups = ((size_t) total + 63) / 64;
-    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
-    EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
+    const t1::MqCheckpoint *ck = (const t1::MqCheckpoint *) jb.ckpt;
+    hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
+                       jb.d_geom, jb.fs, d_active, total);
+    hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.d_blkmap, jb.V, jb.d_geom, jb.fs,
+                       d_active);
     timing_begin("t1_probe_decode", s);
-    hipLaunchKernelGGL(k_t1_decode<true>, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.stream_cap,
-                       jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
+    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.SUF, jb.SGN, jb.cblk_bytes, jb.numbps,
+                       jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
     timing_end("t1_probe_decode", s);
     decode_tail(data, jb, n_frames, d_active, true, s);
 }

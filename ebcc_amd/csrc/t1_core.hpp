@@ -533,14 +533,60 @@ T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h
     return r;
 }
 
-template <class Store, class Source>
-T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses)
+// MQ decoder registers at the start of a bit-plane (taken while decoding the complete segment)
+struct MqCheckpoint {
+    uint32_t a, c;
+    int ct, pos;
+    u64 w0, w1, w2;
+};
+
+struct NoObserver {
+    template <class Mq>
+    T1_HD void plane_start(int, const Mq &) {}
+};
+
+// index of the first coding pass of bit-plane `bp` in a code-block with P planes, and the plane of pass i
+T1_HD int first_pass_of_plane(int P, int bp) { return bp == P - 1 ? 0 : 3 * (P - 1 - bp) - 2; }
+T1_HD int plane_of_pass(int P, int i) { return i == 0 ? P - 1 : P - 2 - (i - 1) / 3; }
+
+template <class Store, class Source, class Observer>
+T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Observer &obs)
 {
     MqDecoder<Source> mq{0, 0, 0, 0, {0, 0, 0}, src};
     mq.init();
     Passes<false, Store, MqDecoder<Source>> ps(st, mq, w, h, orient);
     int passtype = 2, bp = numbps - 1;
     for (int p = 0; p < npasses && bp >= 0; p++) {
+        if (passtype == 0 || p == 0) obs.plane_start(bp, mq);
+        if (passtype == 0) ps.sigprop(bp);
+        else if (passtype == 1) ps.refine(bp);
+        else ps.cleanup(bp);
+        if (++passtype == 3) { passtype = 0; bp--; }
+    }
+}
+
+template <class Store, class Source>
+T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses)
+{
+    NoObserver obs;
+    decode_block_observed(st, src, w, h, orient, numbps, npasses, obs);
+}
+
+// Decode passes [first_pass_of_plane(q), npasses) only.  The caller has put the store into the state the
+// decoder has at the start of plane q (S/NEG/REF masks and values of everything significant in planes above
+// q, VIS clear); `ck` holds the MQ registers there (ignored for q == numbps-1, where decoding starts afresh).
+// Valid whenever the checkpoint was taken with no byte at or beyond the (truncated) segment length consumed:
+// ck.pos + 1 < length of src.
+template <class Store, class Source>
+T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int q,
+                         const MqCheckpoint &ck)
+{
+    MqDecoder<Source> mq{0, 0, 0, 0, {0, 0, 0}, src};
+    if (q == numbps - 1) mq.init();
+    else { mq.a = ck.a; mq.c = ck.c; mq.ct = ck.ct; mq.pos = ck.pos; mq.cx.w0 = ck.w0; mq.cx.w1 = ck.w1; mq.cx.w2 = ck.w2; }
+    Passes<false, Store, MqDecoder<Source>> ps(st, mq, w, h, orient);
+    int bp = q, passtype = q == numbps - 1 ? 2 : 0;
+    for (int p = first_pass_of_plane(numbps, q); p < npasses && bp >= 0; p++) {
         if (passtype == 0) ps.sigprop(bp);
         else if (passtype == 1) ps.refine(bp);
         else ps.cleanup(bp);

@@ -43,6 +43,10 @@ struct HostStore {
 };
 struct VecSink { std::vector<uint8_t> *v; void put(int i, uint8_t b) { if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = b; } };
 struct VecAt { std::vector<uint8_t> *v; uint8_t operator()(int i) const { return i < (int) v->size() ? (*v)[i] : 0; } };
+struct Obs {
+    MqCheckpoint ck[40];
+    template <class Mq> void plane_start(int bp, const Mq &m) { ck[bp] = MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+};
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
 int main(int argc, char **argv)
@@ -56,6 +60,7 @@ int main(int argc, char **argv)
         int maxbits = 7 + rng() % 16;                  // q6 magnitude bits (6 fractional)
         int style = rng() % 4;
         std::vector<int32_t> q((size_t) w * h);
+        std::vector<int32_t> &qvals = q;
         for (int i = 0; i < w * h; i++) {
             int32_t m;
             if (style == 0) m = (int32_t) (rng() % (1u << maxbits));
@@ -111,6 +116,37 @@ int main(int argc, char **argv)
             ds.out = d2.data(); ds.w = w;
             decode_block(ds, BufSrc{bytes.data(), len}, w, h, orient, numbps, np);
             if (d1 != d2) { printf("trial %d DECODE mismatch np %d/%d\n", t, np, opasses); bad++; break; }
+            // ---- resume at the last coded plane from a checkpoint of the FULL-segment decode
+            Obs obs;
+            {
+                std::vector<int32_t> dummy((size_t) w * h, 0);
+                HostStore fs;
+                fs.out = dummy.data(); fs.w = w;
+                decode_block_observed(fs, BufSrc{bytes.data(), r.length}, w, h, orient, numbps, opasses, obs);
+            }
+            int qp = plane_of_pass(numbps, np - 1);
+            while (qp < numbps - 1 && obs.ck[qp].pos + 1 >= len) qp++;
+            std::vector<int32_t> d3((size_t) w * h, 0);
+            HostStore rs;
+            rs.out = d3.data(); rs.w = w;
+            // state at the start of plane q from the quantised values
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    int32_t src6 = qvals[(size_t) y * w + x];
+                    uint32_t a = (uint32_t) (src6 < 0 ? -src6 : src6) >> 6;
+                    if (!a) continue;
+                    int bs = 31 - __builtin_clz(a);
+                    if (bs > qp) {
+                        rs.s[y + 1] |= 1ull << x;
+                        if (src6 < 0) rs.neg[y] |= 1ull << x;
+                        if (bs >= qp + 2) rs.ref[y] |= 1ull << x;
+                        int v = 3 << bs;
+                        for (int pl = bs - 1; pl > qp; pl--) v += ((a >> pl) & 1) ? (1 << pl) : -(1 << pl);
+                        d3[(size_t) y * w + x] = src6 < 0 ? -v : v;
+                    }
+                }
+            decode_resume(rs, BufSrc{bytes.data(), len}, w, h, orient, numbps, np, qp, obs.ck[qp]);
+            if (d1 != d3) { printf("trial %d RESUME mismatch np %d/%d q %d P %d\n", t, np, opasses, qp, numbps); bad++; break; }
         }
     }
     printf("t1_host_check: %d trials, %d failures\n", trials, bad);

@@ -6,12 +6,15 @@
 // a HIP device every entry point fails loudly.
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ebcc_hip.h"
@@ -186,6 +189,19 @@ struct EncodeEnv {
     }
 };
 
+// wall-clock phase report on stderr when EBCC_HIP_PHASE_TIMING is set (diagnostics only)
+struct PhaseTimer {
+    bool on = getenv("EBCC_HIP_PHASE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "ebcc-mi355x phase %-28s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 struct Job {                     // host-side state of one frame being encoded
     bool const_field = false;
     float minv = 0, maxv = 0, target = -1, cr = -1;
@@ -281,6 +297,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     J2kBuffers &jb = b.jb;
     hipStream_t s = b.s;
     std::vector<Job> jobs(n);
+    PhaseTimer pt;
 
     // ---- statistics, scaling, transform, tier-1: once per frame
     launch_input_stats(d_frames, (int) n, n_pix, ctx->rb.fs, s);
@@ -297,6 +314,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         b.jf[f].target = 0;
         ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
     }
+    pt.mark("analysis (dwt, tier-1, ckpt)");
     const bool need_decode = mode != NONE;
     if (need_decode)
         for (size_t f = 0; f < n; f++) {
@@ -326,6 +344,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         }
     }
 
+    pt.mark("first probe");
     if (searching) {
         // ---- rate search #1 (:728)
         for (size_t f = 0; f < n; f++)
@@ -335,6 +354,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs.result; jobs[f].len1 = (size_t) b.jf[f].stream_bytes; }
         }
+        pt.mark("rate search 1");
         b.collect_tails(jobs);                                                                // base layer of search #1
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, ctx->rb.fs, s);               // :730-733
         fetch_frame_states(ctx, n);
@@ -349,6 +369,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             if (!j.skip) { ctx->h_active[f] = 1; any_resid = true; }
         }
         const bool pure_done = q_target == 1.0;                                               // :738
+        pt.mark("tails + residual range");
 
         if (any_resid) {
             // ---- residual layer: SPIHT with a budget of the base layer's size (:744-754)
@@ -433,21 +454,42 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 else j.coeffs_size = (size_t) (j.t_best / 8.);                                // :796
             }
         }
-        // ---- entropy stage of the kept SPIHT prefix on host cores (:811-817)
+        pt.mark("residual layer + truncation");
+        // ---- entropy stage of the kept SPIHT prefix on host cores (:811-817): level-22 zstd is by far the
+        //      longest host step, so the frames are compressed by a small thread pool while the GPU runs
+        //      the fallback search; the results are only needed for the size comparison at :838
         if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+        std::vector<std::vector<uint8_t>> coeff_bytes(n);
         for (size_t f = 0; f < n; f++) {
             Job &j = jobs[f];
             if (j.coeffs_size <= 16) j.coeffs_size = 0;
             if (j.coeffs_size > 0) {
-                std::vector<uint8_t> coeffs(j.coeffs_size);
-                EBCC_HIP_CHECK(hipMemcpyAsync(coeffs.data(), ctx->rb.stream + f * ctx->rb.stream_words, j.coeffs_size,
+                coeff_bytes[f].resize(j.coeffs_size);
+                EBCC_HIP_CHECK(hipMemcpyAsync(coeff_bytes[f].data(), ctx->rb.stream + f * ctx->rb.stream_words, j.coeffs_size,
                                               hipMemcpyDeviceToHost, s));
-                EBCC_HIP_CHECK(hipStreamSynchronize(s));
-                j.zbytes.resize(zstd().bound(j.coeffs_size));
-                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeffs.data(), j.coeffs_size, 22);
-                j.zbytes.resize(z);
             }
         }
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        std::atomic<size_t> next_frame{0};
+        auto zworker = [&]() {
+            for (size_t f = next_frame++; f < n; f = next_frame++) {
+                Job &j = jobs[f];
+                if (j.coeffs_size == 0) continue;
+                j.zbytes.resize(zstd().bound(j.coeffs_size));
+                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_bytes[f].data(), j.coeffs_size, 22);
+                j.zbytes.resize(z);
+            }
+        };
+        std::vector<std::thread> zpool;
+        {
+            unsigned hw = std::thread::hardware_concurrency();
+            unsigned nthreads = hw ? std::min(16u, hw) : 4u;
+            if (const char *e = getenv("EBCC_HOST_THREADS")) nthreads = (unsigned) std::max(1L, strtol(e, nullptr, 10));
+            nthreads = (unsigned) std::min<size_t>(nthreads, n);
+            for (unsigned t = 0; t < nthreads; t++) zpool.emplace_back(zworker);
+        }
+        auto zjoin = [&]() { for (auto &t : zpool) if (t.joinable()) t.join(); };
+        pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)
         if (!pure_done && !env.no_fallback) {
             if (!env.no_consistency) {
@@ -459,6 +501,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             for (size_t f = 0; f < n; f++)
                 if (!jobs[f].const_field) jobs[f].rs.start(jobs[f].cr, jobs[f].q, 1.0);
             b.run_searches(jobs);                                                             // :836
+            zjoin();
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
                 ctx->h_active[f] = 0;
@@ -474,8 +517,10 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
             b.collect_tails(jobs);
         }
+        zjoin();
     }
 
+    pt.mark("fallback search + tails");
     // ---- assemble (:863-907)
     for (size_t f = 0; f < n; f++) {
         Job &j = jobs[f];
@@ -507,6 +552,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         outs[f] = o;
         sizes[f] = total;
     }
+    pt.mark("assemble");
     return 0;
 }
 

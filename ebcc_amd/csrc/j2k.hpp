@@ -89,6 +89,14 @@ struct J2kBuffers {
     unsigned long long *partial_u;// [frames][kPartials]
 };
 
+// Code-blocks per wavefront in the tier-1 kernels.  The coders are serial and branchy: a wave executes the
+// union of its lanes' paths, and with 76 288 code-blocks a full 64-lane mapping leaves ~1 wave per SIMD, so
+// the SIMDs sit idle between dependent instructions.  Fewer code-blocks per wave = more waves in flight and
+// smaller unions.  Defaults measured on MI355X (profiles/): encode/checkpoint 32, probe restart 16, decode 8;
+// EBCC_T1_LPW=<8|16|32|64> overrides all four.
+enum T1Kernel { T1_ENCODE = 0, T1_CHECKPOINT = 1, T1_RESUME = 2, T1_DECODE = 3 };
+int t1_lanes_per_wave(int kernel);
+
 J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks);
 
 // ---- launchers (asynchronous on s) ---------------------------------------------------------------

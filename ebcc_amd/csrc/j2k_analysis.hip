@@ -6,6 +6,7 @@
 // frame with different rates (/root/reference/src/ebcc_codec.c:545-596).  None of it depends on the
 // rate, so here it runs once per frame.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "j2k.hpp"
@@ -24,6 +25,18 @@ static const double kNormsReal[4][10] = {
     {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
     {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
     {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2}};
+
+int t1_lanes_per_wave(int kernel)
+{
+    static int override_v = [] {
+        const char *e = getenv("EBCC_T1_LPW");
+        int x = e ? atoi(e) : 0;
+        return (x == 8 || x == 16 || x == 32 || x == 64) ? x : 0;
+    }();
+    if (override_v) return override_v;
+    static const int defaults[4] = {32, 32, 16, 8};
+    return defaults[kernel & 3];
+}
 
 J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
 {
@@ -418,6 +431,18 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
     if (threadIdx.x == 0) blkmax[gid] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
 }
 
+
+// MQ state table in LDS (see t1_core.hpp ConstTable): filled by the first 47 lanes of the workgroup
+struct LdsTable {
+    const __attribute__((address_space(3))) uint32_t *t;
+    __device__ uint32_t operator()(int i) const { return t[i]; }
+};
+#define EBCC_LDS_MQ_TABLE(name)                                                              \
+    __shared__ uint32_t name##_store[48];                                                    \
+    if (threadIdx.x < 47) name##_store[threadIdx.x] = t1::mq_entry((int) threadIdx.x);       \
+    __syncthreads();                                                                         \
+    LdsTable name{(const __attribute__((address_space(3))) uint32_t *) name##_store}
+
 // ================================================================================================
 // tier-1 encoder: one code-block per lane (t1_core.hpp)
 // ================================================================================================
@@ -446,9 +471,11 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
                                                    const unsigned long long *SGN, const int *blkmax, int *numbps,
                                                    int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes,
                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
-                                                   J2kFrame *jf, int total)
+                                                   J2kFrame *jf, int total, int lpw)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    EBCC_LDS_MQ_TABLE(tab);
+    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
+    const int gid = blockIdx.x * lpw + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     DevStore st{T1S + grp * kT1StateWords * 64 + gl, BP + grp * kJ2kMaxPlanes * 64 * 64 + gl, SGN + grp * 64 * 64 + gl};
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
     t1::EncodeResult r = t1::encode_block(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
-                                          blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses);
+                                          blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, tab);
     totalpasses[gid] = r.totalpasses;
     cblk_len[gid] = r.length;
 }
@@ -540,7 +567,7 @@ struct CkStore {
     __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
     __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
     __device__ void set_sig(int, int, int, int) {}
-    __device__ void refine(int, int, int, int) {}
+    __device__ void refine(int, int, int, int, int) {}
 };
 struct CkObserver {
     t1::MqCheckpoint *ck;
@@ -548,16 +575,26 @@ struct CkObserver {
     __device__ void plane_start(int bp, const Mq &m) { ck[bp] = t1::MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
 };
 struct CkSrc {
+    // byte source with an 8-byte register window: one aligned load per 8 bytes instead of two byte loads per BYTEIN
     const uint8_t *p; int n;
-    __device__ uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; }
+    unsigned long long win = 0; int base = -16;
+    __device__ uint32_t get(int i)
+    {
+        if (i >= n) return 0xFFu;
+        const int b = i & ~7;
+        if (b != base) { win = *reinterpret_cast<const unsigned long long *>(p + b); base = b; }
+        return (uint32_t) (win >> (8 * (i & 7))) & 0xFFu;
+    }
 };
 
 __global__ __launch_bounds__(64) void k_t1_checkpoints(unsigned long long *T1S, const uint8_t *cblk_bytes, const int *numbps,
                                                         const int *totalpasses, const int *cblk_len, t1::MqCheckpoint *ckpt,
                                                         const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
-                                                        int total)
+                                                        int total, int lpw)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    EBCC_LDS_MQ_TABLE(tab);
+    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
+    const int gid = blockIdx.x * lpw + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -568,7 +605,7 @@ __global__ __launch_bounds__(64) void k_t1_checkpoints(unsigned long long *T1S, 
     CkStore st{T1S + (size_t) (gid >> 6) * kT1StateWords * 64 + (gid & 63)};
     CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPlanes};
     t1::decode_block_observed(st, CkSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, cblk_len[gid]}, blk.w, blk.h,
-                              geom->bands[blk.band].orient, P, np, obs);
+                              geom->bands[blk.band].orient, P, np, obs, tab);
 }
 
 }  // namespace
@@ -626,16 +663,20 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
                        jb.d_geom, jb.d_blocks, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_encode", s);
-    hipLaunchKernelGGL(k_t1_encode, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.blkmax, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.d_geom, jb.d_blocks, fs, jb.jf, total);
+    int lpw = t1_lanes_per_wave(T1_ENCODE);
+    unsigned t1_grid = (unsigned) ceil_div(total, lpw);
+    hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.blkmax, jb.numbps,
+                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.d_geom, jb.d_blocks, fs, jb.jf, total, lpw);
     timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.T1S, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
     // decoder checkpoints for the rate probes (the encoder's SPS masks in T1S are no longer needed)
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_checkpoints", s);
-    hipLaunchKernelGGL(k_t1_checkpoints, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, (t1::MqCheckpoint *) jb.ckpt, jb.d_geom, jb.d_blocks, fs, total);
+    lpw = t1_lanes_per_wave(T1_CHECKPOINT);
+    t1_grid = (unsigned) ceil_div(total, lpw);
+    hipLaunchKernelGGL(k_t1_checkpoints, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.numbps,
+                       jb.totalpasses, jb.cblk_len, (t1::MqCheckpoint *) jb.ckpt, jb.d_geom, jb.d_blocks, fs, total, lpw);
     timing_end("t1_checkpoints", s);
 }
 

@@ -8,6 +8,7 @@
 // encoder's code-block slots (no codestream is assembled or parsed for a probe).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "j2k.hpp"
 #include "t1_core.hpp"
@@ -609,6 +610,18 @@ __global__ void k_finish_reduce(const double *partial, const unsigned long long 
     jf[f].nbad = b;
 }
 
+
+// MQ state table in LDS (see t1_core.hpp ConstTable): filled by the first 47 lanes of the workgroup
+struct LdsTable {
+    const __attribute__((address_space(3))) uint32_t *t;
+    __device__ uint32_t operator()(int i) const { return t[i]; }
+};
+#define EBCC_LDS_MQ_TABLE(name)                                                              \
+    __shared__ uint32_t name##_store[48];                                                    \
+    if (threadIdx.x < 47) name##_store[threadIdx.x] = t1::mq_entry((int) threadIdx.x);       \
+    __syncthreads();                                                                         \
+    LdsTable name{(const __attribute__((address_space(3))) uint32_t *) name##_store}
+
 // ================================================================================================
 // true decode: tier-1 MQ decoding, one code-block per lane, values scattered into V (half units)
 // ================================================================================================
@@ -625,16 +638,29 @@ struct DecStore {
         int one = 1 << (plane + 1), val = one | (one >> 1);
         v[(size_t) y * W + x] = neg ? -val : val;
     }
-    __device__ void refine(int x, int y, int bit, int plane)
+    __device__ void refine(int x, int y, int bit, int plane, int neg)
     {
-        int half = 1 << plane;
-        int32_t &d = v[(size_t) y * W + x];
-        d += (bit ^ (d < 0)) ? half : -half;
+        // the sign is known from the NEG row mask, so the update is a fire-and-forget atomic add (no load stall)
+        const int half = 1 << plane;
+        atomicAdd(&v[(size_t) y * W + x], (bit ^ neg) ? half : -half);
     }
 };
 struct DecSrc {
+    // byte source with an 8-byte register window (slots and stream slots are 8-byte aligned and padded)
     const uint8_t *p; int n;
-    __device__ uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; }
+    unsigned long long win = 0; int base = -16;
+    __device__ uint32_t get(int i)
+    {
+        if (i >= n) return 0xFFu;
+        const int b = i & ~7;
+        if (b != base) {
+            const uintptr_t a = (uintptr_t) (p + b);
+            if ((a & 7) == 0) win = *reinterpret_cast<const unsigned long long *>(p + b);
+            else { win = 0; for (int k = 0; k < 8; k++) win |= (unsigned long long) p[b + k] << (8 * k); }
+            base = b;
+        }
+        return (uint32_t) (win >> (8 * (i & 7))) & 0xFFu;
+    }
 };
 
 // PROBE = true: decode the first npass[gid] passes straight from the encoder's code-block slots (the rate
@@ -646,9 +672,11 @@ template <bool PROBE>
 __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const uint8_t *bytes, size_t stream_cap,
                                                    const int *dec_table, const int *numbps, const int *npass,
                                                    const int *rates, int32_t *V, const J2kGeom *geom,
-                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
+                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total, int lpw)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    EBCC_LDS_MQ_TABLE(tab);
+    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
+    const int gid = blockIdx.x * lpw + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -669,7 +697,7 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
     const size_t grp = (size_t) (gid >> 6);
     DecStore st{T1S + grp * kT1StateWords * 64 + (gid & 63),
                 V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
-    t1::decode_block(st, DecSrc{src, len}, blk.w, blk.h, geom->bands[blk.band].orient, P, np);
+    t1::decode_block(st, DecSrc{src, len}, blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
 }
 
 
@@ -731,15 +759,19 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
                                                    const unsigned long long *SGN, const uint8_t *cblk_bytes,
                                                    const int *numbps, const int *npass, const int *rates, const int *qplane,
                                                    const t1::MqCheckpoint *ckpt, int32_t *V, const J2kGeom *geom,
-                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
+                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total,
+                                                   int dbg_res, int lpw)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    EBCC_LDS_MQ_TABLE(tab);
+    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
+    const int gid = blockIdx.x * lpw + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const int q = qplane[gid];
     if (q < 0) return;
+    if (dbg_res >= 0 && geom->bands[blocks[bi].band].res != dbg_res) return;
     const int np = npass[gid], P = numbps[gid];
     const int len = rates[(size_t) gid * kJ2kMaxPasses + np - 1];
     const J2kBlock blk = blocks[bi];
@@ -759,7 +791,7 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
         st.VIS(y) = 0ull;
     }
     t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
-                      np, q, ckpt[(size_t) gid * kJ2kMaxPlanes + q]);
+                      np, q, ckpt[(size_t) gid * kJ2kMaxPlanes + q], tab);
 }
 
 __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, const std::uint16_t *__restrict__ blkmap,
@@ -823,8 +855,10 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
     hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.d_blkmap, jb.V, jb.d_geom, jb.fs,
                        d_active);
     timing_begin("t1_probe_decode", s);
-    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.SUF, jb.SGN, jb.cblk_bytes, jb.numbps,
-                       jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
+    const int lpw = t1_lanes_per_wave(T1_RESUME);
+    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.SUF, jb.SGN, jb.cblk_bytes, jb.numbps,
+                       jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total,
+                       getenv("EBCC_DEBUG_RESUME_RES") ? atoi(getenv("EBCC_DEBUG_RESUME_RES")) : -1, lpw);
     timing_end("t1_probe_decode", s);
     decode_tail(data, jb, n_frames, d_active, true, s);
 }
@@ -837,9 +871,10 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
     timing_begin("t1_decode", s);
-    hipLaunchKernelGGL(k_t1_decode<false>, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
+    const int lpw = t1_lanes_per_wave(T1_DECODE);
+    hipLaunchKernelGGL(k_t1_decode<false>, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
                        jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, (const int *) nullptr,
-                       total);
+                       total, lpw);
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);
 }

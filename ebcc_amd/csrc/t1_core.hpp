@@ -51,6 +51,13 @@ T1_HD uint32_t mq_entry(int i)
     return T[i];
 }
 
+// Where the state table lives: the constexpr array above ends up in constant memory, and a per-lane dynamic
+// index into it is a global load on the critical path of EVERY symbol.  Device kernels copy the 47 words to
+// LDS once and pass an LdsTable; the host build uses ConstTable.
+struct ConstTable {
+    T1_HD uint32_t operator()(int i) const { return mq_entry(i); }
+};
+
 // Context states: 19 contexts x (6-bit state index + mps) packed in two u64 words would need dynamic
 // bit-field updates; a small per-lane byte array in registers/scratch is simpler: state | mps << 7.
 struct Contexts {
@@ -81,7 +88,7 @@ struct Contexts {
 // ------------------------------------------------------------------------------------------------
 // MQ encoder (C.2).  Sink: void put(int index, uint8_t byte)
 // ------------------------------------------------------------------------------------------------
-template <class Sink>
+template <class Sink, class Table = ConstTable>
 struct MqEncoder {
     uint32_t a, c;
     int ct;
@@ -89,6 +96,7 @@ struct MqEncoder {
     uint32_t cur;     // its value; index -1 is the non-FF byte that precedes the segment
     Contexts cx;
     Sink sink;
+    Table tab;
 
     T1_HD void init()
     {
@@ -122,7 +130,7 @@ struct MqEncoder {
     T1_HD void encode(int ctx, int d)
     {
         uint32_t st = cx.get(ctx);
-        uint32_t e = mq_entry(st & 0x3F);
+        uint32_t e = tab((int) (st & 0x3F));
         uint32_t qe = e & 0xFFFF;
         int mps = st >> 6;
         a -= qe;
@@ -157,12 +165,13 @@ struct MqEncoder {
 // ------------------------------------------------------------------------------------------------
 // MQ decoder (C.3).  Source: uint32_t get(int index) returning 0xFF past the end
 // ------------------------------------------------------------------------------------------------
-template <class Source>
+template <class Source, class Table = ConstTable>
 struct MqDecoder {
     uint32_t a, c;
     int ct, pos;
     Contexts cx;
     Source src;
+    Table tab;
 
     T1_HD void bytein()
     {
@@ -192,7 +201,7 @@ struct MqDecoder {
     T1_HD int decode(int ctx)
     {
         uint32_t st = cx.get(ctx);
-        uint32_t e = mq_entry(st & 0x3F);
+        uint32_t e = tab((int) (st & 0x3F));
         uint32_t qe = e & 0xFFFF;
         int mps = st >> 6, d;
         a -= qe;
@@ -281,7 +290,7 @@ T1_HD int ctz64(u64 v)
 //   u64 &NEG(int y), &VIS(int y), &REF(int y)   y in [0, 64)
 // Encoder store additionally:  u64 BP(int plane, int y) (bit-plane masks), u64 SGN(int y) (sign of every
 //   coefficient), u64 &SPS(int y) (output: became significant in a significance-propagation pass)
-// Decoder store additionally:  void set_sig(int x, int y, int neg, int plane), void refine(int x, int y, int bit, int plane)
+// Decoder store additionally:  void set_sig(int x, int y, int neg, int plane), void refine(int x, int y, int bit, int plane, int neg)
 // ------------------------------------------------------------------------------------------------
 
 // One stripe worth of state held in locals (fully unrolled accesses keep it in registers).
@@ -290,6 +299,8 @@ struct Stripe {
     u64 neg[6];      // signs of those rows
     u64 vis[4];
     u64 valid[4];
+    u64 sgn[4];      // encoder: sign of every coefficient of the stripe's rows
+    u64 sps[4];      // encoder: became significant in a propagation pass (accumulated, stored with the stripe)
 };
 
 template <bool ENC, class Store, class Coder>
@@ -313,6 +324,7 @@ struct Passes {
         for (int r = 0; r < 4; r++) {
             sp.vis[r] = st.VIS(y0 + r);
             sp.valid[r] = (y0 + r < h) ? wmask : 0ull;
+            if constexpr (ENC) { sp.sgn[r] = st.SGN(y0 + r); sp.sps[r] = 0; }
         }
     }
     T1_HD void store(const Stripe &sp, int y0)
@@ -322,6 +334,7 @@ struct Passes {
             st.S(y0 + r) = sp.s[r + 1];
             st.NEG(y0 + r) = sp.neg[r + 1];
             st.VIS(y0 + r) = sp.vis[r];
+            if constexpr (ENC) { if (sp.sps[r]) st.SPS(y0 + r) |= sp.sps[r]; }
         }
     }
 
@@ -334,14 +347,14 @@ struct Passes {
                         tri(sp.neg[R + 2], x), xb);
         int neg;
         if constexpr (ENC) {
-            neg = (int) ((st.SGN(y0 + R) >> x) & 1);
+            neg = (int) ((sp.sgn[R] >> x) & 1);
             mq.encode(cx, neg ^ xb);
         } else {
             neg = mq.decode(cx) ^ xb;
         }
         sp.s[R + 1] |= 1ull << x;
         if (neg) sp.neg[R + 1] |= 1ull << x;
-        if constexpr (ENC) { if (from_sigprop) st.SPS(y0 + R) |= 1ull << x; }
+        if constexpr (ENC) { if (from_sigprop) sp.sps[R] |= 1ull << x; }
         else st.set_sig(x, y0 + R, neg, plane);
     }
 
@@ -402,7 +415,7 @@ struct Passes {
         }
         int v;
         if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
-        else { v = mq.decode(cx); st.refine(x, y0 + R, v, plane); }
+        else { v = mq.decode(cx); st.refine(x, y0 + R, v, plane, (int) ((sp.neg[R + 1] >> x) & 1)); }
         ref |= bit;
     }
 
@@ -505,12 +518,13 @@ struct EncodeResult {
 // Encodes every pass of a code-block with `numbps` magnitude bit-planes (numbps >= 1).
 // rates[p] follow OpenJPEG: bytes completed + 3 for unterminated passes, clipped to be non-decreasing,
 // never ending on 0xFF (needs read access to the bytes: ByteAt(int) -> uint8_t).
-template <class Store, class Sink, class ByteAt>
-T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates)
+template <class Store, class Sink, class ByteAt, class Table = ConstTable>
+T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates,
+                                Table tab = Table())
 {
-    MqEncoder<Sink> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink};
+    MqEncoder<Sink, Table> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink, tab};
     mq.init();
-    Passes<true, Store, MqEncoder<Sink>> ps(st, mq, w, h, orient);
+    Passes<true, Store, MqEncoder<Sink, Table>> ps(st, mq, w, h, orient);
     int passno = 0, passtype = 2;
     for (int bp = numbps - 1; bp >= 0; passno++) {
         if (passtype == 0) ps.sigprop(bp);
@@ -549,12 +563,13 @@ struct NoObserver {
 T1_HD int first_pass_of_plane(int P, int bp) { return bp == P - 1 ? 0 : 3 * (P - 1 - bp) - 2; }
 T1_HD int plane_of_pass(int P, int i) { return i == 0 ? P - 1 : P - 2 - (i - 1) / 3; }
 
-template <class Store, class Source, class Observer>
-T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Observer &obs)
+template <class Store, class Source, class Observer, class Table = ConstTable>
+T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Observer &obs,
+                                 Table tab = Table())
 {
-    MqDecoder<Source> mq{0, 0, 0, 0, {0, 0, 0}, src};
+    MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
     mq.init();
-    Passes<false, Store, MqDecoder<Source>> ps(st, mq, w, h, orient);
+    Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
     int passtype = 2, bp = numbps - 1;
     for (int p = 0; p < npasses && bp >= 0; p++) {
         if (passtype == 0 || p == 0) obs.plane_start(bp, mq);
@@ -565,11 +580,11 @@ T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient
     }
 }
 
-template <class Store, class Source>
-T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses)
+template <class Store, class Source, class Table = ConstTable>
+T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Table tab = Table())
 {
     NoObserver obs;
-    decode_block_observed(st, src, w, h, orient, numbps, npasses, obs);
+    decode_block_observed(st, src, w, h, orient, numbps, npasses, obs, tab);
 }
 
 // Decode passes [first_pass_of_plane(q), npasses) only.  The caller has put the store into the state the
@@ -577,14 +592,14 @@ T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int num
 // q, VIS clear); `ck` holds the MQ registers there (ignored for q == numbps-1, where decoding starts afresh).
 // Valid whenever the checkpoint was taken with no byte at or beyond the (truncated) segment length consumed:
 // ck.pos + 1 < length of src.
-template <class Store, class Source>
+template <class Store, class Source, class Table = ConstTable>
 T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int q,
-                         const MqCheckpoint &ck)
+                         const MqCheckpoint &ck, Table tab = Table())
 {
-    MqDecoder<Source> mq{0, 0, 0, 0, {0, 0, 0}, src};
+    MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
     if (q == numbps - 1) mq.init();
     else { mq.a = ck.a; mq.c = ck.c; mq.ct = ck.ct; mq.pos = ck.pos; mq.cx.w0 = ck.w0; mq.cx.w1 = ck.w1; mq.cx.w2 = ck.w2; }
-    Passes<false, Store, MqDecoder<Source>> ps(st, mq, w, h, orient);
+    Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
     int bp = q, passtype = q == numbps - 1 ? 2 : 0;
     for (int p = first_pass_of_plane(numbps, q); p < npasses && bp >= 0; p++) {
         if (passtype == 0) ps.sigprop(bp);

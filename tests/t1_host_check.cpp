@@ -34,11 +34,10 @@ struct HostStore {
         int one = 1 << (plane + 1), v = one | (one >> 1);
         out[y * w + x] = negv ? -v : v;
     }
-    void refine(int x, int y, int bit, int plane)
+    void refine(int x, int y, int bit, int plane, int negv)
     {
         int half = 1 << plane;
-        int32_t &d = out[y * w + x];
-        d += (bit ^ (d < 0)) ? half : -half;
+        out[y * w + x] += (bit ^ negv) ? half : -half;
     }
 };
 struct VecSink { std::vector<uint8_t> *v; void put(int i, uint8_t b) { if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = b; } };

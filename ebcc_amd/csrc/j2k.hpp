@@ -68,8 +68,10 @@ struct J2kBuffers {
     unsigned long long *BP;       // [groups][planes][64][64] bit-plane row masks, lane-interleaved
     unsigned long long *SGN;      // [groups][64][64] sign row masks
     unsigned long long *SUF;      // [groups][planes+2][64][64] suffix-OR of BP over planes >= p (significance above a plane)
-    void *ckpt;                   // [frames*nblocks][planes] MQ-decoder checkpoints at every bit-plane start
-    int *qplane;                  // [frames*nblocks] bit-plane at which the current probe's decode restarts (-1: nothing)
+    unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
+    unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
+    void *ckpt;                   // [frames*nblocks][passes] MQ-decoder checkpoints at every coding-pass start
+    int *qplane;                  // [frames*nblocks] coding pass at which the current probe's decode restarts (-1: nothing)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
     int *blkmax;                  // [frames*nblocks] max |q6|
     int *numbps;                  // [frames*nblocks]

@@ -450,11 +450,12 @@ struct DevStore {
     unsigned long long *st;       // group base of the state words, lane offset already applied
     const unsigned long long *bp; // group base of the bit-plane masks, lane offset applied
     const unsigned long long *sg;
+    unsigned long long *sps;      // group base of the propagation-significance masks, lane offset applied
     __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
     __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
     __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
     __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
-    __device__ unsigned long long &SPS(int y) { return st[(size_t) (258 + y) * 64]; }
+    __device__ unsigned long long &SPS(int y) { return sps[(size_t) y * 64]; }
     __device__ unsigned long long SGN(int y) const { return y < 64 ? sg[(size_t) y * 64] : 0ull; }
     __device__ unsigned long long BP(int plane, int y) const { return y < 64 ? bp[((size_t) plane * 64 + y) * 64] : 0ull; }
 };
@@ -468,7 +469,7 @@ struct DevAt {
 };
 
 __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const unsigned long long *BP,
-                                                   const unsigned long long *SGN, const int *blkmax, int *numbps,
+                                                   const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax, int *numbps,
                                                    int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes,
                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
                                                    J2kFrame *jf, int total, int lpw)
@@ -488,7 +489,8 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     if (P <= 0) { totalpasses[gid] = 0; cblk_len[gid] = 0; return; }
     const size_t grp = (size_t) (gid >> 6);
     const int gl = gid & 63;
-    DevStore st{T1S + grp * kT1StateWords * 64 + gl, BP + grp * kJ2kMaxPlanes * 64 * 64 + gl, SGN + grp * 64 * 64 + gl};
+    DevStore st{T1S + grp * kT1StateWords * 64 + gl, BP + grp * kJ2kMaxPlanes * 64 * 64 + gl, SGN + grp * 64 * 64 + gl,
+                SPS + grp * 64 * 64 + gl};
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
     t1::EncodeResult r = t1::encode_block(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
                                           blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, tab);
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
 // distortion tables: per-pass nmsedec sums are order-independent integers, so they are accumulated in
 // parallel from (q6, msb, "significant in a propagation pass") instead of inside the serial coder
 // ================================================================================================
-__global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ Q6, const unsigned long long *__restrict__ T1S,
+__global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ Q6, const unsigned long long *__restrict__ SPS,
                                                      const int *__restrict__ numbps, const int *__restrict__ totalpasses,
                                                      double *__restrict__ disto, const short *__restrict__ luts,
                                                      const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs)
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
     const int32_t *q = Q6 + (size_t) frame * W * geom->H;
     const size_t grp = (size_t) (gid >> 6);
     const int gl = gid & 63;
-    const unsigned long long *sps = T1S + (grp * kT1StateWords + 258) * 64 + gl;
+    const unsigned long long *sps = SPS + grp * 64 * 64 + gl;
     for (int t = threadIdx.x; t < blk.w * blk.h; t += 256) {
         int y = t / blk.w, x = t - y * blk.w;
         int q6 = q[(size_t) (blk.y + y) * W + blk.x + x];
@@ -557,7 +559,8 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
 
 // ================================================================================================
 // MQ-decoder checkpoints: decode every code-block's complete segment once and save the decoder registers at
-// the start of every bit-plane.  A rate probe then restarts at the last plane it keeps (j2k_rate.hip)
+// the start of every coding pass (plus the visited masks after every propagation pass).  A rate probe then
+// restarts at the last pass it keeps (j2k_rate.hip)
 // instead of decoding all kept passes.
 // ================================================================================================
 struct CkStore {
@@ -570,9 +573,15 @@ struct CkStore {
     __device__ void refine(int, int, int, int, int) {}
 };
 struct CkObserver {
-    t1::MqCheckpoint *ck;
+    t1::MqCheckpoint *ck;          // [passes] of this code-block
+    unsigned long long *visp;      // group base of the per-plane visited masks, lane offset applied
     template <class Mq>
-    __device__ void plane_start(int bp, const Mq &m) { ck[bp] = t1::MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+    __device__ void pass_start(int p, const Mq &m) { ck[p] = t1::MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+    template <class Store>
+    __device__ void sigprop_done(int bp, Store &st)
+    {
+        for (int y = 0; y < 64; y++) visp[((size_t) bp * 64 + y) * 64] = st.VIS(y);
+    }
 };
 struct CkSrc {
     // byte source with an 8-byte register window: one aligned load per 8 bytes instead of two byte loads per BYTEIN
@@ -589,7 +598,7 @@ struct CkSrc {
 
 __global__ __launch_bounds__(64) void k_t1_checkpoints(unsigned long long *T1S, const uint8_t *cblk_bytes, const int *numbps,
                                                         const int *totalpasses, const int *cblk_len, t1::MqCheckpoint *ckpt,
-                                                        const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
+                                                        unsigned long long *VISP, const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
                                                         int total, int lpw)
 {
     EBCC_LDS_MQ_TABLE(tab);
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(64) void k_t1_checkpoints(unsigned long long *T1S, 
     if (np <= 0 || P <= 0) return;
     const J2kBlock blk = blocks[bi];
     CkStore st{T1S + (size_t) (gid >> 6) * kT1StateWords * 64 + (gid & 63)};
-    CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPlanes};
+    CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPasses, VISP + (size_t) (gid >> 6) * kJ2kMaxPlanes * 64 * 64 + (gid & 63)};
     t1::decode_block_observed(st, CkSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, cblk_len[gid]}, blk.w, blk.h,
                               geom->bands[blk.band].orient, P, np, obs, tab);
 }
@@ -662,13 +671,14 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     hipLaunchKernelGGL(k_quantize, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
                        jb.d_geom, jb.d_blocks, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.SPS, 0, groups * 64 * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_encode", s);
     int lpw = t1_lanes_per_wave(T1_ENCODE);
     unsigned t1_grid = (unsigned) ceil_div(total, lpw);
-    hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.blkmax, jb.numbps,
+    hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
                        jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.d_geom, jb.d_blocks, fs, jb.jf, total, lpw);
     timing_end("t1_encode", s);
-    hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.T1S, jb.numbps, jb.totalpasses,
+    hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
     // decoder checkpoints for the rate probes (the encoder's SPS masks in T1S are no longer needed)
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
@@ -676,7 +686,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     lpw = t1_lanes_per_wave(T1_CHECKPOINT);
     t1_grid = (unsigned) ceil_div(total, lpw);
     hipLaunchKernelGGL(k_t1_checkpoints, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, (t1::MqCheckpoint *) jb.ckpt, jb.d_geom, jb.d_blocks, fs, total, lpw);
+                       jb.totalpasses, jb.cblk_len, (t1::MqCheckpoint *) jb.ckpt, jb.VISP, jb.d_geom, jb.d_blocks, fs, total, lpw);
     timing_end("t1_checkpoints", s);
 }
 

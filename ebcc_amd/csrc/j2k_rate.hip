@@ -702,16 +702,17 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
 
 
 // ================================================================================================
-// rate-probe decode, restarted at the last bit-plane the layer keeps
-//   k_probe_plan : per code-block, the restart plane q (last coded plane, or an earlier one if the checkpoint
-//                  there was taken after the decoder had already consumed a byte at/after the truncation point)
-//   k_probe_init : per sample, the value the decoder holds at the start of plane q (all planes above q are
-//                  complete, so it follows from the quantised coefficient) - replaces zero-filling V
-//   k_t1_resume  : one code-block per lane: state masks from the suffix-OR bit-plane masks, MQ registers from
-//                  the checkpoint, then the (at most three) passes of the remaining planes on the truncated bytes
+// rate-probe decode, restarted at the last coding pass the layer keeps
+//   k_probe_plan : per code-block, the restart pass r (last kept pass, or an earlier one if the checkpoint there
+//                  was taken after the decoder had already consumed a byte at/after the truncation point)
+//   k_probe_init : per sample, the value the decoder holds at the start of pass r (passes < r are complete, so
+//                  it follows from the quantised coefficient and the encoder's pass bookkeeping) - replaces
+//                  zero-filling V
+//   k_t1_resume  : one code-block per lane: state masks from the bit-plane / suffix-OR / visited masks, MQ
+//                  registers from the checkpoint, then only passes r .. n-1 on the truncated bytes
 // ================================================================================================
 __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restrict__ npass, const int *__restrict__ rates,
-                             const t1::MqCheckpoint *__restrict__ ckpt, int *__restrict__ qplane, const J2kGeom *geom,
+                             const t1::MqCheckpoint *__restrict__ ckpt, int *__restrict__ rpass, const J2kGeom *geom,
                              const FrameState *fs, const int *active, int total)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -719,35 +720,47 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
     const int frame = gid / geom->nblocks;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const int n = npass[gid], P = numbps[gid];
-    int q = -1;
+    int r = -1;
     if (n > 0 && P > 0) {
         const int len = rates[(size_t) gid * kJ2kMaxPasses + n - 1];
-        q = t1::plane_of_pass(P, n - 1);
-        while (q < P - 1 && ckpt[(size_t) gid * kJ2kMaxPlanes + q].pos + 1 >= len) q++;
+        r = n - 1;
+        while (r > 0 && ckpt[(size_t) gid * kJ2kMaxPasses + r].pos + 1 >= len) r--;
     }
-    qplane[gid] = q;
+    rpass[gid] = r;
 }
 
-__global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ Q6, const int *__restrict__ qplane,
+__global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ Q6, const int *__restrict__ rpass,
+                                                     const int *__restrict__ numbps, const unsigned long long *__restrict__ SPS,
                                                      const std::uint16_t *__restrict__ blkmap, int32_t *__restrict__ V,
-                                                     const J2kGeom *geom, const FrameState *fs, const int *active)
+                                                     const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
+                                                     const int *active)
 {
     const int frame = blockIdx.y;
     if ((active && !active[frame]) || fs[frame].const_field) return;
-    const size_t n_pix = (size_t) geom->W * geom->H;
+    const int W = geom->W;
+    const size_t n_pix = (size_t) W * geom->H;
     const int32_t *q = Q6 + (size_t) frame * n_pix;
     int32_t *v = V + (size_t) frame * n_pix;
     const int gid0 = frame * geom->nblocks;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
-        const int qp = qplane[gid0 + blkmap[i]];
+        const int bi = blkmap[i], gid = gid0 + bi;
+        const int r = rpass[gid];
         const int q6 = q[i];
         const unsigned int a = (unsigned int) (q6 < 0 ? -q6 : q6) >> 6;
         int out = 0;
-        if (qp >= 0 && a) {
+        if (r > 0 && a) {
+            const int P = numbps[gid];
             const int bs = 31 - __clz(a);
-            if (bs > qp) {
+            const J2kBlock blk = blocks[bi];
+            const int y = (int) (i / W), x = (int) (i - (size_t) y * W);
+            const unsigned long long sps = SPS[(((size_t) (gid >> 6)) * 64 + (y - blk.y)) * 64 + (gid & 63)];
+            const int ps = bs == P - 1 ? 0 : 3 * (P - 1 - bs) - (((sps >> (x - blk.x)) & 1ull) ? 2 : 0);
+            if (ps < r) {
                 out = 3 << bs;                                          // 1.5 * 2^bs in half units, then the refinements
-                for (int pl = bs - 1; pl > qp; pl--) out += ((a >> pl) & 1u) ? (1 << pl) : -(1 << pl);
+                for (int pl = bs - 1; pl >= 0; pl--) {
+                    if (3 * (P - 1 - pl) - 1 >= r) break;
+                    out += ((a >> pl) & 1u) ? (1 << pl) : -(1 << pl);
+                }
                 if (q6 < 0) out = -out;
             }
         }
@@ -755,12 +768,13 @@ __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const unsigned long long *SUF,
-                                                   const unsigned long long *SGN, const uint8_t *cblk_bytes,
-                                                   const int *numbps, const int *npass, const int *rates, const int *qplane,
-                                                   const t1::MqCheckpoint *ckpt, int32_t *V, const J2kGeom *geom,
-                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total,
-                                                   int dbg_res, int lpw)
+__global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const unsigned long long *BP,
+                                                   const unsigned long long *SUF, const unsigned long long *SGN,
+                                                   const unsigned long long *SPS, const unsigned long long *VISP,
+                                                   const uint8_t *cblk_bytes, const int *numbps, const int *npass,
+                                                   const int *rates, const int *rpass, const t1::MqCheckpoint *ckpt, int32_t *V,
+                                                   const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
+                                                   const int *active, int total, int lpw)
 {
     EBCC_LDS_MQ_TABLE(tab);
     if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
@@ -769,9 +783,8 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
     if ((active && !active[frame]) || fs[frame].const_field) return;
-    const int q = qplane[gid];
-    if (q < 0) return;
-    if (dbg_res >= 0 && geom->bands[blocks[bi].band].res != dbg_res) return;
+    const int r = rpass[gid];
+    if (r < 0) return;
     const int np = npass[gid], P = numbps[gid];
     const int len = rates[(size_t) gid * kJ2kMaxPasses + np - 1];
     const J2kBlock blk = blocks[bi];
@@ -779,19 +792,29 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     const int gl = gid & 63;
     DecStore st{T1S + grp * kT1StateWords * 64 + gl, V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x,
                 geom->W};
-    // state at the start of plane q: significant = some bit above q, refined = some bit at least two planes above q
-    const unsigned long long *suf1 = SUF + ((grp * (kJ2kMaxPlanes + 2) + q + 1) * 64) * 64 + gl;
-    const unsigned long long *suf2 = SUF + ((grp * (kJ2kMaxPlanes + 2) + q + 2) * 64) * 64 + gl;
+    // decoder state at the start of pass r = (plane p, type t); see DESIGN.md section 3
+    const int p = t1::plane_of_pass(P, r), t = r == 0 ? 0 : t1::type_of_pass(r);
+    const unsigned long long *suf1 = SUF + ((grp * (kJ2kMaxPlanes + 2) + p + 1) * 64) * 64 + gl;
+    const unsigned long long *suf2 = SUF + ((grp * (kJ2kMaxPlanes + 2) + p + 2) * 64) * 64 + gl;
+    const unsigned long long *bpp = BP + ((grp * kJ2kMaxPlanes + p) * 64) * 64 + gl;
+    const unsigned long long *visp = VISP + ((grp * kJ2kMaxPlanes + p) * 64) * 64 + gl;
     const unsigned long long *sg = SGN + grp * 64 * 64 + gl;
+    const unsigned long long *sps = SPS + grp * 64 * 64 + gl;
     for (int y = 0; y < 64; y++) {
-        const unsigned long long s1 = y < blk.h ? suf1[(size_t) y * 64] : 0ull;
-        st.S(y) = s1;
-        st.NEG(y) = y < blk.h ? (sg[(size_t) y * 64] & s1) : 0ull;
-        st.REF(y) = y < blk.h ? suf2[(size_t) y * 64] : 0ull;
-        st.VIS(y) = 0ull;
+        unsigned long long S = 0, R = 0, Vv = 0;
+        if (y < blk.h && r > 0) {
+            const unsigned long long s1 = suf1[(size_t) y * 64];
+            S = s1;
+            if (t >= 1) { S |= sps[(size_t) y * 64] & bpp[(size_t) y * 64] & ~s1; Vv = visp[(size_t) y * 64]; }
+            R = t == 2 ? s1 : suf2[(size_t) y * 64];
+        }
+        st.S(y) = S;
+        st.NEG(y) = S ? (sg[(size_t) y * 64] & S) : 0ull;
+        st.REF(y) = R;
+        st.VIS(y) = Vv;
     }
     t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
-                      np, q, ckpt[(size_t) gid * kJ2kMaxPlanes + q], tab);
+                      np, r, ckpt[(size_t) gid * kJ2kMaxPasses + r], tab);
 }
 
 __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, const std::uint16_t *__restrict__ blkmap,
@@ -848,17 +871,16 @@ static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, c
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
     const int total = n_frames * jb.geom.nblocks;
-    const size_t groups = ((size_t) total + 63) / 64;
     const t1::MqCheckpoint *ck = (const t1::MqCheckpoint *) jb.ckpt;
     hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
                        jb.d_geom, jb.fs, d_active, total);
-    hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.d_blkmap, jb.V, jb.d_geom, jb.fs,
-                       d_active);
+    hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.numbps, jb.SPS, jb.d_blkmap, jb.V,
+                       jb.d_geom, jb.d_blocks, jb.fs, d_active);
     timing_begin("t1_probe_decode", s);
     const int lpw = t1_lanes_per_wave(T1_RESUME);
-    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.SUF, jb.SGN, jb.cblk_bytes, jb.numbps,
-                       jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs, d_active, total,
-                       getenv("EBCC_DEBUG_RESUME_RES") ? atoi(getenv("EBCC_DEBUG_RESUME_RES")) : -1, lpw);
+    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.BP, jb.SUF, jb.SGN, jb.SPS,
+                       jb.VISP, jb.cblk_bytes, jb.numbps, jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs,
+                       d_active, total, lpw);
     timing_end("t1_probe_decode", s);
     decode_tail(data, jb, n_frames, d_active, true, s);
 }

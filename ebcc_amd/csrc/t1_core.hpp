@@ -547,7 +547,7 @@ T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h
     return r;
 }
 
-// MQ decoder registers at the start of a bit-plane (taken while decoding the complete segment)
+// MQ decoder registers at the start of a coding pass (taken while decoding the complete segment)
 struct MqCheckpoint {
     uint32_t a, c;
     int ct, pos;
@@ -556,12 +556,15 @@ struct MqCheckpoint {
 
 struct NoObserver {
     template <class Mq>
-    T1_HD void plane_start(int, const Mq &) {}
+    T1_HD void pass_start(int, const Mq &) {}
+    template <class Store>
+    T1_HD void sigprop_done(int, Store &) {}
 };
 
-// index of the first coding pass of bit-plane `bp` in a code-block with P planes, and the plane of pass i
+// index of the first coding pass of bit-plane `bp` in a code-block with P planes; plane / type of pass i
 T1_HD int first_pass_of_plane(int P, int bp) { return bp == P - 1 ? 0 : 3 * (P - 1 - bp) - 2; }
 T1_HD int plane_of_pass(int P, int i) { return i == 0 ? P - 1 : P - 2 - (i - 1) / 3; }
+T1_HD int type_of_pass(int i) { return i == 0 ? 2 : (i - 1) % 3; }          // 0 propagation, 1 refinement, 2 cleanup
 
 template <class Store, class Source, class Observer, class Table = ConstTable>
 T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Observer &obs,
@@ -572,8 +575,8 @@ T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient
     Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
     int passtype = 2, bp = numbps - 1;
     for (int p = 0; p < npasses && bp >= 0; p++) {
-        if (passtype == 0 || p == 0) obs.plane_start(bp, mq);
-        if (passtype == 0) ps.sigprop(bp);
+        obs.pass_start(p, mq);
+        if (passtype == 0) { ps.sigprop(bp); obs.sigprop_done(bp, st); }
         else if (passtype == 1) ps.refine(bp);
         else ps.cleanup(bp);
         if (++passtype == 3) { passtype = 0; bp--; }
@@ -587,21 +590,20 @@ T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int num
     decode_block_observed(st, src, w, h, orient, numbps, npasses, obs, tab);
 }
 
-// Decode passes [first_pass_of_plane(q), npasses) only.  The caller has put the store into the state the
-// decoder has at the start of plane q (S/NEG/REF masks and values of everything significant in planes above
-// q, VIS clear); `ck` holds the MQ registers there (ignored for q == numbps-1, where decoding starts afresh).
-// Valid whenever the checkpoint was taken with no byte at or beyond the (truncated) segment length consumed:
-// ck.pos + 1 < length of src.
+// Decode passes [r, npasses) only.  The caller has put the store into the state the decoder has at the start
+// of pass r (S/NEG/VIS/REF masks and the values of everything already significant); `ck` holds the MQ
+// registers there (ignored for r == 0, where decoding starts afresh).  Valid whenever the checkpoint was taken
+// with no byte at or beyond the (truncated) segment length consumed: ck.pos + 1 < length of src.
 template <class Store, class Source, class Table = ConstTable>
-T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int q,
+T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int r,
                          const MqCheckpoint &ck, Table tab = Table())
 {
     MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
-    if (q == numbps - 1) mq.init();
+    if (r == 0) mq.init();
     else { mq.a = ck.a; mq.c = ck.c; mq.ct = ck.ct; mq.pos = ck.pos; mq.cx.w0 = ck.w0; mq.cx.w1 = ck.w1; mq.cx.w2 = ck.w2; }
     Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
-    int bp = q, passtype = q == numbps - 1 ? 2 : 0;
-    for (int p = first_pass_of_plane(numbps, q); p < npasses && bp >= 0; p++) {
+    int bp = plane_of_pass(numbps, r), passtype = type_of_pass(r);
+    for (int p = r; p < npasses && bp >= 0; p++) {
         if (passtype == 0) ps.sigprop(bp);
         else if (passtype == 1) ps.refine(bp);
         else ps.cleanup(bp);

@@ -43,8 +43,10 @@ struct HostStore {
 struct VecSink { std::vector<uint8_t> *v; void put(int i, uint8_t b) { if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = b; } };
 struct VecAt { std::vector<uint8_t> *v; uint8_t operator()(int i) const { return i < (int) v->size() ? (*v)[i] : 0; } };
 struct Obs {
-    MqCheckpoint ck[40];
-    template <class Mq> void plane_start(int bp, const Mq &m) { ck[bp] = MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+    MqCheckpoint ck[120];
+    u64 visp[40][64];
+    template <class Mq> void pass_start(int p, const Mq &m) { ck[p] = MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+    template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
 };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
@@ -123,28 +125,35 @@ int main(int argc, char **argv)
                 fs.out = dummy.data(); fs.w = w;
                 decode_block_observed(fs, BufSrc{bytes.data(), r.length}, w, h, orient, numbps, opasses, obs);
             }
-            int qp = plane_of_pass(numbps, np - 1);
-            while (qp < numbps - 1 && obs.ck[qp].pos + 1 >= len) qp++;
+            // restart at the last kept pass (or an earlier one whose checkpoint is still valid for this truncation)
+            int r = np - 1;
+            while (r > 0 && obs.ck[r].pos + 1 >= len) r--;
+            const int pr = plane_of_pass(numbps, r), tr = type_of_pass(r);
             std::vector<int32_t> d3((size_t) w * h, 0);
             HostStore rs;
             rs.out = d3.data(); rs.w = w;
-            // state at the start of plane q from the quantised values
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++) {
                     int32_t src6 = qvals[(size_t) y * w + x];
                     uint32_t a = (uint32_t) (src6 < 0 ? -src6 : src6) >> 6;
                     if (!a) continue;
                     int bs = 31 - __builtin_clz(a);
-                    if (bs > qp) {
-                        rs.s[y + 1] |= 1ull << x;
-                        if (src6 < 0) rs.neg[y] |= 1ull << x;
-                        if (bs >= qp + 2) rs.ref[y] |= 1ull << x;
-                        int v = 3 << bs;
-                        for (int pl = bs - 1; pl > qp; pl--) v += ((a >> pl) & 1) ? (1 << pl) : -(1 << pl);
-                        d3[(size_t) y * w + x] = src6 < 0 ? -v : v;
+                    bool sps = (st.sps[y] >> x) & 1;
+                    int ps = bs == numbps - 1 ? 0 : 3 * (numbps - 1 - bs) - (sps ? 2 : 0);     // pass of first significance
+                    if (ps >= r) continue;
+                    rs.s[y + 1] |= 1ull << x;
+                    if (src6 < 0) rs.neg[y] |= 1ull << x;
+                    int v = 3 << bs;
+                    for (int pl = bs - 1; pl >= 0; pl--) {
+                        if (3 * (numbps - 1 - pl) - 1 >= r) break;
+                        v += ((a >> pl) & 1) ? (1 << pl) : -(1 << pl);
+                        rs.ref[y] |= 1ull << x;
                     }
+                    d3[(size_t) y * w + x] = src6 < 0 ? -v : v;
                 }
-            decode_resume(rs, BufSrc{bytes.data(), len}, w, h, orient, numbps, np, qp, obs.ck[qp]);
+            if (tr != 0 && r > 0) for (int y = 0; y < 64; y++) rs.vis[y] = obs.visp[pr][y];
+            decode_resume(rs, BufSrc{bytes.data(), len}, w, h, orient, numbps, np, r, obs.ck[r]);
+            int qp = r;
             if (d1 != d3) { printf("trial %d RESUME mismatch np %d/%d q %d P %d\n", t, np, opasses, qp, numbps); bad++; break; }
         }
     }

@@ -23,6 +23,9 @@ struct ebcc_hip_ctx {
     ebcc::FrameState *h_fs = nullptr;      // pinned
     std::vector<void *> allocs;
     void *j2k = nullptr;                   // base-layer state (j2k.hpp)
+    void *j2k_alt = nullptr;               // same inputs, second set of probe outputs (concurrent second rate search)
+    hipStream_t stream2 = nullptr;
+    int *d_active2 = nullptr;
 };
 
 namespace ebcc {

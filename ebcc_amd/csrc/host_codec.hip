@@ -213,7 +213,8 @@ struct Job {                     // host-side state of one frame being encoded
     double t_hi = 0, t_lo = 0, t_best = 0;
     bool trunc_active = false;
     std::vector<uint8_t> tail, zbytes;
-    RateSearch rs;
+    RateSearch rs, rs2;          // error-bounded search (:728) and pure-base-layer search (:836)
+    double q2 = 0;
 };
 
 struct Batch {
@@ -222,59 +223,37 @@ struct Batch {
     const float *d_frames;
     size_t n;
     std::vector<J2kFrame> jf;
+    std::vector<int> active;       // host copy of this probe set's active mask
+    int *d_active;
     hipStream_t s;
-    Batch(ebcc_hip_ctx *c, const float *d, size_t n_) : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), jf(n_), s(c->stream) {}
+    Batch(ebcc_hip_ctx *c, const float *d, size_t n_, bool alt = false)
+        : ctx(c), jb(*static_cast<J2kBuffers *>(alt ? c->j2k_alt : c->j2k)), d_frames(d), n(n_), jf(n_), active(n_, 0),
+          d_active(alt ? c->d_active2 : c->d_active), s(alt ? c->stream2 : c->stream) {}
     void fetch_jf()
     {
         EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
     }
     void push_jf() { EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n, hipMemcpyHostToDevice, s)); }
-    void push_active()
-    {
-        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, sizeof(int) * n, hipMemcpyHostToDevice, s));
-    }
+    void push_active() { EBCC_HIP_CHECK(hipMemcpyAsync(d_active, active.data(), sizeof(int) * n, hipMemcpyHostToDevice, s)); }
     // one probe of the base layer for the active frames: rate allocation at jf[f].cr (+ decode and statistics)
-    void probe(bool decode)
+    void launch_probe(bool decode)
     {
         push_jf();
         push_active();
-        launch_j2k_rate(jb, (int) n, ctx->d_active, s);
-        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) n, ctx->d_active, s);
-        fetch_jf();
+        launch_j2k_rate(jb, (int) n, d_active, s);
+        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) n, d_active, s);
     }
-    // drive one rate search (per-frame state machines in jobs[f].rs) to completion
-    void run_searches(std::vector<Job> &jobs)
-    {
-        for (;;) {
-            bool any = false;
-            for (size_t f = 0; f < n; f++) {
-                float cr;
-                ctx->h_active[f] = 0;
-                if (!jobs[f].rs.done() && jobs[f].rs.next(cr)) {
-                    ctx->h_active[f] = 1;
-                    jf[f].cr = cr;
-                    any = true;
-                }
-            }
-            if (!any) break;
-            probe(true);
-            for (size_t f = 0; f < n; f++)
-                if (ctx->h_active[f]) {
-                    jobs[f].q = 1. - ((double) jf[f].nbad / (double) ctx->n_pix);              // :512
-                    jobs[f].rs.feed(jobs[f].q);
-                    log_trace("frame %zu: cr %f 1-quantile %.1e jp2_length %d", f, jf[f].cr, 1 - jobs[f].q, jf[f].stream_bytes);
-                }
-        }
-    }
+    void probe(bool decode) { launch_probe(decode); fetch_jf(); }
     // codestream of the current layer assignment of the active frames -> jobs[f].tail
-    void collect_tails(std::vector<Job> &jobs)
+    template <class Jobs>
+    void collect_tails(Jobs &jobs)
     {
         push_active();
-        launch_j2k_write(jb, (int) n, ctx->d_active, s);
+        launch_j2k_write(jb, (int) n, d_active, s);
         fetch_jf();
         for (size_t f = 0; f < n; f++)
-            if (ctx->h_active[f]) {
+            if (active[f]) {
                 jobs[f].tail.resize((size_t) jf[f].stream_bytes);
                 EBCC_HIP_CHECK(hipMemcpyAsync(jobs[f].tail.data(), jb.stream + f * jb.stream_cap, jobs[f].tail.size(),
                                               hipMemcpyDeviceToHost, s));
@@ -282,6 +261,42 @@ struct Batch {
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
     }
 };
+
+// Drive rate searches to completion, one probe per frame and search per round.  `second` may be null; when
+// given, search #2 of every frame (jobs[f].rs2, probe set b2) advances in the same rounds on its own stream.
+template <class Jobs>
+void run_searches(Batch &b1, Batch *b2, Jobs &jobs, size_t n_pix)
+{
+    for (;;) {
+        bool any1 = false, any2 = false;
+        for (size_t f = 0; f < b1.n; f++) {
+            float cr;
+            b1.active[f] = 0;
+            if (!jobs[f].rs.done() && jobs[f].rs.next(cr)) { b1.active[f] = 1; b1.jf[f].cr = cr; any1 = true; }
+            if (b2) {
+                b2->active[f] = 0;
+                if (!jobs[f].rs2.done() && jobs[f].rs2.next(cr)) { b2->active[f] = 1; b2->jf[f].cr = cr; any2 = true; }
+            }
+        }
+        if (!any1 && !any2) break;
+        if (any1) b1.launch_probe(true);
+        if (any2) b2->launch_probe(true);
+        if (any1) b1.fetch_jf();
+        if (any2) b2->fetch_jf();
+        for (size_t f = 0; f < b1.n; f++) {
+            if (any1 && b1.active[f]) {
+                jobs[f].q = 1. - ((double) b1.jf[f].nbad / (double) n_pix);                    // :512
+                jobs[f].rs.feed(jobs[f].q);
+                log_trace("frame %zu: cr %f 1-quantile %.1e jp2_length %d", f, b1.jf[f].cr, 1 - jobs[f].q, b1.jf[f].stream_bytes);
+            }
+            if (any2 && b2->active[f]) {
+                jobs[f].q2 = 1. - ((double) b2->jf[f].nbad / (double) n_pix);
+                jobs[f].rs2.feed(jobs[f].q2);
+                log_trace("frame %zu (pure): cr %f 1-quantile %.1e jp2_length %d", f, b2->jf[f].cr, 1 - jobs[f].q2, b2->jf[f].stream_bytes);
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // ebcc_encode for a batch of device-resident single-frame chunks.  Returns 0, 1 (error) or 2 (NaN/Inf).
@@ -312,7 +327,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         jobs[f].maxv = ctx->h_fs[f].maxv;
         b.jf[f].cr = cfg->base_cr;
         b.jf[f].target = 0;
-        ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
+        b.active[f] = jobs[f].const_field ? 0 : 1;
     }
     pt.mark("analysis (dwt, tier-1, ckpt)");
     const bool need_decode = mode != NONE;
@@ -339,7 +354,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         fetch_frame_states(ctx, n);
         for (size_t f = 0; f < n; f++) { jobs[f].rmin = ctx->h_fs[f].rmin; jobs[f].rmax = ctx->h_fs[f].rmax; }
         if (!searching) {                       // stale enum values fall through to a base-only stream (quirk Q2)
-            for (size_t f = 0; f < n; f++) ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
+            for (size_t f = 0; f < n; f++) b.active[f] = jobs[f].const_field ? 0 : 1;
             b.collect_tails(jobs);
         }
     }
@@ -347,11 +362,21 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     pt.mark("first probe");
     if (searching) {
         // ---- rate search #1 (:728)
-        for (size_t f = 0; f < n; f++)
-            if (!jobs[f].const_field) jobs[f].rs.start(cfg->base_cr, jobs[f].q, q_target);
-        b.run_searches(jobs);
+        //      The pure-base-layer search (:836) restarts from base_cr with the quantile of a re-encode at
+        //      base_cr (:829-833), i.e. of the first probe above, so unless that consistency step is disabled
+        //      it does not depend on search #1 and both advance together on two streams / probe sets.
+        const bool pure_done = q_target == 1.0;                                               // :738
+        const bool want_pure = !pure_done && !env.no_fallback;
+        const bool concurrent = want_pure && !env.no_consistency;
+        Batch b2(ctx, d_frames, n, true);
         for (size_t f = 0; f < n; f++) {
-            ctx->h_active[f] = jobs[f].const_field ? 0 : 1;
+            if (jobs[f].const_field) continue;
+            jobs[f].rs.start(cfg->base_cr, jobs[f].q, q_target);
+            if (concurrent) { jobs[f].rs2.start(cfg->base_cr, jobs[f].q, 1.0); b2.jf[f] = b.jf[f]; }
+        }
+        run_searches(b, concurrent ? &b2 : nullptr, jobs, n_pix);
+        for (size_t f = 0; f < n; f++) {
+            b.active[f] = jobs[f].const_field ? 0 : 1;
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs.result; jobs[f].len1 = (size_t) b.jf[f].stream_bytes; }
         }
         pt.mark("rate search 1");
@@ -361,21 +386,20 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         bool any_resid = false;
         for (size_t f = 0; f < n; f++) {
             Job &j = jobs[f];
-            ctx->h_active[f] = 0;
+            b.active[f] = 0;
             if (j.const_field) continue;
             j.rmin = ctx->h_fs[f].rmin; j.rmax = ctx->h_fs[f].rmax;
             float cur = fmaxf(fabsf(j.rmin), fabsf(j.rmax));                                  // :735
             j.skip = cur <= j.target;                                                         // :737
-            if (!j.skip) { ctx->h_active[f] = 1; any_resid = true; }
+            if (!j.skip) { b.active[f] = 1; any_resid = true; }
         }
-        const bool pure_done = q_target == 1.0;                                               // :738
         pt.mark("tails + residual range");
 
         if (any_resid) {
             // ---- residual layer: SPIHT with a budget of the base layer's size (:744-754)
             b.push_active();
-            launch_pad_and_dc(d_frames, jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
-            launch_analysis(ctx->rb, (int) n, ctx->d_active, s);
+            launch_pad_and_dc(d_frames, jb.DEC, ctx->rb, (int) n, b.d_active, s);
+            launch_analysis(ctx->rb, (int) n, b.d_active, s);
             fetch_frame_states(ctx, n);
             for (size_t f = 0; f < n; f++) {
                 unsigned long long bits0 = (unsigned long long) jobs[f].len1 * 8 + 128;       // trunc_bits + 128
@@ -384,10 +408,10 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
             push_frame_states(ctx, n);
             EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-            launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, ctx->d_active, s);
+            launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, b.d_active, s);
             fetch_frame_states(ctx, n);
             for (size_t f = 0; f < n; f++) {
-                if (!ctx->h_active[f]) continue;
+                if (!b.active[f]) continue;
                 jobs[f].coeffs_orig = ctx->h_fs[f].stream_bytes;
                 jobs[f].coeffs_size = jobs[f].coeffs_orig;
                 ctx->h_u64b[f] = (unsigned long long) jobs[f].coeffs_orig * 8;                // full decode, :749
@@ -396,15 +420,15 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             auto probe_residual = [&]() {
                 EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
                 b.push_active();
-                launch_reconstruct(ctx->rb, (int) n, ctx->d_u64b, ctx->d_active, s);
-                launch_synthesis(ctx->rb, (int) n, ctx->d_active, s);
-                launch_probe_stats(d_frames, jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
+                launch_reconstruct(ctx->rb, (int) n, ctx->d_u64b, b.d_active, s);
+                launch_synthesis(ctx->rb, (int) n, b.d_active, s);
+                launch_probe_stats(d_frames, jb.DEC, ctx->rb, (int) n, b.d_active, s);
                 fetch_frame_states(ctx, n);
             };
             probe_residual();
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
-                if (!ctx->h_active[f]) continue;
+                if (!b.active[f]) continue;
                 float cur = u2f(ctx->h_fs[f].maxerr_bits);                                    // :754
                 if (cur > j.target) {                                                         // :755-759
                     log_info("frame %zu: could not reach error target %f (%f instead); retry with pure base compression", f, j.target, cur);
@@ -422,12 +446,12 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 bool any = false;
                 for (size_t f = 0; f < n; f++) {
                     Job &j = jobs[f];
-                    ctx->h_active[f] = 0;
+                    b.active[f] = 0;
                     if (!j.trunc_active) continue;
                     if (((j.target - j.best_err) / j.target > eps) && (j.t_hi - j.t_lo > 8 * 4)) {
                         size_t tb = ((size_t) ceill((long double) ((j.t_hi + j.t_lo) / 2 / 8))) * 8;
                         ctx->h_u64b[f] = tb;
-                        ctx->h_active[f] = 1;
+                        b.active[f] = 1;
                         any = true;
                     } else {
                         j.trunc_active = false;
@@ -437,7 +461,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 probe_residual();
                 for (size_t f = 0; f < n; f++) {
                     Job &j = jobs[f];
-                    if (!ctx->h_active[f]) continue;
+                    if (!b.active[f]) continue;
                     const double tb = (double) ctx->h_u64b[f];
                     float cur = u2f(ctx->h_fs[f].maxerr_bits);
                     if (cur > j.target) j.t_lo = tb;
@@ -491,31 +515,28 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         auto zjoin = [&]() { for (auto &t : zpool) if (t.joinable()) t.join(); };
         pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)
-        if (!pure_done && !env.no_fallback) {
-            if (!env.no_consistency) {
-                for (size_t f = 0; f < n; f++) { ctx->h_active[f] = jobs[f].const_field ? 0 : 1; b.jf[f].cr = cfg->base_cr; }
-                b.probe(true);                                                                // :829-833
+        if (want_pure) {
+            Batch &bp = concurrent ? b2 : b;
+            if (!concurrent) {
                 for (size_t f = 0; f < n; f++)
-                    if (!jobs[f].const_field) { jobs[f].q = 1. - ((double) b.jf[f].nbad / (double) n_pix); jobs[f].cr = cfg->base_cr; }
+                    if (!jobs[f].const_field) jobs[f].rs.start(jobs[f].cr, jobs[f].q, 1.0);   // consistency off: from search #1's state
+                run_searches(b, nullptr, jobs, n_pix);                                        // :836
             }
-            for (size_t f = 0; f < n; f++)
-                if (!jobs[f].const_field) jobs[f].rs.start(jobs[f].cr, jobs[f].q, 1.0);
-            b.run_searches(jobs);                                                             // :836
             zjoin();
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
-                ctx->h_active[f] = 0;
+                bp.active[f] = 0;
                 if (j.const_field) continue;
-                const size_t len2 = (size_t) b.jf[f].stream_bytes;
+                const size_t len2 = (size_t) bp.jf[f].stream_bytes;
                 if (len2 < j.zbytes.size() + j.len1 || j.need_pure) {                         // :838
                     if (len2 < j.zbytes.size() + j.len1)
                         log_info("frame %zu: pure base compression (%zu) beats base (%zu) + residual (%zu)", f, len2, j.len1, j.zbytes.size());
-                    j.mean_err = b.jf[f].err_sum / (double) n_pix;                            // :843
+                    j.mean_err = bp.jf[f].err_sum / (double) n_pix;                           // :843
                     j.zbytes.clear(); j.coeffs_size = 0;
-                    ctx->h_active[f] = 1;
+                    bp.active[f] = 1;
                 }
             }
-            b.collect_tails(jobs);
+            bp.collect_tails(jobs);
         }
         zjoin();
     }

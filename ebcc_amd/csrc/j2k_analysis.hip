@@ -468,9 +468,38 @@ struct DevAt {
     __device__ uint8_t operator()(int i) const { return i < cap ? p[i] : (uint8_t) 0; }
 };
 
+// MQ-decoder checkpoints for the rate probes: the decoder registers at the start of every coding pass (and the
+// visited masks after every propagation pass) so that a probe restarts at the last pass it keeps
+// (j2k_rate.hip).  They are derived from the encoder's own registers - see t1::finalize_checkpoints - so no
+// decode of the segment is needed.
+struct CkObserver {
+    t1::MqCheckpoint *ck;          // [passes] of this code-block
+    unsigned long long *visp;      // group base of the per-plane visited masks, lane offset applied
+    template <class Mq>
+    __device__ void pass_start(int p, const Mq &m) { ck[p] = t1::encoder_checkpoint(m); }
+    template <class Store>
+    __device__ void sigprop_done(int bp, Store &st)
+    {
+        for (int y = 0; y < 64; y++) visp[((size_t) bp * 64 + y) * 64] = st.VIS(y);
+    }
+};
+struct CkSrc {
+    // byte source with an 8-byte register window: one aligned load per 8 bytes instead of two byte loads per BYTEIN
+    const uint8_t *p; int n;
+    unsigned long long win = 0; int base = -16;
+    __device__ uint32_t get(int i)
+    {
+        if (i >= n) return 0xFFu;
+        const int b = i & ~7;
+        if (b != base) { win = *reinterpret_cast<const unsigned long long *>(p + b); base = b; }
+        return (uint32_t) (win >> (8 * (i & 7))) & 0xFFu;
+    }
+};
+
 __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const unsigned long long *BP,
                                                    const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax, int *numbps,
                                                    int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes,
+                                                   t1::MqCheckpoint *ckpt, unsigned long long *VISP,
                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
                                                    J2kFrame *jf, int total, int lpw)
 {
@@ -492,10 +521,13 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     DevStore st{T1S + grp * kT1StateWords * 64 + gl, BP + grp * kJ2kMaxPlanes * 64 * 64 + gl, SGN + grp * 64 * 64 + gl,
                 SPS + grp * 64 * 64 + gl};
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    t1::EncodeResult r = t1::encode_block(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
-                                          blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, tab);
+    CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPasses, VISP + grp * kJ2kMaxPlanes * 64 * 64 + gl};
+    t1::EncodeResult r = t1::encode_block_observed(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
+                                                   blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, obs, tab);
     totalpasses[gid] = r.totalpasses;
     cblk_len[gid] = r.length;
+    __threadfence();                                                    // the sweep below re-reads this lane's own bytes
+    t1::finalize_checkpoints(obs.ck, r.totalpasses, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
 }
 
 // ================================================================================================
@@ -557,66 +589,6 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
 }
 
 
-// ================================================================================================
-// MQ-decoder checkpoints: decode every code-block's complete segment once and save the decoder registers at
-// the start of every coding pass (plus the visited masks after every propagation pass).  A rate probe then
-// restarts at the last pass it keeps (j2k_rate.hip)
-// instead of decoding all kept passes.
-// ================================================================================================
-struct CkStore {
-    unsigned long long *st;
-    __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
-    __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
-    __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
-    __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
-    __device__ void set_sig(int, int, int, int) {}
-    __device__ void refine(int, int, int, int, int) {}
-};
-struct CkObserver {
-    t1::MqCheckpoint *ck;          // [passes] of this code-block
-    unsigned long long *visp;      // group base of the per-plane visited masks, lane offset applied
-    template <class Mq>
-    __device__ void pass_start(int p, const Mq &m) { ck[p] = t1::MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
-    template <class Store>
-    __device__ void sigprop_done(int bp, Store &st)
-    {
-        for (int y = 0; y < 64; y++) visp[((size_t) bp * 64 + y) * 64] = st.VIS(y);
-    }
-};
-struct CkSrc {
-    // byte source with an 8-byte register window: one aligned load per 8 bytes instead of two byte loads per BYTEIN
-    const uint8_t *p; int n;
-    unsigned long long win = 0; int base = -16;
-    __device__ uint32_t get(int i)
-    {
-        if (i >= n) return 0xFFu;
-        const int b = i & ~7;
-        if (b != base) { win = *reinterpret_cast<const unsigned long long *>(p + b); base = b; }
-        return (uint32_t) (win >> (8 * (i & 7))) & 0xFFu;
-    }
-};
-
-__global__ __launch_bounds__(64) void k_t1_checkpoints(unsigned long long *T1S, const uint8_t *cblk_bytes, const int *numbps,
-                                                        const int *totalpasses, const int *cblk_len, t1::MqCheckpoint *ckpt,
-                                                        unsigned long long *VISP, const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
-                                                        int total, int lpw)
-{
-    EBCC_LDS_MQ_TABLE(tab);
-    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int gid = blockIdx.x * lpw + threadIdx.x;
-    if (gid >= total) return;
-    const int nb = geom->nblocks;
-    const int frame = gid / nb, bi = gid - frame * nb;
-    if (fs[frame].const_field) return;
-    const int P = numbps[gid], np = totalpasses[gid];
-    if (np <= 0 || P <= 0) return;
-    const J2kBlock blk = blocks[bi];
-    CkStore st{T1S + (size_t) (gid >> 6) * kT1StateWords * 64 + (gid & 63)};
-    CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPasses, VISP + (size_t) (gid >> 6) * kJ2kMaxPlanes * 64 * 64 + (gid & 63)};
-    t1::decode_block_observed(st, CkSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, cblk_len[gid]}, blk.w, blk.h,
-                              geom->bands[blk.band].orient, P, np, obs, tab);
-}
-
 }  // namespace
 
 // ================================================================================================
@@ -676,18 +648,11 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     int lpw = t1_lanes_per_wave(T1_ENCODE);
     unsigned t1_grid = (unsigned) ceil_div(total, lpw);
     hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.d_geom, jb.d_blocks, fs, jb.jf, total, lpw);
+                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, (t1::MqCheckpoint *) jb.ckpt, jb.VISP, jb.d_geom,
+                       jb.d_blocks, fs, jb.jf, total, lpw);
     timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
-    // decoder checkpoints for the rate probes (the encoder's SPS masks in T1S are no longer needed)
-    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
-    timing_begin("t1_checkpoints", s);
-    lpw = t1_lanes_per_wave(T1_CHECKPOINT);
-    t1_grid = (unsigned) ceil_div(total, lpw);
-    hipLaunchKernelGGL(k_t1_checkpoints, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.cblk_bytes, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, (t1::MqCheckpoint *) jb.ckpt, jb.VISP, jb.d_geom, jb.d_blocks, fs, total, lpw);
-    timing_end("t1_checkpoints", s);
 }
 
 // inverse transform of the tile buffers, used by both decode flavours (j2k_rate.hip)

@@ -97,11 +97,12 @@ struct MqEncoder {
     Contexts cx;
     Sink sink;
     Table tab;
+    uint32_t shifts;  // renormalisation shifts so far (the decoder performs exactly the same number)
 
     T1_HD void init()
     {
         cx.reset();
-        a = 0x8000; c = 0; ct = 12; n = -1; cur = 0;
+        a = 0x8000; c = 0; ct = 12; n = -1; cur = 0; shifts = 0;
     }
     T1_HD void emit() { if (n >= 0) sink.put(n, (uint8_t) cur); }
     T1_HD void byteout()
@@ -123,7 +124,7 @@ struct MqEncoder {
     T1_HD void renorm()
     {
         do {
-            a <<= 1; c <<= 1; ct--;
+            a <<= 1; c <<= 1; ct--; shifts++;
             if (ct == 0) byteout();
         } while ((a & 0x8000) == 0);
     }
@@ -518,16 +519,24 @@ struct EncodeResult {
 // Encodes every pass of a code-block with `numbps` magnitude bit-planes (numbps >= 1).
 // rates[p] follow OpenJPEG: bytes completed + 3 for unterminated passes, clipped to be non-decreasing,
 // never ending on 0xFF (needs read access to the bytes: ByteAt(int) -> uint8_t).
-template <class Store, class Sink, class ByteAt, class Table = ConstTable>
-T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates,
-                                Table tab = Table())
+struct NoObserver {
+    template <class Mq>
+    T1_HD void pass_start(int, const Mq &) {}
+    template <class Store>
+    T1_HD void sigprop_done(int, Store &) {}
+};
+
+template <class Store, class Sink, class ByteAt, class Observer, class Table = ConstTable>
+T1_HD EncodeResult encode_block_observed(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates,
+                                         Observer &obs, Table tab = Table())
 {
-    MqEncoder<Sink, Table> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink, tab};
+    MqEncoder<Sink, Table> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink, tab, 0};
     mq.init();
     Passes<true, Store, MqEncoder<Sink, Table>> ps(st, mq, w, h, orient);
     int passno = 0, passtype = 2;
     for (int bp = numbps - 1; bp >= 0; passno++) {
-        if (passtype == 0) ps.sigprop(bp);
+        obs.pass_start(passno, mq);
+        if (passtype == 0) { ps.sigprop(bp); obs.sigprop_done(bp, st); }
         else if (passtype == 1) ps.refine(bp);
         else ps.cleanup(bp);
         if (passtype == 2 && bp == 0) { mq.flush(); rates[passno] = mq.numbytes(); }
@@ -547,6 +556,14 @@ T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h
     return r;
 }
 
+template <class Store, class Sink, class ByteAt, class Table = ConstTable>
+T1_HD EncodeResult encode_block(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates,
+                                Table tab = Table())
+{
+    NoObserver obs;
+    return encode_block_observed(st, sink, bytes, w, h, orient, numbps, rates, obs, tab);
+}
+
 // MQ decoder registers at the start of a coding pass (taken while decoding the complete segment)
 struct MqCheckpoint {
     uint32_t a, c;
@@ -554,12 +571,57 @@ struct MqCheckpoint {
     u64 w0, w1, w2;
 };
 
-struct NoObserver {
-    template <class Mq>
-    T1_HD void pass_start(int, const Mq &) {}
-    template <class Store>
-    T1_HD void sigprop_done(int, Store &) {}
-};
+// ------------------------------------------------------------------------------------------------
+// Decoder checkpoints without decoding.  The MQ decoder's registers at a pass boundary follow from the
+// ENCODER's registers there plus the finished bytes:
+//   * A and the context states evolve identically in both coders (C.2.2 / C.3.2 mirror each other);
+//   * the decoder's C register only ever sees linear updates mod 2^32: "c <<= 1" per renormalisation shift,
+//     "c += byte << 8|9" per BYTEIN, "c -= Qe << 16" whenever the symbol lies in the upper sub-interval - and
+//     those are exactly the symbols for which the encoder does "c += Qe".  Hence
+//         C_dec = Inject(shifts, bytes) - ((C_enc & 0xFFFF) << 16)   (mod 2^32)
+//     where Inject is the decoder's C with the subtractions left out: a function of the number of shifts so
+//     far (equal in both coders) and of the segment bytes only;
+//   * CT and the byte position are the same function of (shifts, bytes).
+// The encoder therefore stores {A, C_enc & 0xFFFF, shifts, contexts} at every pass start and one sweep over
+// the bytes afterwards (O(bytes + passes), no symbols decoded) turns them into decoder registers.
+// ------------------------------------------------------------------------------------------------
+template <class Mq>
+T1_HD MqCheckpoint encoder_checkpoint(const Mq &m)
+{
+    return MqCheckpoint{m.a, m.c & 0xFFFFu, 0, (int) m.shifts, m.cx.w0, m.cx.w1, m.cx.w2};
+}
+
+template <class Source>
+T1_HD void finalize_checkpoints(MqCheckpoint *ck, int npasses, Source src)
+{
+    uint32_t c;
+    int ct, pos = 0;
+    auto bytein = [&]() {
+        uint32_t cur = src.get(pos), nxt = src.get(pos + 1);
+        if (cur == 0xFF) {
+            if (nxt > 0x8F) { c += 0xFF00; ct = 8; }
+            else { pos++; c += nxt << 9; ct = 7; }
+        } else {
+            pos++; c += nxt << 8; ct = 8;
+        }
+    };
+    c = src.get(0) << 16;
+    bytein();
+    c <<= 7; ct -= 7;
+    uint32_t done = 0;
+    for (int p = 0; p < npasses; p++) {
+        uint32_t rem = (uint32_t) ck[p].pos - done;
+        done = (uint32_t) ck[p].pos;
+        while (rem) {
+            if (ct == 0) bytein();
+            uint32_t k = rem < (uint32_t) ct ? rem : (uint32_t) ct;
+            c <<= k; ct -= (int) k; rem -= k;
+        }
+        ck[p].c = c - (ck[p].c << 16);
+        ck[p].ct = ct;
+        ck[p].pos = pos;
+    }
+}
 
 // index of the first coding pass of bit-plane `bp` in a code-block with P planes; plane / type of pass i
 T1_HD int first_pass_of_plane(int P, int bp) { return bp == P - 1 ? 0 : 3 * (P - 1 - bp) - 2; }

@@ -48,6 +48,12 @@ struct Obs {
     template <class Mq> void pass_start(int p, const Mq &m) { ck[p] = MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
     template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
 };
+struct EncObs {
+    MqCheckpoint ck[120];
+    u64 visp[40][64];
+    template <class Mq> void pass_start(int p, const Mq &m) { ck[p] = encoder_checkpoint(m); }
+    template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
+};
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
 int main(int argc, char **argv)
@@ -93,7 +99,10 @@ int main(int argc, char **argv)
             }
         std::vector<uint8_t> bytes;
         int rates[kMaxPasses];
-        EncodeResult r = encode_block(st, VecSink{&bytes}, VecAt{&bytes}, w, h, orient, numbps, rates);
+        EncObs eobs;
+        memset(eobs.visp, 0, sizeof eobs.visp);
+        EncodeResult r = encode_block_observed(st, VecSink{&bytes}, VecAt{&bytes}, w, h, orient, numbps, rates, eobs);
+        finalize_checkpoints(eobs.ck, r.totalpasses, BufSrc{bytes.data(), r.length});
         bool ok = r.totalpasses == opasses && r.length == (opasses ? orates[opasses - 1] >= 0 ? r.length : 0 : 0);
         int olen = 0;
         // oracle's len is mq numbytes; recover it as the max rate (last pass rate equals it unless trimmed for FF)
@@ -124,6 +133,20 @@ int main(int argc, char **argv)
                 HostStore fs;
                 fs.out = dummy.data(); fs.w = w;
                 decode_block_observed(fs, BufSrc{bytes.data(), r.length}, w, h, orient, numbps, opasses, obs);
+            }
+            // the encoder-derived checkpoints (no decoding) must equal the decoder's own registers
+            if (k == 0) {
+                bool same = true;
+                for (int p = 0; p < opasses && same; p++) {
+                    const MqCheckpoint &x = obs.ck[p], &y = eobs.ck[p];
+                    same = x.a == y.a && x.c == y.c && x.ct == y.ct && x.pos == y.pos && x.w0 == y.w0 && x.w1 == y.w1 && x.w2 == y.w2;
+                    if (!same) printf("trial %d pass %d ckpt dec {a %x c %x ct %d pos %d} enc {a %x c %x ct %d pos %d}\n", t, p, x.a, x.c, x.ct, x.pos, y.a, y.c, y.ct, y.pos);
+                    if (same && type_of_pass(p) == 0) {
+                        const int pl = plane_of_pass(numbps, p);
+                        for (int yy = 0; yy < 64; yy++) if (obs.visp[pl][yy] != eobs.visp[pl][yy]) { same = false; printf("trial %d visp plane %d row %d\n", t, pl, yy); break; }
+                    }
+                }
+                if (!same) { printf("trial %d ENCODER CHECKPOINT mismatch\n", t); bad++; break; }
             }
             // restart at the last kept pass (or an earlier one whose checkpoint is still valid for this truncation)
             int r = np - 1;

@@ -202,10 +202,12 @@ struct PhaseTimer {
     }
 };
 
+struct ProbeRec { float cr = -1; unsigned long long nbad = 0; int stream_bytes = 0; double err_sum = 0; };
+
 struct Job {                     // host-side state of one frame being encoded
     bool const_field = false;
     float minv = 0, maxv = 0, target = -1, cr = -1;
-    double mean_err = 0, q = 0;
+    double mean_err = 0, q = 0, q_first = 0;
     float rmin = 0, rmax = 0;
     bool skip = true, need_pure = false;
     float best_err = -1;
@@ -213,8 +215,18 @@ struct Job {                     // host-side state of one frame being encoded
     double t_hi = 0, t_lo = 0, t_best = 0;
     bool trunc_active = false;
     std::vector<uint8_t> tail, zbytes;
-    RateSearch rs, rs2;          // error-bounded search (:728) and pure-base-layer search (:836)
-    double q2 = 0;
+    // rate searches: [0] error-bounded (:728), [1] pure base layer (:836).  A probe's outcome depends only on
+    // (frame, rate), so both searches share one record of the probes made so far.
+    RateSearch rs[2];
+    bool want[2] = {false, false};    // search k waits for the probe at want_cr[k]
+    float want_cr[2] = {0, 0};
+    ProbeRec last[2];                 // the final probe of search k (phase 3)
+    std::vector<ProbeRec> probes;
+    const ProbeRec *find_probe(float cr) const
+    {
+        for (const ProbeRec &r : probes) if (r.cr == cr) return &r;
+        return nullptr;
+    }
 };
 
 struct Batch {
@@ -224,11 +236,12 @@ struct Batch {
     size_t n;
     std::vector<J2kFrame> jf;
     std::vector<int> active;       // host copy of this probe set's active mask
+    std::vector<float> state_cr;   // rate of the decode this set holds for every frame (-1: none)
     int *d_active;
     hipStream_t s;
     Batch(ebcc_hip_ctx *c, const float *d, size_t n_, bool alt = false)
         : ctx(c), jb(*static_cast<J2kBuffers *>(alt ? c->j2k_alt : c->j2k)), d_frames(d), n(n_), jf(n_), active(n_, 0),
-          d_active(alt ? c->d_active2 : c->d_active), s(alt ? c->stream2 : c->stream) {}
+          state_cr(n_, -1.f), d_active(alt ? c->d_active2 : c->d_active), s(alt ? c->stream2 : c->stream) {}
     void fetch_jf()
     {
         EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n, hipMemcpyDeviceToHost, s));
@@ -262,39 +275,101 @@ struct Batch {
     }
 };
 
-// Drive rate searches to completion, one probe per frame and search per round.  `second` may be null; when
-// given, search #2 of every frame (jobs[f].rs2, probe set b2) advances in the same rounds on its own stream.
+// Drive rate searches to completion; every round runs at most one probe per frame and probe set.
+//   set[k]   : probe set search k decodes into (null = search k is not run); both may name the same set only
+//              if one of them is null
+//   A search first advances through the probes already on record for its frame (the other search, or the
+//   first encode, usually made them) and only asks the GPU for rates not seen yet.  The final probe of
+//   search 0 (:590) must leave its decode in the set - the residual layer is computed from it - so it is
+//   re-run unless that set's last decode of the frame was at exactly that rate.
 template <class Jobs>
-void run_searches(Batch &b1, Batch *b2, Jobs &jobs, size_t n_pix)
+void run_searches(Batch *set0, Batch *set1, Jobs &jobs, size_t n_pix)
 {
-    for (;;) {
-        bool any1 = false, any2 = false;
-        for (size_t f = 0; f < b1.n; f++) {
+    Batch *sets[2] = {set0, set1};
+    const size_t n = (set0 ? set0 : set1)->n;
+    auto advance = [&](Job &j, int k, size_t f) {
+        RateSearch &rs = j.rs[k];
+        while (!j.want[k] && !rs.done()) {
             float cr;
-            b1.active[f] = 0;
-            if (!jobs[f].rs.done() && jobs[f].rs.next(cr)) { b1.active[f] = 1; b1.jf[f].cr = cr; any1 = true; }
-            if (b2) {
-                b2->active[f] = 0;
-                if (!jobs[f].rs2.done() && jobs[f].rs2.next(cr)) { b2->active[f] = 1; b2->jf[f].cr = cr; any2 = true; }
+            if (!rs.next(cr)) break;
+            const ProbeRec *rec = j.find_probe(cr);
+            const bool need_state = k == 0 && rs.phase == 3 && sets[k]->state_cr[f] != cr;
+            if (rec && !need_state) {
+                if (rs.phase == 3) j.last[k] = *rec;
+                const double q = 1. - ((double) rec->nbad / (double) n_pix);                   // :512
+                if (k == 0) j.q = q;
+                rs.feed(q);
+            } else {
+                j.want[k] = true; j.want_cr[k] = cr;
             }
         }
-        if (!any1 && !any2) break;
-        if (any1) b1.launch_probe(true);
-        if (any2) b2->launch_probe(true);
-        if (any1) b1.fetch_jf();
-        if (any2) b2->fetch_jf();
-        for (size_t f = 0; f < b1.n; f++) {
-            if (any1 && b1.active[f]) {
-                jobs[f].q = 1. - ((double) b1.jf[f].nbad / (double) n_pix);                    // :512
-                jobs[f].rs.feed(jobs[f].q);
-                log_trace("frame %zu: cr %f 1-quantile %.1e jp2_length %d", f, b1.jf[f].cr, 1 - jobs[f].q, b1.jf[f].stream_bytes);
-            }
-            if (any2 && b2->active[f]) {
-                jobs[f].q2 = 1. - ((double) b2->jf[f].nbad / (double) n_pix);
-                jobs[f].rs2.feed(jobs[f].q2);
-                log_trace("frame %zu (pure): cr %f 1-quantile %.1e jp2_length %d", f, b2->jf[f].cr, 1 - jobs[f].q2, b2->jf[f].stream_bytes);
+    };
+    for (;;) {
+        bool any[2] = {false, false};
+        for (int k = 0; k < 2; k++)
+            if (sets[k]) std::fill(sets[k]->active.begin(), sets[k]->active.end(), 0);
+        for (size_t f = 0; f < n; f++) {
+            Job &j = jobs[f];
+            if (j.const_field) continue;
+            for (int k = 0; k < 2; k++) {
+                if (!sets[k]) continue;
+                advance(j, k, f);
+                if (!j.want[k]) continue;
+                // the other search asks for the same rate this round: one probe serves both
+                if (k == 1 && sets[0] && j.want[0] && j.want_cr[0] == j.want_cr[1] && sets[0]->active[f]) continue;
+                sets[k]->active[f] = 1; sets[k]->jf[f].cr = j.want_cr[k]; any[k] = true;
             }
         }
+        if (!any[0] && !any[1]) break;
+        for (int k = 0; k < 2; k++) if (any[k]) sets[k]->launch_probe(true);
+        for (int k = 0; k < 2; k++) if (any[k]) sets[k]->fetch_jf();
+        for (size_t f = 0; f < n; f++) {
+            Job &j = jobs[f];
+            for (int k = 0; k < 2; k++) {
+                if (!any[k] || !sets[k]->active[f]) continue;
+                const J2kFrame &r = sets[k]->jf[f];
+                sets[k]->state_cr[f] = r.cr;
+                if (!j.find_probe(r.cr)) j.probes.push_back(ProbeRec{r.cr, r.nbad, r.stream_bytes, r.err_sum});
+                log_trace("frame %zu (search %d): cr %f 1-quantile %.1e jp2_length %d", f, k, r.cr,
+                          (double) r.nbad / (double) n_pix, r.stream_bytes);
+            }
+            for (int k = 0; k < 2; k++) {
+                if (!sets[k] || !j.want[k]) continue;
+                const ProbeRec *rec = j.find_probe(j.want_cr[k]);
+                if (!rec) continue;
+                if (k == 0 && j.rs[0].phase == 3 && sets[0]->state_cr[f] != j.want_cr[0]) continue;
+                RateSearch &rs = j.rs[k];
+                if (rs.phase == 3) j.last[k] = *rec;
+                const double q = 1. - ((double) rec->nbad / (double) n_pix);
+                if (k == 0) j.q = q;
+                rs.feed(q);
+                j.want[k] = false;
+            }
+        }
+    }
+    // A search that leaves through the rate > 1000 exit (:571-574) makes no final probe: its result is the
+    // last doubling step.  Take that probe's record, and for search 0 make sure its decode is in the set.
+    bool redo = false;
+    for (int k = 0; k < 2; k++) if (sets[k]) std::fill(sets[k]->active.begin(), sets[k]->active.end(), 0);
+    for (size_t f = 0; f < n; f++) {
+        Job &j = jobs[f];
+        if (j.const_field) continue;
+        for (int k = 0; k < 2; k++) {
+            if (!sets[k] || j.last[k].cr == j.rs[k].result) continue;
+            if (const ProbeRec *rec = j.find_probe(j.rs[k].result)) j.last[k] = *rec;
+        }
+        if (sets[0] && sets[0]->state_cr[f] != j.rs[0].result) {
+            sets[0]->active[f] = 1; sets[0]->jf[f].cr = j.rs[0].result; redo = true;
+        }
+    }
+    if (redo) {
+        sets[0]->probe(true);
+        for (size_t f = 0; f < n; f++)
+            if (sets[0]->active[f]) {
+                const J2kFrame &r = sets[0]->jf[f];
+                sets[0]->state_cr[f] = r.cr;
+                jobs[f].last[0] = ProbeRec{r.cr, r.nbad, r.stream_bytes, r.err_sum};
+            }
     }
 }
 
@@ -346,8 +421,10 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         for (size_t f = 0; f < n; f++) {
             if (jobs[f].const_field) continue;
             jobs[f].mean_err = b.jf[f].err_sum / (double) n_pix;                              // :709
-            jobs[f].q = 1. - ((double) b.jf[f].nbad / (double) n_pix);
+            jobs[f].q = jobs[f].q_first = 1. - ((double) b.jf[f].nbad / (double) n_pix);
             jobs[f].cr = cfg->base_cr;
+            jobs[f].probes.push_back(ProbeRec{b.jf[f].cr, b.jf[f].nbad, b.jf[f].stream_bytes, b.jf[f].err_sum});
+            b.state_cr[f] = b.jf[f].cr;
         }
         // residual range of the first decode: only the header fields survive when no search runs (:716)
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, ctx->rb.fs, s);
@@ -364,20 +441,23 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         // ---- rate search #1 (:728)
         //      The pure-base-layer search (:836) restarts from base_cr with the quantile of a re-encode at
         //      base_cr (:829-833), i.e. of the first probe above, so unless that consistency step is disabled
-        //      it does not depend on search #1 and both advance together on two streams / probe sets.
+        //      it does not depend on search #1.  It either runs beside search #1 on the second probe set
+        //      (EBCC_HIP_PURE_SEARCH=concurrent) or later, while host cores run zstd (default); either way it
+        //      re-uses every probe search #1 already made.
         const bool pure_done = q_target == 1.0;                                               // :738
         const bool want_pure = !pure_done && !env.no_fallback;
-        const bool concurrent = want_pure && !env.no_consistency;
+        const char *ps_env = getenv("EBCC_HIP_PURE_SEARCH");
+        const bool concurrent = want_pure && !env.no_consistency && ps_env && !strcmp(ps_env, "concurrent");
         Batch b2(ctx, d_frames, n, true);
         for (size_t f = 0; f < n; f++) {
             if (jobs[f].const_field) continue;
-            jobs[f].rs.start(cfg->base_cr, jobs[f].q, q_target);
-            if (concurrent) { jobs[f].rs2.start(cfg->base_cr, jobs[f].q, 1.0); b2.jf[f] = b.jf[f]; }
+            jobs[f].rs[0].start(cfg->base_cr, jobs[f].q, q_target);
+            if (concurrent) { jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0); b2.jf[f] = b.jf[f]; }
         }
-        run_searches(b, concurrent ? &b2 : nullptr, jobs, n_pix);
+        run_searches(&b, concurrent ? &b2 : nullptr, jobs, n_pix);
         for (size_t f = 0; f < n; f++) {
             b.active[f] = jobs[f].const_field ? 0 : 1;
-            if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs.result; jobs[f].len1 = (size_t) b.jf[f].stream_bytes; }
+            if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
         }
         pt.mark("rate search 1");
         b.collect_tails(jobs);                                                                // base layer of search #1
@@ -516,27 +596,36 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)
         if (want_pure) {
-            Batch &bp = concurrent ? b2 : b;
             if (!concurrent) {
-                for (size_t f = 0; f < n; f++)
-                    if (!jobs[f].const_field) jobs[f].rs.start(jobs[f].cr, jobs[f].q, 1.0);   // consistency off: from search #1's state
-                run_searches(b, nullptr, jobs, n_pix);                                        // :836
+                for (size_t f = 0; f < n; f++) {
+                    if (jobs[f].const_field) continue;
+                    if (env.no_consistency) jobs[f].rs[1].start(jobs[f].cr, jobs[f].q, 1.0);  // from search #1's state
+                    else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);             // :829-833 == the first probe
+                }
+                run_searches((Batch *) nullptr, &b, jobs, n_pix);                             // :836
             }
             zjoin();
+            bool any_pure = false;
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
-                bp.active[f] = 0;
+                b.active[f] = 0;
                 if (j.const_field) continue;
-                const size_t len2 = (size_t) bp.jf[f].stream_bytes;
+                const size_t len2 = (size_t) j.last[1].stream_bytes;
                 if (len2 < j.zbytes.size() + j.len1 || j.need_pure) {                         // :838
                     if (len2 < j.zbytes.size() + j.len1)
                         log_info("frame %zu: pure base compression (%zu) beats base (%zu) + residual (%zu)", f, len2, j.len1, j.zbytes.size());
-                    j.mean_err = bp.jf[f].err_sum / (double) n_pix;                           // :843
+                    j.mean_err = j.last[1].err_sum / (double) n_pix;                          // :843
                     j.zbytes.clear(); j.coeffs_size = 0;
-                    bp.active[f] = 1;
+                    b.active[f] = 1; b.jf[f].cr = j.rs[1].result; any_pure = true;
                 }
             }
-            bp.collect_tails(jobs);
+            if (any_pure) {
+                // the layer assignment of that rate again (allocation only, no decode), then its codestream
+                b.push_jf();
+                b.push_active();
+                launch_j2k_rate(jb, (int) n, b.d_active, s);
+                b.collect_tails(jobs);
+            }
         }
         zjoin();
     }

@@ -20,7 +20,8 @@ void j2k_inverse_dwt(float *B, const J2kGeom &g, int n_frames, const FrameState 
 namespace {
 
 constexpr int kMainHeaderBytes = 135;
-constexpr int kRateThreads = 64;
+constexpr int kRateThreads = 512;     // k_rate: one workgroup per frame, about one code-block per thread
+constexpr int kWriteThreads = 64;     // k_write: one wave per frame
 
 __device__ inline int floorlog2d(int a) { return a > 1 ? 31 - __clz(a) : 0; }
 
@@ -163,9 +164,10 @@ __device__ inline void tree_setmin(const J2kBand &bd, short *val, int cx, int cy
 }
 
 // static part: node minima of Mb - numbps over ALL code-blocks (opj_tgt_setvalue for every cblk)
+template <int NT>
 __device__ void trees_static(const J2kGeom &g, RateLds &L, const int *numbps, int gid0, int lane)
 {
-    for (int i = lane; i < g.tree_nodes; i += kRateThreads) L.mval0[i] = 999;
+    for (int i = lane; i < g.tree_nodes; i += NT) L.mval0[i] = 999;
     __syncthreads();
     if (lane < g.nbands) {                                           // one lane per band: sequential min propagation
         const J2kBand &bd = g.bands[lane];
@@ -176,9 +178,10 @@ __device__ void trees_static(const J2kGeom &g, RateLds &L, const int *numbps, in
     __syncthreads();
 }
 
+template <int NT>
 __device__ void trees_reset(const J2kGeom &g, RateLds &L, int lane)
 {
-    for (int i = lane; i < g.tree_nodes; i += kRateThreads) {
+    for (int i = lane; i < g.tree_nodes; i += NT) {
         L.t.ival[i] = 999; L.t.ilow[i] = 0; L.t.iknown[i] = 0;
         L.t.mval[i] = L.mval0[i]; L.t.mlow[i] = 0; L.t.mknown[i] = 0;
     }
@@ -193,33 +196,42 @@ __device__ void trees_reset(const J2kGeom &g, RateLds &L, int lane)
 }
 
 // opj_tcd_makelayer for one quality layer
+template <int NT>
 __device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const int *rates, const double *disto,
                            int gid0, double thresh, int lane)
 {
-    for (int b = lane; b < g.nblocks; b += kRateThreads) {
+    for (int b = lane; b < g.nblocks; b += NT) {
         const int tp = totalpasses[gid0 + b];
         const int *rt = rates + (size_t) (gid0 + b) * kJ2kMaxPasses;
         const double *ds = disto + (size_t) (gid0 + b) * kJ2kMaxPasses;
         int n = 0;
         if (thresh < 0) n = tp;
-        else
+        else {
+            int rbase = 0;                                           // rate / distortion of the last pass taken
+            double dbase = 0;
             for (int p = 0; p < tp; p++) {
+                const int rp = rt[p];
+                const double dp = ds[p];
                 unsigned int dr;
                 double dd;
-                if (n == 0) { dr = (unsigned int) rt[p]; dd = ds[p]; }
-                else { dr = (unsigned int) (rt[p] - rt[n - 1]); dd = ds[p] - ds[n - 1]; }
-                if (!dr) { if (dd != 0) n = p + 1; continue; }
-                if (thresh - (dd / dr) < DBL_EPSILON) n = p + 1;
+                if (n == 0) { dr = (unsigned int) rp; dd = dp; }
+                else { dr = (unsigned int) (rp - rbase); dd = dp - dbase; }
+                bool take;
+                if (!dr) take = dd != 0;
+                else take = thresh - (dd / dr) < DBL_EPSILON;
+                if (take) { n = p + 1; rbase = rp; dbase = dp; }
             }
+        }
         L.npass[b] = (short) n;
     }
     __syncthreads();
 }
 
 // total packet bytes of the current assignment (one lane per resolution)
+template <int NT>
 __device__ int layer_bytes(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum)
 {
-    trees_reset(g, L, lane);
+    trees_reset<NT>(g, L, lane);
     if (lane == 0) *s_sum = 0;
     __syncthreads();
     if (lane < kJ2kRes) {
@@ -266,15 +278,16 @@ __device__ inline unsigned int raw_byte(const unsigned int *raw, int pos)
     return (unsigned int) ((x << sh) >> 56);
 }
 
-__device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum, int *s_tmp)
+template <int NT>
+__device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum)
 {
     const int INF = 0x7FFFFFFF;
-    for (int i = lane; i < g.tree_nodes; i += kRateThreads) L.firstinc[i] = INF;
-    for (int i = lane; i < g.nblocks * 4 + 4; i += kRateThreads) L.raw[i] = 0;
+    for (int i = lane; i < g.tree_nodes; i += NT) L.firstinc[i] = INF;
+    for (int i = lane; i < g.nblocks * 4 + 4; i += NT) L.raw[i] = 0;
     if (lane == 0) *s_sum = 0;
     __syncthreads();
     // first included leaf below every node
-    for (int b = lane; b < g.nblocks; b += kRateThreads) {
+    for (int b = lane; b < g.nblocks; b += NT) {
         if (!L.npass[b]) continue;
         // band of the block: bands are few, find by first_block
         int bi = 0;
@@ -284,10 +297,11 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
         for (int l = 0; l < bd.tree_levels; l++)
             atomicMin(&L.firstinc[bd.tree_off + bd.lvl_off[l] + (cy >> l) * bd.lvl_w[l] + (cx >> l)], k);
     }
+    if (lane < kJ2kRes) atomicOr(&L.raw[(g.res_first[lane] * 128) >> 5], 0x80000000u);   // leading "packet present" bit
     __syncthreads();
     // per-leaf header bits: A = inclusion + zero-bit-plane bits, B = passes + Lblock comma code + length
     int body = 0;
-    for (int base = 0; base < g.nblocks; base += kRateThreads) {
+    for (int base = 0; base < g.nblocks; base += NT) {
         const int b = base + lane;
         unsigned long long A = 0, B = 0;
         int na = 0, nbb = 0, res = 0;
@@ -344,25 +358,22 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
         __syncthreads();
     }
     for (int d = 32; d >= 1; d >>= 1) body += __shfl_xor(body, d);
-    // stuffing-aware byte count per resolution
-    int total = body;
-    for (int r = 0; r < kJ2kRes; r++) {
+    // stuffing-aware byte count: one wave per resolution (the search for the next 0xFF byte is a chain)
+    const int wl = lane & 63;
+    int count = 0;
+    for (int r = lane >> 6; r < kJ2kRes; r += NT / 64) {
         const int region = g.res_first[r] * 128;
-        if (lane == 0) {
-            atomicOr(&L.raw[region >> 5], 0x80000000u);                            // leading bit = 1
-            int T = 1;
-            for (int j = g.res_first[r]; j < g.res_first[r + 1]; j++) T += L.leafbits[j];
-            *s_tmp = T;
-        }
-        __syncthreads();
-        const int T = *s_tmp;
-        int p = 0, count = 0;
+        int T = 0;
+        for (int j = g.res_first[r] + wl; j < g.res_first[r + 1]; j += 64) T += L.leafbits[j];
+        for (int d = 32; d >= 1; d >>= 1) T += __shfl_xor(T, d);
+        T += 1;
+        int p = 0;
         for (;;) {
             // first full byte == 0xFF at or after bit p (8-bit groups)
             const int groups = (T - p) >> 3;                                       // full bytes available
             int found = -1;
-            for (int j0 = 0; j0 < groups && found < 0; j0 += kRateThreads) {
-                const int j = j0 + lane;
+            for (int j0 = 0; j0 < groups && found < 0; j0 += 64) {
+                const int j = j0 + wl;
                 const bool hit = j < groups && raw_byte(L.raw, region + p + 8 * j) == 0xFFu;
                 const unsigned long long m = __ballot(hit);
                 if (m) found = j0 + (__ffsll((long long) m) - 1);
@@ -372,9 +383,11 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
             p += 8 * (found + 1) + 7;
             if (p >= T) break;
         }
-        total += count;
-        __syncthreads();
     }
+    if (wl == 0) atomicAdd(s_sum, body + count);
+    __syncthreads();
+    const int total = *s_sum;
+    __syncthreads();
     return total;
 }
 
@@ -387,15 +400,15 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                                                         const FrameState *fs, const int *active)
 {
     extern __shared__ unsigned char lds_raw[];
-    __shared__ int s_sum, s_tmp, s_changed;
-    __shared__ double s_min[kRateThreads], s_max[kRateThreads];
+    __shared__ int s_sum, s_changed;
+    __shared__ double s_min[kRateThreads / 64], s_max[kRateThreads / 64];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const J2kGeom &g = *geom;
     const int gid0 = frame * g.nblocks;
     RateLds L;
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
-    trees_static(g, L, numbps, gid0, lane);
+    trees_static<kRateThreads>(g, L, numbps, gid0, lane);
     for (int b = lane; b < g.nblocks; b += kRateThreads) L.prev[b] = -1;
     int prev_bytes = 0;
     // size of the current assignment; identical assignments (late bisection steps) reuse the previous result
@@ -408,12 +421,12 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         __syncthreads();
         if (s_changed) {
 #ifdef EBCC_RATE_CHECK
-            const int ref = layer_bytes(g, L, rates, gid0, lane, &s_sum);
-            prev_bytes = layer_bytes_fast(g, L, rates, gid0, lane, &s_sum, &s_tmp);
+            const int ref = layer_bytes<kRateThreads>(g, L, rates, gid0, lane, &s_sum);
+            prev_bytes = layer_bytes_fast<kRateThreads>(g, L, rates, gid0, lane, &s_sum);
             if (ref != prev_bytes && lane == 0) { printf("rate check: frame %d fast %d serial %d\n", frame, prev_bytes, ref); }
             prev_bytes = ref;
 #else
-            prev_bytes = layer_bytes_fast(g, L, rates, gid0, lane, &s_sum, &s_tmp);
+            prev_bytes = layer_bytes_fast<kRateThreads>(g, L, rates, gid0, lane, &s_sum);
 #endif
         }
         return prev_bytes;
@@ -443,9 +456,13 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             if (sl > mx) mx = sl;
         }
     }
-    s_min[lane] = mn; s_max[lane] = mx;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+        mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+    }
+    if ((lane & 63) == 0) { s_min[lane >> 6] = mn; s_max[lane >> 6] = mx; }
     __syncthreads();
-    for (int i = 0; i < kRateThreads; i++) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
+    for (int i = 0; i < kRateThreads / 64; i++) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
 
     double good = -1;                                                // rate 0: every pass
     if (rate > 0.0f) {
@@ -455,7 +472,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             thresh = (lo + hi) / 2;
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
-            make_layer(g, L, totalpasses, rates, disto, gid0, thresh, lane);
+            make_layer<kRateThreads>(g, L, totalpasses, rates, disto, gid0, thresh, lane);
             const int bytes = sized();
             if ((long long) bytes > maxlen) { lo = thresh; continue; }
             hi = thresh;
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         }
         good = stable == 0 ? thresh : stable;
     }
-    make_layer(g, L, totalpasses, rates, disto, gid0, good, lane);
+    make_layer<kRateThreads>(g, L, totalpasses, rates, disto, gid0, good, lane);
     const int body = sized();
     for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
     if (lane == 0) {
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
 __device__ inline void put16(uint8_t *&p, unsigned v) { *p++ = (uint8_t) (v >> 8); *p++ = (uint8_t) v; }
 __device__ inline void put32(uint8_t *&p, unsigned v) { put16(p, v >> 16); put16(p, v & 0xFFFFu); }
 
-__global__ __launch_bounds__(kRateThreads) void k_write(const int *__restrict__ numbps, const int *__restrict__ rates,
+__global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__ numbps, const int *__restrict__ rates,
                                                          const int *__restrict__ npass_in, const uint8_t *__restrict__ cblk_bytes,
                                                          uint8_t *__restrict__ stream, size_t stream_cap, const J2kGeom *geom,
                                                          J2kFrame *jf, const FrameState *fs, const int *active)
@@ -492,13 +509,13 @@ __global__ __launch_bounds__(kRateThreads) void k_write(const int *__restrict__ 
     const int gid0 = frame * g.nblocks;
     RateLds L;
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
-    trees_static(g, L, numbps, gid0, lane);
-    for (int b = lane; b < g.nblocks; b += kRateThreads) L.npass[b] = (short) npass_in[gid0 + b];
+    trees_static<kWriteThreads>(g, L, numbps, gid0, lane);
+    for (int b = lane; b < g.nblocks; b += kWriteThreads) L.npass[b] = (short) npass_in[gid0 + b];
     __syncthreads();
     uint8_t *base = stream + (size_t) frame * stream_cap;
 
     // pass 1: sizes
-    trees_reset(g, L, lane);
+    trees_reset<kWriteThreads>(g, L, lane);
     if (lane < kJ2kRes) { int body = 0; s_hdr[lane] = packet_header(lane, g, L.t, L.npass, rates, gid0, nullptr, &body); s_body[lane] = body; }
     __syncthreads();
     if (lane == 0) {
@@ -508,7 +525,7 @@ __global__ __launch_bounds__(kRateThreads) void k_write(const int *__restrict__ 
     }
     __syncthreads();
     // pass 2: headers
-    trees_reset(g, L, lane);
+    trees_reset<kWriteThreads>(g, L, lane);
     if (lane < kJ2kRes) { int body = 0; packet_header(lane, g, L.t, L.npass, rates, gid0, base + s_off[lane], &body); }
     // bodies: every lane copies code-block segments; offsets by a serial walk per resolution (cheap)
     __syncthreads();
@@ -847,7 +864,7 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
 
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_write, dim3(n_frames), dim3(kRateThreads), rate_lds(jb.geom), s, jb.numbps, jb.rates, jb.npass,
+    hipLaunchKernelGGL(k_write, dim3(n_frames), dim3(kWriteThreads), rate_lds(jb.geom), s, jb.numbps, jb.rates, jb.npass,
                        jb.cblk_bytes, jb.stream, jb.stream_cap, jb.d_geom, jb.jf, jb.fs, d_active);
 }
 

@@ -36,7 +36,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->SUF = ctx_alloc<unsigned long long>(ctx, groups * (kJ2kMaxPlanes + 2) * 64 * 64)) != nullptr;
     ok &= (jb->SPS = ctx_alloc<unsigned long long>(ctx, groups * 64 * 64)) != nullptr;
     ok &= (jb->VISP = ctx_alloc<unsigned long long>(ctx, groups * kJ2kMaxPlanes * 64 * 64)) != nullptr;
-    ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kMaxPasses * 40)) != nullptr;
+    ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kCkptPerBlock * 40)) != nullptr;
     ok &= (jb->qplane = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;
     ok &= (jb->blkmax = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;

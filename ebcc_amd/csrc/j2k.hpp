@@ -45,6 +45,32 @@ struct J2kGeom {
     J2kBand bands[kJ2kBands];
 };
 
+constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
+
+// Checkpoint storage: structure of arrays, lane-interleaved like the tier-1 state, so that the 64 code-blocks
+// of a group - which reach the same (pass, stripe) together - store one slot with coalesced writes.
+//   group base + field array + slot * 64 + lane
+struct J2kCkptView {
+    std::uint32_t *a, *c;          // [slots][64]
+    int *ct, *pos;
+    unsigned long long *w0, *w1, *w2;
+    __host__ __device__ static size_t group_bytes() { return (size_t) kJ2kCkptPerBlock * 64 * 40; }
+    __host__ __device__ static J2kCkptView of(void *base, size_t group, int lane)
+    {
+        unsigned char *g = (unsigned char *) base + group * group_bytes();
+        const size_t n = (size_t) kJ2kCkptPerBlock * 64;
+        J2kCkptView v;
+        v.w0 = (unsigned long long *) g + lane;
+        v.w1 = v.w0 + n;
+        v.w2 = v.w1 + n;
+        v.a = (std::uint32_t *) ((unsigned long long *) g + 3 * n) + lane;
+        v.c = v.a + n;
+        v.ct = (int *) (v.c + n);
+        v.pos = v.ct + n;
+        return v;
+    }
+};
+
 struct J2kFrame {                 // per-frame scalars (device)
     float cr;                     // rate of the current probe
     float target;                 // error target of the current search
@@ -70,7 +96,7 @@ struct J2kBuffers {
     unsigned long long *SUF;      // [groups][planes+2][64][64] suffix-OR of BP over planes >= p (significance above a plane)
     unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
     unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
-    void *ckpt;                   // [frames*nblocks][passes] MQ-decoder checkpoints at every coding-pass start
+    void *ckpt;                   // [frames*nblocks][passes][16 stripes] MQ-decoder checkpoints at every stripe start of every coding pass
     int *qplane;                  // [frames*nblocks] coding pass at which the current probe's decode restarts (-1: nothing)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
     int *blkmax;                  // [frames*nblocks] max |q6|

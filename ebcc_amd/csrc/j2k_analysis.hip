@@ -5,6 +5,7 @@
 // OpenJPEG runs all of this inside every opj_encode call; the reference calls opj_encode ~22 times per
 // frame with different rates (/root/reference/src/ebcc_codec.c:545-596).  None of it depends on the
 // rate, so here it runs once per frame.
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -28,14 +29,19 @@ static const double kNormsReal[4][10] = {
 
 int t1_lanes_per_wave(int kernel)
 {
-    static int override_v = [] {
-        const char *e = getenv("EBCC_T1_LPW");
-        int x = e ? atoi(e) : 0;
-        return (x == 8 || x == 16 || x == 32 || x == 64) ? x : 0;
+    // EBCC_T1_LPW = "<n>" (all kernels) or "<encode>,<unused>,<probe restart>,<decode>", each 8, 16, 32 or 64
+    static const std::array<int, 4> table = [] {
+        std::array<int, 4> t = {32, 32, 16, 8};
+        if (const char *e = getenv("EBCC_T1_LPW")) {
+            int v[4], n = sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+            for (int i = 0; i < 4; i++) {
+                const int x = n == 1 ? v[0] : (i < n ? v[i] : 0);
+                if (x == 8 || x == 16 || x == 32 || x == 64) t[i] = x;
+            }
+        }
+        return t;
     }();
-    if (override_v) return override_v;
-    static const int defaults[4] = {32, 32, 16, 8};
-    return defaults[kernel & 3];
+    return table[kernel & 3];
 }
 
 J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
@@ -446,18 +452,24 @@ struct LdsTable {
 // ================================================================================================
 // tier-1 encoder: one code-block per lane (t1_core.hpp)
 // ================================================================================================
+// All per-code-block arrays are lane-interleaved inside a group of 64 code-blocks, and a wave never straddles
+// two groups, so every access is (group base: uniform, lives in SGPRs) + (32-bit lane offset: one VGPR) -
+// the saddr + voffset form of the global instructions - instead of a 64-bit pointer per lane and array.
 struct DevStore {
-    unsigned long long *st;       // group base of the state words, lane offset already applied
-    const unsigned long long *bp; // group base of the bit-plane masks, lane offset applied
-    const unsigned long long *sg;
-    unsigned long long *sps;      // group base of the propagation-significance masks, lane offset applied
-    __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
-    __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
-    __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
-    __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
-    __device__ unsigned long long &SPS(int y) { return sps[(size_t) y * 64]; }
-    __device__ unsigned long long SGN(int y) const { return y < 64 ? sg[(size_t) y * 64] : 0ull; }
-    __device__ unsigned long long BP(int plane, int y) const { return y < 64 ? bp[((size_t) plane * 64 + y) * 64] : 0ull; }
+    unsigned char *st;            // group base of the state words
+    const unsigned char *bp;      // group base of the bit-plane masks
+    const unsigned char *sg;
+    unsigned char *sps;           // group base of the propagation-significance masks
+    uint32_t lane8;               // lane * 8
+    __device__ unsigned long long &at(unsigned char *b, int row) const { return *(unsigned long long *) (b + ((uint32_t) row * 512u + lane8)); }
+    __device__ unsigned long long ld(const unsigned char *b, int row) const { return *(const unsigned long long *) (b + ((uint32_t) row * 512u + lane8)); }
+    __device__ unsigned long long &S(int y) { return at(st, y + 1); }
+    __device__ unsigned long long &NEG(int y) { return at(st, 66 + y); }
+    __device__ unsigned long long &VIS(int y) { return at(st, 130 + y); }
+    __device__ unsigned long long &REF(int y) { return at(st, 194 + y); }
+    __device__ unsigned long long &SPS(int y) { return at(sps, y); }
+    __device__ unsigned long long SGN(int y) const { return y < 64 ? ld(sg, y) : 0ull; }
+    __device__ unsigned long long BP(int plane, int y) const { return y < 64 ? ld(bp, plane * 64 + y) : 0ull; }
 };
 struct DevSink {
     uint8_t *p; int cap; int *overflow;
@@ -468,19 +480,39 @@ struct DevAt {
     __device__ uint8_t operator()(int i) const { return i < cap ? p[i] : (uint8_t) 0; }
 };
 
-// MQ-decoder checkpoints for the rate probes: the decoder registers at the start of every coding pass (and the
-// visited masks after every propagation pass) so that a probe restarts at the last pass it keeps
-// (j2k_rate.hip).  They are derived from the encoder's own registers - see t1::finalize_checkpoints - so no
+// MQ-decoder checkpoints for the rate probes: the decoder registers at the start of every stripe of every
+// coding pass (and the visited masks after every propagation pass) so that a probe restarts a stripe or two
+// before the point where its truncated segment ends (j2k_rate.hip).  They are derived from the encoder's own registers - see t1::finalize_checkpoints - so no
 // decode of the segment is needed.
 struct CkObserver {
-    t1::MqCheckpoint *ck;          // [passes] of this code-block
-    unsigned long long *visp;      // group base of the per-plane visited masks, lane offset applied
+    unsigned char *ck;             // group base of the checkpoint arrays (J2kCkptView layout)
+    unsigned char *visp;           // group base of the per-plane visited masks
+    uint32_t lane8;                // lane * 8
+    int cur = 0;
+    static constexpr uint32_t kN = (uint32_t) kJ2kCkptPerBlock * 64;     // elements per field array
+    __device__ unsigned long long &w(int k, uint32_t slot) const { return *(unsigned long long *) (ck + ((kN * k + slot * 64u) * 8u + lane8)); }
+    __device__ uint32_t &u(int k, uint32_t slot) const { return *(uint32_t *) (ck + (kN * 24u + (kN * k + slot * 64u) * 4u + (lane8 >> 1))); }
     template <class Mq>
-    __device__ void pass_start(int p, const Mq &m) { ck[p] = t1::encoder_checkpoint(m); }
+    __device__ void pass_start(int p, const Mq &) { cur = p * 16; }
+    template <class Mq>
+    __device__ void stripe_start(int y0, const Mq &m)
+    {
+        const uint32_t i = (uint32_t) (cur + (y0 >> 2));
+        u(0, i) = m.a; u(1, i) = m.c & 0xFFFFu; u(3, i) = m.shifts;
+        w(0, i) = m.cx.w0; w(1, i) = m.cx.w1; w(2, i) = m.cx.w2;
+    }
+    // CkArray of t1::finalize_checkpoints
+    __device__ uint32_t shifts(int p, int s) const { return u(3, (uint32_t) (p * 16 + s)); }
+    __device__ uint32_t c16(int p, int s) const { return u(1, (uint32_t) (p * 16 + s)); }
+    __device__ void finish(int p, int s, uint32_t c, int ct, int pos)
+    {
+        const uint32_t i = (uint32_t) (p * 16 + s);
+        u(1, i) = c; u(2, i) = (uint32_t) ct; u(3, i) = (uint32_t) pos;
+    }
     template <class Store>
     __device__ void sigprop_done(int bp, Store &st)
     {
-        for (int y = 0; y < 64; y++) visp[((size_t) bp * 64 + y) * 64] = st.VIS(y);
+        for (int y = 0; y < 64; y++) *(unsigned long long *) (visp + ((uint32_t) (bp * 64 + y) * 512u + lane8)) = st.VIS(y);
     }
 };
 struct CkSrc {
@@ -499,13 +531,14 @@ struct CkSrc {
 __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const unsigned long long *BP,
                                                    const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax, int *numbps,
                                                    int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes,
-                                                   t1::MqCheckpoint *ckpt, unsigned long long *VISP,
+                                                   void *ckpt, unsigned long long *VISP,
                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
                                                    J2kFrame *jf, int total, int lpw)
 {
     EBCC_LDS_MQ_TABLE(tab);
     if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int gid = blockIdx.x * lpw + threadIdx.x;
+    const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
+    const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -516,18 +549,18 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     int P = m ? (31 - __clz(m)) + 1 - 6 : 0;                         // opj_t1_encode_cblk: numbps
     numbps[gid] = P;
     if (P <= 0) { totalpasses[gid] = 0; cblk_len[gid] = 0; return; }
-    const size_t grp = (size_t) (gid >> 6);
-    const int gl = gid & 63;
-    DevStore st{T1S + grp * kT1StateWords * 64 + gl, BP + grp * kJ2kMaxPlanes * 64 * 64 + gl, SGN + grp * 64 * 64 + gl,
-                SPS + grp * 64 * 64 + gl};
+    const size_t grp = (size_t) (gid0 >> 6);
+    const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
+    DevStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64),
+                (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (SPS + grp * 64 * 64), lane8};
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    CkObserver obs{ckpt + (size_t) gid * kJ2kMaxPasses, VISP + grp * kJ2kMaxPlanes * 64 * 64 + gl};
+    CkObserver obs{(unsigned char *) ckpt + grp * J2kCkptView::group_bytes(), (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
     t1::EncodeResult r = t1::encode_block_observed(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
                                                    blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, obs, tab);
     totalpasses[gid] = r.totalpasses;
     cblk_len[gid] = r.length;
     __threadfence();                                                    // the sweep below re-reads this lane's own bytes
-    t1::finalize_checkpoints(obs.ck, r.totalpasses, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
+    t1::finalize_checkpoints(obs, r.totalpasses, (blk.h + 3) >> 2, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
 }
 
 // ================================================================================================
@@ -648,7 +681,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     int lpw = t1_lanes_per_wave(T1_ENCODE);
     unsigned t1_grid = (unsigned) ceil_div(total, lpw);
     hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, (t1::MqCheckpoint *) jb.ckpt, jb.VISP, jb.d_geom,
+                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.VISP, jb.d_geom,
                        jb.d_blocks, fs, jb.jf, total, lpw);
     timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,

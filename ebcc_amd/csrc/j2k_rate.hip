@@ -643,23 +643,25 @@ struct LdsTable {
 // true decode: tier-1 MQ decoding, one code-block per lane, values scattered into V (half units)
 // ================================================================================================
 struct DecStore {
-    unsigned long long *st;
+    unsigned char *st; // group base of the state words (uniform: a wave stays inside one group of 64 code-blocks)
+    uint32_t lane8;    // lane * 8
     int32_t *v;        // tile-buffer position of the block's (0,0)
     int W;
-    __device__ unsigned long long &S(int y) { return st[(size_t) (y + 1) * 64]; }
-    __device__ unsigned long long &NEG(int y) { return st[(size_t) (66 + y) * 64]; }
-    __device__ unsigned long long &VIS(int y) { return st[(size_t) (130 + y) * 64]; }
-    __device__ unsigned long long &REF(int y) { return st[(size_t) (194 + y) * 64]; }
+    __device__ unsigned long long &at(int row) const { return *(unsigned long long *) (st + ((uint32_t) row * 512u + lane8)); }
+    __device__ unsigned long long &S(int y) { return at(y + 1); }
+    __device__ unsigned long long &NEG(int y) { return at(66 + y); }
+    __device__ unsigned long long &VIS(int y) { return at(130 + y); }
+    __device__ unsigned long long &REF(int y) { return at(194 + y); }
     __device__ void set_sig(int x, int y, int neg, int plane)
     {
         int one = 1 << (plane + 1), val = one | (one >> 1);
-        v[(size_t) y * W + x] = neg ? -val : val;
+        v[y * W + x] = neg ? -val : val;
     }
     __device__ void refine(int x, int y, int bit, int plane, int neg)
     {
         // the sign is known from the NEG row mask, so the update is a fire-and-forget atomic add (no load stall)
         const int half = 1 << plane;
-        atomicAdd(&v[(size_t) y * W + x], (bit ^ neg) ? half : -half);
+        atomicAdd(&v[y * W + x], (bit ^ neg) ? half : -half);
     }
 };
 struct DecSrc {
@@ -693,7 +695,8 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
 {
     EBCC_LDS_MQ_TABLE(tab);
     if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int gid = blockIdx.x * lpw + threadIdx.x;
+    const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
+    const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -711,8 +714,8 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
     }
     if (np <= 0 || P <= 0) return;
     const J2kBlock blk = blocks[bi];
-    const size_t grp = (size_t) (gid >> 6);
-    DecStore st{T1S + grp * kT1StateWords * 64 + (gid & 63),
+    const size_t grp = (size_t) (gid0 >> 6);
+    DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u,
                 V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
     t1::decode_block(st, DecSrc{src, len}, blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
 }
@@ -729,21 +732,31 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
 //                  registers from the checkpoint, then only passes r .. n-1 on the truncated bytes
 // ================================================================================================
 __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restrict__ npass, const int *__restrict__ rates,
-                             const t1::MqCheckpoint *__restrict__ ckpt, int *__restrict__ rpass, const J2kGeom *geom,
-                             const FrameState *fs, const int *active, int total)
+                             void *ckpt, int *__restrict__ rpass, const J2kGeom *geom,
+                             const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int frame = gid / geom->nblocks;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const int n = npass[gid], P = numbps[gid];
-    int r = -1;
+    int plan = -1;
     if (n > 0 && P > 0) {
         const int len = rates[(size_t) gid * kJ2kMaxPasses + n - 1];
-        r = n - 1;
-        while (r > 0 && ckpt[(size_t) gid * kJ2kMaxPasses + r].pos + 1 >= len) r--;
+        const int nstr = (blocks[gid - frame * geom->nblocks].h + 3) >> 2;
+        const J2kCkptView ck = J2kCkptView::of(ckpt, (size_t) (gid >> 6), gid & 63);
+        // latest checkpoint taken before the decoder touched a byte at/after the truncation point (pos is
+        // non-decreasing in coding order); slot 0 is the initial state and always usable
+        int lo = 0, hi = n * nstr - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const int mp = mid / nstr, ms = mid - mp * nstr;
+            if (ck.pos[(size_t) (mp * 16 + ms) * 64] + 1 < len) lo = mid; else hi = mid - 1;
+        }
+        const int r = lo / nstr, st = lo - r * nstr;
+        plan = r | (st << 8);
     }
-    rpass[gid] = r;
+    rpass[gid] = plan;
 }
 
 __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ Q6, const int *__restrict__ rpass,
@@ -761,15 +774,17 @@ __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ 
     const int gid0 = frame * geom->nblocks;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
         const int bi = blkmap[i], gid = gid0 + bi;
-        const int r = rpass[gid];
+        const int plan = rpass[gid];
         const int q6 = q[i];
         const unsigned int a = (unsigned int) (q6 < 0 ? -q6 : q6) >> 6;
         int out = 0;
-        if (r > 0 && a) {
+        if (plan > 0 && a) {
             const int P = numbps[gid];
             const int bs = 31 - __clz(a);
             const J2kBlock blk = blocks[bi];
             const int y = (int) (i / W), x = (int) (i - (size_t) y * W);
+            // rows above the restart stripe have already been through pass r
+            const int r = (plan & 0xFF) + ((y - blk.y) < 4 * (plan >> 8) ? 1 : 0);
             const unsigned long long sps = SPS[(((size_t) (gid >> 6)) * 64 + (y - blk.y)) * 64 + (gid & 63)];
             const int ps = bs == P - 1 ? 0 : 3 * (P - 1 - bs) - (((sps >> (x - blk.x)) & 1ull) ? 2 : 0);
             if (ps < r) {
@@ -789,49 +804,56 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
                                                    const unsigned long long *SUF, const unsigned long long *SGN,
                                                    const unsigned long long *SPS, const unsigned long long *VISP,
                                                    const uint8_t *cblk_bytes, const int *numbps, const int *npass,
-                                                   const int *rates, const int *rpass, const t1::MqCheckpoint *ckpt, int32_t *V,
+                                                   const int *rates, const int *rpass, void *ckpt, int32_t *V,
                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
                                                    const int *active, int total, int lpw)
 {
     EBCC_LDS_MQ_TABLE(tab);
     if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int gid = blockIdx.x * lpw + threadIdx.x;
+    const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
+    const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
     if ((active && !active[frame]) || fs[frame].const_field) return;
-    const int r = rpass[gid];
-    if (r < 0) return;
+    const int plan = rpass[gid];
+    if (plan < 0) return;
+    const int r = plan & 0xFF, stripe = plan >> 8;
     const int np = npass[gid], P = numbps[gid];
     const int len = rates[(size_t) gid * kJ2kMaxPasses + np - 1];
     const J2kBlock blk = blocks[bi];
-    const size_t grp = (size_t) (gid >> 6);
-    const int gl = gid & 63;
-    DecStore st{T1S + grp * kT1StateWords * 64 + gl, V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x,
-                geom->W};
-    // decoder state at the start of pass r = (plane p, type t); see DESIGN.md section 3
-    const int p = t1::plane_of_pass(P, r), t = r == 0 ? 0 : t1::type_of_pass(r);
-    const unsigned long long *suf1 = SUF + ((grp * (kJ2kMaxPlanes + 2) + p + 1) * 64) * 64 + gl;
-    const unsigned long long *suf2 = SUF + ((grp * (kJ2kMaxPlanes + 2) + p + 2) * 64) * 64 + gl;
-    const unsigned long long *bpp = BP + ((grp * kJ2kMaxPlanes + p) * 64) * 64 + gl;
-    const unsigned long long *visp = VISP + ((grp * kJ2kMaxPlanes + p) * 64) * 64 + gl;
+    const size_t grp = (size_t) (gid0 >> 6);
+    const int gl = (gid0 & 63) + threadIdx.x;
+    DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (uint32_t) gl * 8u,
+                V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
+    // Decoder state when pass r reaches the restart stripe: rows above it are as at the start of pass r + 1,
+    // the rest as at the start of pass r.  Only the rows the remaining stripes can
+    // see are needed when no further pass follows, but all 64 are cheap next to the decode.
     const unsigned long long *sg = SGN + grp * 64 * 64 + gl;
     const unsigned long long *sps = SPS + grp * 64 * 64 + gl;
     for (int y = 0; y < 64; y++) {
         unsigned long long S = 0, R = 0, Vv = 0;
-        if (y < blk.h && r > 0) {
-            const unsigned long long s1 = suf1[(size_t) y * 64];
+        const int q = r + (y < 4 * stripe ? 1 : 0);
+        if (y < blk.h && q > 0) {
+            const int p = t1::plane_of_pass(P, q), t = t1::type_of_pass(q);
+            const unsigned long long s1 = SUF[((grp * (kJ2kMaxPlanes + 2) + p + 1) * 64 + y) * 64 + gl];
             S = s1;
-            if (t >= 1) { S |= sps[(size_t) y * 64] & bpp[(size_t) y * 64] & ~s1; Vv = visp[(size_t) y * 64]; }
-            R = t == 2 ? s1 : suf2[(size_t) y * 64];
+            if (t >= 1) {
+                S |= sps[(size_t) y * 64] & BP[((grp * kJ2kMaxPlanes + p) * 64 + y) * 64 + gl] & ~s1;
+                Vv = VISP[((grp * kJ2kMaxPlanes + p) * 64 + y) * 64 + gl];
+            }
+            R = t == 2 ? s1 : SUF[((grp * (kJ2kMaxPlanes + 2) + p + 2) * 64 + y) * 64 + gl];
         }
         st.S(y) = S;
         st.NEG(y) = S ? (sg[(size_t) y * 64] & S) : 0ull;
         st.REF(y) = R;
         st.VIS(y) = Vv;
     }
+    const J2kCkptView cv = J2kCkptView::of(ckpt, grp, gl);
+    const size_t ci = (size_t) (r * 16 + stripe) * 64;
+    const t1::MqCheckpoint ck{cv.a[ci], cv.c[ci], cv.ct[ci], cv.pos[ci], cv.w0[ci], cv.w1[ci], cv.w2[ci]};
     t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
-                      np, r, ckpt[(size_t) gid * kJ2kMaxPasses + r], tab);
+                      np, r, stripe, ck, tab);
 }
 
 __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, const std::uint16_t *__restrict__ blkmap,
@@ -888,9 +910,9 @@ static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, c
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
     const int total = n_frames * jb.geom.nblocks;
-    const t1::MqCheckpoint *ck = (const t1::MqCheckpoint *) jb.ckpt;
+    void *ck = jb.ckpt;
     hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
-                       jb.d_geom, jb.fs, d_active, total);
+                       jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
     hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.numbps, jb.SPS, jb.d_blkmap, jb.V,
                        jb.d_geom, jb.d_blocks, jb.fs, d_active);
     timing_begin("t1_probe_decode", s);

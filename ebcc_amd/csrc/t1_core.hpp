@@ -17,11 +17,15 @@
 #pragma once
 
 #include <cstdint>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #define T1_HD __host__ __device__ inline
 #else
 #define T1_HD inline
+#endif
+#ifndef T1_STAT
+#define T1_STAT(i)            // work counters of the host statistics tool (tools/t1_stats.cpp)
 #endif
 
 namespace ebcc {
@@ -294,27 +298,44 @@ T1_HD int ctz64(u64 v)
 // Decoder store additionally:  void set_sig(int x, int y, int neg, int plane), void refine(int x, int y, int bit, int plane, int neg)
 // ------------------------------------------------------------------------------------------------
 
+// Observer of a coder run (checkpointing): every hook is a no-op here.
+struct NoObserver {
+    template <class Mq>
+    T1_HD void pass_start(int, const Mq &) {}
+    template <class Mq>
+    T1_HD void stripe_start(int, const Mq &) {}
+    template <class Store>
+    T1_HD void sigprop_done(int, Store &) {}
+};
+
 // One stripe worth of state held in locals (fully unrolled accesses keep it in registers).
 struct Stripe {
     u64 s[6];        // significance rows y0-1 .. y0+4
     u64 neg[6];      // signs of those rows
     u64 vis[4];
-    u64 valid[4];
+    u64 wmask;       // columns inside the code-block
+    int nrows;       // rows of this stripe inside the code-block (1..4)
     u64 sgn[4];      // encoder: sign of every coefficient of the stripe's rows
     u64 sps[4];      // encoder: became significant in a propagation pass (accumulated, stored with the stripe)
 };
 
-template <bool ENC, class Store, class Coder>
+template <bool ENC, class Store, class Coder, class Obs = NoObserver>
 struct Passes {
     Store &st;
     Coder &mq;
     int w, h, orient;
+    Obs *obs;
 
-    T1_HD Passes(Store &s, Coder &c, int w_, int h_, int o) : st(s), mq(c), w(w_), h(h_), orient(o) {}
+    T1_HD Passes(Store &s, Coder &c, int w_, int h_, int o, Obs *ob = nullptr) : st(s), mq(c), w(w_), h(h_), orient(o), obs(ob) {}
+    T1_HD void stripe_hook(int y0)
+    {
+        if constexpr (!std::is_same<Obs, NoObserver>::value) obs->stripe_start(y0, mq);
+    }
 
     T1_HD void load(Stripe &sp, int y0)
     {
-        const u64 wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+        sp.wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+        sp.nrows = h - y0 < 4 ? h - y0 : 4;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
             int y = y0 - 1 + r;
@@ -324,7 +345,6 @@ struct Passes {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             sp.vis[r] = st.VIS(y0 + r);
-            sp.valid[r] = (y0 + r < h) ? wmask : 0ull;
             if constexpr (ENC) { sp.sgn[r] = st.SGN(y0 + r); sp.sps[r] = 0; }
         }
     }
@@ -364,7 +384,7 @@ struct Passes {
     T1_HD bool sigprop_cell(Stripe &sp, int x, int y0, int plane, u64 bp)
     {
         const u64 bit = 1ull << x;
-        if (!(sp.valid[R] & bit) || (sp.s[R + 1] & bit)) return false;
+        if (R >= sp.nrows || (sp.s[R + 1] & bit)) return false;      // (x comes from a width-masked column set)
         uint32_t up = tri(sp.s[R], x), mid = tri(sp.s[R + 1], x), dn = tri(sp.s[R + 2], x);
         if ((up | (mid & 5u) | dn) == 0) return false;
         int cx = ctx_zc(up, mid, dn, orient);
@@ -376,9 +396,10 @@ struct Passes {
         return false;
     }
 
-    T1_HD void sigprop(int plane)
+    T1_HD void sigprop(int plane, int ystart = 0)
     {
-        for (int y0 = 0; y0 < h; y0 += 4) {
+        for (int y0 = ystart; y0 < h; y0 += 4) {
+            stripe_hook(y0);
             Stripe sp;
             load(sp, y0);
             u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
@@ -387,8 +408,9 @@ struct Passes {
             u64 nb = 0;
 #pragma unroll
             for (int r = 0; r < 6; r++) nb |= sp.s[r];
-            u64 pending = (nb | (nb << 1) | (nb >> 1)) & (sp.valid[0]);
+            u64 pending = (nb | (nb << 1) | (nb >> 1)) & sp.wmask;
             while (pending) {
+                T1_STAT(0);
                 int x = ctz64(pending);
                 pending &= pending - 1;
                 bool grew = false;
@@ -407,7 +429,7 @@ struct Passes {
     T1_HD void refine_cell(Stripe &sp, u64 &ref, int x, int y0, int plane, u64 bp)
     {
         const u64 bit = 1ull << x;
-        if (!(sp.s[R + 1] & bit) || (sp.vis[R] & bit) || !(sp.valid[R] & bit)) return;
+        if (!(sp.s[R + 1] & bit) || (sp.vis[R] & bit)) return;           // significant implies inside the block
         int cx;
         if (ref & bit) cx = CTX_MAG0 + 2;
         else {
@@ -420,17 +442,18 @@ struct Passes {
         ref |= bit;
     }
 
-    T1_HD void refine(int plane)
+    T1_HD void refine(int plane, int ystart = 0)
     {
-        for (int y0 = 0; y0 < h; y0 += 4) {
+        for (int y0 = ystart; y0 < h; y0 += 4) {
+            stripe_hook(y0);
             Stripe sp;
             load(sp, y0);
             u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
             if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
             u64 r0 = st.REF(y0), r1 = st.REF(y0 + 1), r2 = st.REF(y0 + 2), r3 = st.REF(y0 + 3);
-            u64 pending = (sp.s[1] & ~sp.vis[0] & sp.valid[0]) | (sp.s[2] & ~sp.vis[1] & sp.valid[1]) |
-                          (sp.s[3] & ~sp.vis[2] & sp.valid[2]) | (sp.s[4] & ~sp.vis[3] & sp.valid[3]);
+            u64 pending = (sp.s[1] & ~sp.vis[0]) | (sp.s[2] & ~sp.vis[1]) | (sp.s[3] & ~sp.vis[2]) | (sp.s[4] & ~sp.vis[3]);
             while (pending) {
+                T1_STAT(1);
                 int x = ctz64(pending);
                 pending &= pending - 1;
                 refine_cell<0>(sp, r0, x, y0, plane, b0);
@@ -448,7 +471,7 @@ struct Passes {
     {
         const u64 bit = 1ull << x;
         if (!skip_zc) {
-            if (!(sp.valid[R] & bit) || (sp.s[R + 1] & bit) || (sp.vis[R] & bit)) return;
+            if (R >= sp.nrows || (sp.s[R + 1] & bit) || (sp.vis[R] & bit)) return;
         }
         int v = 1;
         if (!skip_zc) {
@@ -459,17 +482,22 @@ struct Passes {
         if (v) code_sign<R>(sp, x, y0, plane, false);
     }
 
-    T1_HD void cleanup(int plane)
+    T1_HD void cleanup(int plane, int ystart = 0)
     {
-        for (int y0 = 0; y0 < h; y0 += 4) {
+        for (int y0 = ystart; y0 < h; y0 += 4) {
+            stripe_hook(y0);
             Stripe sp;
             load(sp, y0);
             u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
             if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
             const bool full = y0 + 3 < h;
-            u64 pending = (~sp.s[1] & ~sp.vis[0] & sp.valid[0]) | (~sp.s[2] & ~sp.vis[1] & sp.valid[1]) |
-                          (~sp.s[3] & ~sp.vis[2] & sp.valid[2]) | (~sp.s[4] & ~sp.vis[3] & sp.valid[3]);
+            u64 pending = ~(sp.s[1] | sp.vis[0]);
+            if (sp.nrows > 1) pending |= ~(sp.s[2] | sp.vis[1]);
+            if (sp.nrows > 2) pending |= ~(sp.s[3] | sp.vis[2]);
+            if (sp.nrows > 3) pending |= ~(sp.s[4] | sp.vis[3]);
+            pending &= sp.wmask;
             while (pending) {
+                T1_STAT(2);
                 int x = ctz64(pending);
                 pending &= pending - 1;
                 const u64 bit = 1ull << x;
@@ -519,20 +547,13 @@ struct EncodeResult {
 // Encodes every pass of a code-block with `numbps` magnitude bit-planes (numbps >= 1).
 // rates[p] follow OpenJPEG: bytes completed + 3 for unterminated passes, clipped to be non-decreasing,
 // never ending on 0xFF (needs read access to the bytes: ByteAt(int) -> uint8_t).
-struct NoObserver {
-    template <class Mq>
-    T1_HD void pass_start(int, const Mq &) {}
-    template <class Store>
-    T1_HD void sigprop_done(int, Store &) {}
-};
-
 template <class Store, class Sink, class ByteAt, class Observer, class Table = ConstTable>
 T1_HD EncodeResult encode_block_observed(Store &st, Sink sink, ByteAt bytes, int w, int h, int orient, int numbps, int *rates,
                                          Observer &obs, Table tab = Table())
 {
     MqEncoder<Sink, Table> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink, tab, 0};
     mq.init();
-    Passes<true, Store, MqEncoder<Sink, Table>> ps(st, mq, w, h, orient);
+    Passes<true, Store, MqEncoder<Sink, Table>, Observer> ps(st, mq, w, h, orient, &obs);
     int passno = 0, passtype = 2;
     for (int bp = numbps - 1; bp >= 0; passno++) {
         obs.pass_start(passno, mq);
@@ -591,8 +612,11 @@ T1_HD MqCheckpoint encoder_checkpoint(const Mq &m)
     return MqCheckpoint{m.a, m.c & 0xFFFFu, 0, (int) m.shifts, m.cx.w0, m.cx.w1, m.cx.w2};
 }
 
-template <class Source>
-T1_HD void finalize_checkpoints(MqCheckpoint *ck, int npasses, Source src)
+// CkArray: checkpoint storage of one code-block addressed by (pass, stripe):
+//   uint32_t shifts(p, s), c16(p, s)            what encoder_checkpoint() left in .pos / .c
+//   void finish(p, s, uint32_t c, int ct, int pos)   overwrite them with the decoder's registers
+template <class CkArray, class Source>
+T1_HD void finalize_checkpoints(CkArray &ck, int npasses, int nstripes, Source src)
 {
     uint32_t c;
     int ct, pos = 0;
@@ -609,18 +633,18 @@ T1_HD void finalize_checkpoints(MqCheckpoint *ck, int npasses, Source src)
     bytein();
     c <<= 7; ct -= 7;
     uint32_t done = 0;
-    for (int p = 0; p < npasses; p++) {
-        uint32_t rem = (uint32_t) ck[p].pos - done;
-        done = (uint32_t) ck[p].pos;
-        while (rem) {
-            if (ct == 0) bytein();
-            uint32_t k = rem < (uint32_t) ct ? rem : (uint32_t) ct;
-            c <<= k; ct -= (int) k; rem -= k;
+    for (int p = 0; p < npasses; p++)
+        for (int s = 0; s < nstripes; s++) {
+            const uint32_t target = ck.shifts(p, s);
+            uint32_t rem = target - done;
+            done = target;
+            while (rem) {
+                if (ct == 0) bytein();
+                uint32_t k = rem < (uint32_t) ct ? rem : (uint32_t) ct;
+                c <<= k; ct -= (int) k; rem -= k;
+            }
+            ck.finish(p, s, c - (ck.c16(p, s) << 16), ct, pos);
         }
-        ck[p].c = c - (ck[p].c << 16);
-        ck[p].ct = ct;
-        ck[p].pos = pos;
-    }
 }
 
 // index of the first coding pass of bit-plane `bp` in a code-block with P planes; plane / type of pass i
@@ -634,7 +658,7 @@ T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient
 {
     MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
     mq.init();
-    Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
+    Passes<false, Store, MqDecoder<Source, Table>, Observer> ps(st, mq, w, h, orient, &obs);
     int passtype = 2, bp = numbps - 1;
     for (int p = 0; p < npasses && bp >= 0; p++) {
         obs.pass_start(p, mq);
@@ -657,18 +681,20 @@ T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int num
 // registers there (ignored for r == 0, where decoding starts afresh).  Valid whenever the checkpoint was taken
 // with no byte at or beyond the (truncated) segment length consumed: ck.pos + 1 < length of src.
 template <class Store, class Source, class Table = ConstTable>
-T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int r,
+T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int r, int stripe,
                          const MqCheckpoint &ck, Table tab = Table())
 {
     MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
-    if (r == 0) mq.init();
+    if (r == 0 && stripe == 0) mq.init();
     else { mq.a = ck.a; mq.c = ck.c; mq.ct = ck.ct; mq.pos = ck.pos; mq.cx.w0 = ck.w0; mq.cx.w1 = ck.w1; mq.cx.w2 = ck.w2; }
     Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
     int bp = plane_of_pass(numbps, r), passtype = type_of_pass(r);
+    int ystart = 4 * stripe;                                             // only the first pass starts mid-way
     for (int p = r; p < npasses && bp >= 0; p++) {
-        if (passtype == 0) ps.sigprop(bp);
-        else if (passtype == 1) ps.refine(bp);
-        else ps.cleanup(bp);
+        if (passtype == 0) ps.sigprop(bp, ystart);
+        else if (passtype == 1) ps.refine(bp, ystart);
+        else ps.cleanup(bp, ystart);
+        ystart = 0;
         if (++passtype == 3) { passtype = 0; bp--; }
     }
 }

@@ -1075,6 +1075,11 @@ static void make_layer(tile_t *t, double thresh)
 }
 
 /* everything of the encoder that does not depend on the rate: transform, quantisation, tier-1 */
+/* test hook: hands every code-block's quantised coefficients (6 fractional bits) to the caller, in packet order */
+static void (*g_block_sink)(const int32_t *q, int w, int h, int orient, void *user) = NULL;
+static void *g_block_sink_user = NULL;
+void orc_j2k_set_block_sink(void (*fn)(const int32_t *, int, int, int, void *), void *user) { g_block_sink = fn; g_block_sink_user = user; }
+
 static void j2k_analyse(const uint16_t *img, int H, int W, tile_t *tp, int *expn, int *mant)
 {
     init_luts();
@@ -1123,6 +1128,7 @@ static void j2k_analyse(const uint16_t *img, int H, int W, tile_t *tp, int *expn
                         e.t.data[y * w + x] = q;
                         e.mag[y * w + x] = (uint32_t) (q < 0 ? -q : q);
                     }
+                if (g_block_sink) g_block_sink(e.t.data, w, h, bd->orient, g_block_sink_user);
                 t1_encode_cblk(&e, cb, bd->orient, bd->level, bd->stepsize);
                 free(e.mag);
                 t1_free(&e.t);

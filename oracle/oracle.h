@@ -104,6 +104,8 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
 
 /* Decode a codestream to int32 samples as OpenJPEG's opj_decode does (src/ebcc_codec.c:1092-1136
  * reads image->comps[0].data).  samples malloc'd. Returns number of pixels or 0. */
+/* test hook: called with every code-block's quantised coefficients during orc_j2k_encode / orc_j2k_analysis */
+void orc_j2k_set_block_sink(void (*fn)(const int32_t *q, int w, int h, int orient, void *user), void *user);
 size_t orc_j2k_decode(const uint8_t *cs, size_t cs_size, int32_t **samples, size_t *height, size_t *width);
 
 #ifdef __cplusplus

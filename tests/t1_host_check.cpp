@@ -42,17 +42,27 @@ struct HostStore {
 };
 struct VecSink { std::vector<uint8_t> *v; void put(int i, uint8_t b) { if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = b; } };
 struct VecAt { std::vector<uint8_t> *v; uint8_t operator()(int i) const { return i < (int) v->size() ? (*v)[i] : 0; } };
-struct Obs {
-    MqCheckpoint ck[120];
+struct Obs {                      // decoder registers at the start of every (pass, stripe)
+    MqCheckpoint ck[120 * 16];
     u64 visp[40][64];
-    template <class Mq> void pass_start(int p, const Mq &m) { ck[p] = MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
+    int cur = 0, nstr = 16;
+    template <class Mq> void pass_start(int p, const Mq &) { cur = p; }
+    template <class Mq> void stripe_start(int y0, const Mq &m) { ck[cur * nstr + (y0 >> 2)] = MqCheckpoint{m.a, m.c, m.ct, m.pos, m.cx.w0, m.cx.w1, m.cx.w2}; }
     template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
 };
-struct EncObs {
-    MqCheckpoint ck[120];
+struct EncObs {                   // the same, derived from the encoder
+    MqCheckpoint ck[120 * 16];
     u64 visp[40][64];
-    template <class Mq> void pass_start(int p, const Mq &m) { ck[p] = encoder_checkpoint(m); }
+    int cur = 0, nstr = 16;
+    template <class Mq> void pass_start(int p, const Mq &) { cur = p; }
+    template <class Mq> void stripe_start(int y0, const Mq &m) { ck[cur * nstr + (y0 >> 2)] = encoder_checkpoint(m); }
     template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
+};
+struct CkView {                   // CkArray over a plain [pass * nstr + stripe] array
+    MqCheckpoint *ck; int nstr;
+    uint32_t shifts(int p, int s) const { return (uint32_t) ck[p * nstr + s].pos; }
+    uint32_t c16(int p, int s) const { return ck[p * nstr + s].c; }
+    void finish(int p, int s, uint32_t c, int ct, int pos) { MqCheckpoint &k = ck[p * nstr + s]; k.c = c; k.ct = ct; k.pos = pos; }
 };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
@@ -99,10 +109,13 @@ int main(int argc, char **argv)
             }
         std::vector<uint8_t> bytes;
         int rates[kMaxPasses];
-        EncObs eobs;
+        static EncObs eobs;
         memset(eobs.visp, 0, sizeof eobs.visp);
+        const int nstr = (h + 3) / 4;
+        eobs.nstr = nstr;
         EncodeResult r = encode_block_observed(st, VecSink{&bytes}, VecAt{&bytes}, w, h, orient, numbps, rates, eobs);
-        finalize_checkpoints(eobs.ck, r.totalpasses, BufSrc{bytes.data(), r.length});
+        CkView ckv{eobs.ck, nstr};
+        finalize_checkpoints(ckv, r.totalpasses, nstr, BufSrc{bytes.data(), r.length});
         bool ok = r.totalpasses == opasses && r.length == (opasses ? orates[opasses - 1] >= 0 ? r.length : 0 : 0);
         int olen = 0;
         // oracle's len is mq numbytes; recover it as the max rate (last pass rate equals it unless trimmed for FF)
@@ -127,7 +140,8 @@ int main(int argc, char **argv)
             decode_block(ds, BufSrc{bytes.data(), len}, w, h, orient, numbps, np);
             if (d1 != d2) { printf("trial %d DECODE mismatch np %d/%d\n", t, np, opasses); bad++; break; }
             // ---- resume at the last coded plane from a checkpoint of the FULL-segment decode
-            Obs obs;
+            static Obs obs;
+            obs.nstr = nstr;
             {
                 std::vector<int32_t> dummy((size_t) w * h, 0);
                 HostStore fs;
@@ -137,25 +151,28 @@ int main(int argc, char **argv)
             // the encoder-derived checkpoints (no decoding) must equal the decoder's own registers
             if (k == 0) {
                 bool same = true;
-                for (int p = 0; p < opasses && same; p++) {
-                    const MqCheckpoint &x = obs.ck[p], &y = eobs.ck[p];
+                for (int i = 0; i < opasses * nstr && same; i++) {
+                    const int p = i / nstr;
+                    const MqCheckpoint &x = obs.ck[i], &y = eobs.ck[i];
                     same = x.a == y.a && x.c == y.c && x.ct == y.ct && x.pos == y.pos && x.w0 == y.w0 && x.w1 == y.w1 && x.w2 == y.w2;
                     if (!same) printf("trial %d pass %d ckpt dec {a %x c %x ct %d pos %d} enc {a %x c %x ct %d pos %d}\n", t, p, x.a, x.c, x.ct, x.pos, y.a, y.c, y.ct, y.pos);
-                    if (same && type_of_pass(p) == 0) {
+                    if (same && i % nstr == 0 && type_of_pass(p) == 0) {
                         const int pl = plane_of_pass(numbps, p);
                         for (int yy = 0; yy < 64; yy++) if (obs.visp[pl][yy] != eobs.visp[pl][yy]) { same = false; printf("trial %d visp plane %d row %d\n", t, pl, yy); break; }
                     }
                 }
                 if (!same) { printf("trial %d ENCODER CHECKPOINT mismatch\n", t); bad++; break; }
             }
-            // restart at the last kept pass (or an earlier one whose checkpoint is still valid for this truncation)
-            int r = np - 1;
-            while (r > 0 && obs.ck[r].pos + 1 >= len) r--;
-            const int pr = plane_of_pass(numbps, r), tr = type_of_pass(r);
+            // restart at the latest (pass, stripe) whose checkpoint is still valid for this truncation
+            int idx = np * nstr - 1;
+            while (idx > 0 && eobs.ck[idx].pos + 1 >= len) idx--;
+            const int r = idx / nstr, rs_ = idx % nstr;
             std::vector<int32_t> d3((size_t) w * h, 0);
             HostStore rs;
             rs.out = d3.data(); rs.w = w;
-            for (int y = 0; y < h; y++)
+            for (int y = 0; y < h; y++) {
+                const int q_ = y < 4 * rs_ ? r + 1 : r;                 // rows above the restart stripe have finished pass r
+                const int pq = plane_of_pass(numbps, q_), tq = q_ == 0 ? 0 : type_of_pass(q_);
                 for (int x = 0; x < w; x++) {
                     int32_t src6 = qvals[(size_t) y * w + x];
                     uint32_t a = (uint32_t) (src6 < 0 ? -src6 : src6) >> 6;
@@ -163,19 +180,20 @@ int main(int argc, char **argv)
                     int bs = 31 - __builtin_clz(a);
                     bool sps = (st.sps[y] >> x) & 1;
                     int ps = bs == numbps - 1 ? 0 : 3 * (numbps - 1 - bs) - (sps ? 2 : 0);     // pass of first significance
-                    if (ps >= r) continue;
+                    if (ps >= q_) continue;
                     rs.s[y + 1] |= 1ull << x;
                     if (src6 < 0) rs.neg[y] |= 1ull << x;
                     int v = 3 << bs;
                     for (int pl = bs - 1; pl >= 0; pl--) {
-                        if (3 * (numbps - 1 - pl) - 1 >= r) break;
+                        if (3 * (numbps - 1 - pl) - 1 >= q_) break;
                         v += ((a >> pl) & 1) ? (1 << pl) : -(1 << pl);
                         rs.ref[y] |= 1ull << x;
                     }
                     d3[(size_t) y * w + x] = src6 < 0 ? -v : v;
                 }
-            if (tr != 0 && r > 0) for (int y = 0; y < 64; y++) rs.vis[y] = obs.visp[pr][y];
-            decode_resume(rs, BufSrc{bytes.data(), len}, w, h, orient, numbps, np, r, obs.ck[r]);
+                if (tq != 0 && q_ > 0 && pq >= 0) rs.vis[y] = eobs.visp[pq][y];
+            }
+            decode_resume(rs, BufSrc{bytes.data(), len}, w, h, orient, numbps, np, r, rs_, eobs.ck[idx]);
             int qp = r;
             if (d1 != d3) { printf("trial %d RESUME mismatch np %d/%d q %d P %d\n", t, np, opasses, qp, numbps); bad++; break; }
         }

@@ -79,6 +79,18 @@ struct Contexts {
         u64 w = i >= 18 ? w2 : (i >= 9 ? w1 : w0);
         return (uint32_t) (w >> (7 * k)) & 0x7Fu;
     }
+    // The caller usually knows the word at compile time (zero-coding contexts live in w0, sign / magnitude /
+    // run-length in w1, UNIFORM in w2): no selects between the three words then.
+    template <int W>
+    T1_HD u64 &word() { if constexpr (W == 0) return w0; else if constexpr (W == 1) return w1; else return w2; }
+    template <int W>
+    T1_HD uint32_t get_in(int k) { return (uint32_t) (word<W>() >> (7 * k)) & 0x7Fu; }
+    template <int W>
+    T1_HD void set_in(int k, uint32_t v)
+    {
+        u64 &w = word<W>();
+        w = (w & ~(0x7Full << (7 * k))) | ((u64) (v & 0x7Fu) << (7 * k));
+    }
     T1_HD void set(int i, uint32_t v)
     {
         int k = i >= 18 ? i - 18 : (i >= 9 ? i - 9 : i);
@@ -88,6 +100,8 @@ struct Contexts {
         else w0 = (w0 & ~m) | nv;
     }
 };
+
+T1_HD int renorm_shifts(uint32_t a);
 
 // ------------------------------------------------------------------------------------------------
 // MQ encoder (C.2).  Sink: void put(int index, uint8_t byte)
@@ -127,14 +141,17 @@ struct MqEncoder {
     }
     T1_HD void renorm()
     {
-        do {
-            a <<= 1; c <<= 1; ct--; shifts++;
-            if (ct == 0) byteout();
-        } while ((a & 0x8000) == 0);
+        // all shifts at once (C.2.6 does them bit by bit): BYTEOUT whenever the down-counter runs out
+        int n = renorm_shifts(a);
+        shifts += (uint32_t) n;
+        while (n >= ct) { a <<= ct; c <<= ct; n -= ct; byteout(); }
+        a <<= n; c <<= n; ct -= n;
     }
-    T1_HD void encode(int ctx, int d)
+    // W: word of the context set that holds the context, k: its index inside that word
+    template <int W>
+    T1_HD void encode_in(int k, int d)
     {
-        uint32_t st = cx.get(ctx);
+        uint32_t st = cx.template get_in<W>(k);
         uint32_t e = tab((int) (st & 0x3F));
         uint32_t qe = e & 0xFFFF;
         int mps = st >> 6;
@@ -142,7 +159,7 @@ struct MqEncoder {
         if (d == mps) {
             if ((a & 0x8000) == 0) {
                 if (a < qe) a = qe; else c += qe;
-                cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6));
+                cx.template set_in<W>(k, ((e >> 16) & 0x3F) | (mps << 6));
                 renorm();
             } else {
                 c += qe;
@@ -150,10 +167,15 @@ struct MqEncoder {
         } else {
             if (a < qe) c += qe; else a = qe;
             if (e >> 28) mps ^= 1;
-            cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6));
+            cx.template set_in<W>(k, ((e >> 22) & 0x3F) | (mps << 6));
             renorm();
         }
     }
+    T1_HD void encode_zc(int ctx, int d) { encode_in<0>(ctx - CTX_ZC0, d); }
+    T1_HD void encode_sc(int ctx, int d) { encode_in<1>(ctx - 9, d); }
+    T1_HD void encode_mag(int ctx, int d) { encode_in<1>(ctx - 9, d); }
+    T1_HD void encode_agg(int d) { encode_in<1>(CTX_AGG - 9, d); }
+    T1_HD void encode_uni(int d) { encode_in<2>(0, d); }
     T1_HD int numbytes() const { return n; }
     T1_HD void flush()
     {
@@ -198,28 +220,32 @@ struct MqDecoder {
     }
     T1_HD void renorm()
     {
+        // all shifts at once (C.3.3 does them bit by bit): BYTEIN only when another shift needs a fresh bit
+        int n = renorm_shifts(a);
         do {
             if (ct == 0) bytein();
-            a <<= 1; c <<= 1; ct--;
-        } while ((a & 0x8000) == 0);
+            const int k = n < ct ? n : ct;
+            a <<= k; c <<= k; ct -= k; n -= k;
+        } while (n);
     }
-    T1_HD int decode(int ctx)
+    template <int W>
+    T1_HD int decode_in(int k)
     {
-        uint32_t st = cx.get(ctx);
+        uint32_t st = cx.template get_in<W>(k);
         uint32_t e = tab((int) (st & 0x3F));
         uint32_t qe = e & 0xFFFF;
         int mps = st >> 6, d;
         a -= qe;
         if ((c >> 16) < qe) {
-            if (a < qe) { d = mps; cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6)); }
-            else { d = 1 - mps; if (e >> 28) mps ^= 1; cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6)); }
+            if (a < qe) { d = mps; cx.template set_in<W>(k, ((e >> 16) & 0x3F) | (mps << 6)); }
+            else { d = 1 - mps; if (e >> 28) mps ^= 1; cx.template set_in<W>(k, ((e >> 22) & 0x3F) | (mps << 6)); }
             a = qe;
             renorm();
         } else {
             c -= qe << 16;
             if ((a & 0x8000) == 0) {
-                if (a < qe) { d = 1 - mps; if (e >> 28) mps ^= 1; cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6)); }
-                else { d = mps; cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6)); }
+                if (a < qe) { d = 1 - mps; if (e >> 28) mps ^= 1; cx.template set_in<W>(k, ((e >> 22) & 0x3F) | (mps << 6)); }
+                else { d = mps; cx.template set_in<W>(k, ((e >> 16) & 0x3F) | (mps << 6)); }
                 renorm();
             } else {
                 d = mps;
@@ -227,6 +253,11 @@ struct MqDecoder {
         }
         return d;
     }
+    T1_HD int decode_zc(int ctx) { return decode_in<0>(ctx - CTX_ZC0); }
+    T1_HD int decode_sc(int ctx) { return decode_in<1>(ctx - 9); }
+    T1_HD int decode_mag(int ctx) { return decode_in<1>(ctx - 9); }
+    T1_HD int decode_agg() { return decode_in<1>(CTX_AGG - 9); }
+    T1_HD int decode_uni() { return decode_in<2>(0); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -278,6 +309,16 @@ T1_HD int ctx_sc(uint32_t sup, uint32_t smid, uint32_t sdn, uint32_t nup, uint32
     else { xb = 1; n = vc == 1 ? 2 : (vc == 0 ? 3 : 4); }
     xorbit = xb;
     return CTX_SC0 + n;
+}
+
+// renormalisation shift count of the interval register: a in [1, 0x7FFF] -> shifts until bit 15 is set
+T1_HD int renorm_shifts(uint32_t a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int) a) - 16;
+#else
+    return __builtin_clz(a) - 16;
+#endif
 }
 
 T1_HD int ctz64(u64 v)
@@ -369,9 +410,9 @@ struct Passes {
         int neg;
         if constexpr (ENC) {
             neg = (int) ((sp.sgn[R] >> x) & 1);
-            mq.encode(cx, neg ^ xb);
+            mq.encode_sc(cx, neg ^ xb);
         } else {
-            neg = mq.decode(cx) ^ xb;
+            neg = mq.decode_sc(cx) ^ xb;
         }
         sp.s[R + 1] |= 1ull << x;
         if (neg) sp.neg[R + 1] |= 1ull << x;
@@ -389,8 +430,8 @@ struct Passes {
         if ((up | (mid & 5u) | dn) == 0) return false;
         int cx = ctx_zc(up, mid, dn, orient);
         int v;
-        if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
-        else v = mq.decode(cx);
+        if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_zc(cx, v); }
+        else v = mq.decode_zc(cx);
         sp.vis[R] |= bit;
         if (v) { code_sign<R>(sp, x, y0, plane, true); return true; }
         return false;
@@ -425,21 +466,23 @@ struct Passes {
     }
 
     // ---------------- magnitude refinement pass
+    // nb: "some neighbour is significant" for every column of row R (nothing becomes significant in this pass,
+    // so it is computed once per stripe with a handful of mask operations)
     template <int R>
-    T1_HD void refine_cell(Stripe &sp, u64 &ref, int x, int y0, int plane, u64 bp)
+    T1_HD void refine_cell(Stripe &sp, u64 &ref, u64 nb, int x, int y0, int plane, u64 bp)
     {
         const u64 bit = 1ull << x;
         if (!(sp.s[R + 1] & bit) || (sp.vis[R] & bit)) return;           // significant implies inside the block
-        int cx;
-        if (ref & bit) cx = CTX_MAG0 + 2;
-        else {
-            uint32_t up = tri(sp.s[R], x), mid = tri(sp.s[R + 1], x), dn = tri(sp.s[R + 2], x);
-            cx = CTX_MAG0 + ((up | (mid & 5u) | dn) ? 1 : 0);
-        }
+        const int cx = (ref & bit) ? CTX_MAG0 + 2 : CTX_MAG0 + (int) ((nb >> x) & 1);
         int v;
-        if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
-        else { v = mq.decode(cx); st.refine(x, y0 + R, v, plane, (int) ((sp.neg[R + 1] >> x) & 1)); }
+        if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_mag(cx, v); }
+        else { v = mq.decode_mag(cx); st.refine(x, y0 + R, v, plane, (int) ((sp.neg[R + 1] >> x) & 1)); }
         ref |= bit;
+    }
+    T1_HD static u64 neighbours(u64 up, u64 mid, u64 dn)
+    {
+        const u64 all = up | mid | dn;
+        return up | dn | (all << 1) | (all >> 1);
     }
 
     T1_HD void refine(int plane, int ystart = 0)
@@ -452,14 +495,16 @@ struct Passes {
             if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
             u64 r0 = st.REF(y0), r1 = st.REF(y0 + 1), r2 = st.REF(y0 + 2), r3 = st.REF(y0 + 3);
             u64 pending = (sp.s[1] & ~sp.vis[0]) | (sp.s[2] & ~sp.vis[1]) | (sp.s[3] & ~sp.vis[2]) | (sp.s[4] & ~sp.vis[3]);
+            const u64 n0 = neighbours(sp.s[0], sp.s[1], sp.s[2]), n1 = neighbours(sp.s[1], sp.s[2], sp.s[3]),
+                      n2 = neighbours(sp.s[2], sp.s[3], sp.s[4]), n3 = neighbours(sp.s[3], sp.s[4], sp.s[5]);
             while (pending) {
                 T1_STAT(1);
                 int x = ctz64(pending);
                 pending &= pending - 1;
-                refine_cell<0>(sp, r0, x, y0, plane, b0);
-                refine_cell<1>(sp, r1, x, y0, plane, b1);
-                refine_cell<2>(sp, r2, x, y0, plane, b2);
-                refine_cell<3>(sp, r3, x, y0, plane, b3);
+                refine_cell<0>(sp, r0, n0, x, y0, plane, b0);
+                refine_cell<1>(sp, r1, n1, x, y0, plane, b1);
+                refine_cell<2>(sp, r2, n2, x, y0, plane, b2);
+                refine_cell<3>(sp, r3, n3, x, y0, plane, b3);
             }
             st.REF(y0) = r0; st.REF(y0 + 1) = r1; st.REF(y0 + 2) = r2; st.REF(y0 + 3) = r3;
         }
@@ -476,8 +521,8 @@ struct Passes {
         int v = 1;
         if (!skip_zc) {
             int cx = ctx_zc(tri(sp.s[R], x), tri(sp.s[R + 1], x), tri(sp.s[R + 2], x), orient);
-            if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode(cx, v); }
-            else v = mq.decode(cx);
+            if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_zc(cx, v); }
+            else v = mq.decode_zc(cx);
         }
         if (v) code_sign<R>(sp, x, y0, plane, false);
     }
@@ -513,15 +558,15 @@ struct Passes {
                 if (agg) {
                     if constexpr (ENC) {
                         int run = (b0 >> x) & 1 ? 0 : ((b1 >> x) & 1 ? 1 : ((b2 >> x) & 1 ? 2 : ((b3 >> x) & 1 ? 3 : 4)));
-                        mq.encode(CTX_AGG, run != 4);
+                        mq.encode_agg(run != 4);
                         if (run == 4) continue;
-                        mq.encode(CTX_UNI, run >> 1);
-                        mq.encode(CTX_UNI, run & 1);
+                        mq.encode_uni(run >> 1);
+                        mq.encode_uni(run & 1);
                         start = run;
                     } else {
-                        if (!mq.decode(CTX_AGG)) continue;
-                        start = mq.decode(CTX_UNI);
-                        start = (start << 1) | mq.decode(CTX_UNI);
+                        if (!mq.decode_agg()) continue;
+                        start = mq.decode_uni();
+                        start = (start << 1) | mq.decode_uni();
                     }
                 }
                 if (start <= 0) cleanup_cell<0>(sp, x, y0, plane, b0, agg && start == 0);

@@ -27,6 +27,8 @@ struct HostStore {
 };
 struct CountCoder {      // counts decisions by kind; no arithmetic coding
     long n[5] = {0, 0, 0, 0, 0};   // zc, sc, mr, agg, uni
+    void encode_zc(int c, int d) { encode(c, d); } void encode_sc(int c, int d) { encode(c, d); } void encode_mag(int c, int d) { encode(c, d); }
+    void encode_agg(int d) { encode(CTX_AGG, d); } void encode_uni(int d) { encode(CTX_UNI, d); }
     void encode(int ctx, int) { if (ctx <= CTX_ZC0 + 8 && ctx >= CTX_ZC0) n[0]++; else if (ctx >= CTX_SC0 && ctx < CTX_SC0 + 5) n[1]++; else if (ctx >= CTX_MAG0 && ctx < CTX_MAG0 + 3) n[2]++; else if (ctx == CTX_AGG) n[3]++; else n[4]++; }
 };
 int main(int argc, char **argv)

@@ -189,7 +189,7 @@ def main():
         tms, launches = ctypes.c_double(), ctypes.c_long()
         lib.ebcc_hip_timing_read(ctx, b"t1_encode", ctypes.byref(tms), ctypes.byref(launches))
         kern = {}
-        for name in (b"t1_encode", b"t1_checkpoints", b"t1_probe_decode", b"rate_alloc", b"j2k_dwt_fwd", b"spiht_encode", b"t1_decode"):
+        for name in (b"t1_encode", b"t1_symbols", b"t1_mq", b"t1_probe_decode", b"rate_alloc", b"j2k_dwt_fwd", b"spiht_encode", b"t1_decode"):
             a, c = ctypes.c_double(), ctypes.c_long()
             lib.ebcc_hip_timing_read(ctx, name, ctypes.byref(a), ctypes.byref(c))
             if c.value:
@@ -197,7 +197,9 @@ def main():
         roof = None
         if launches.value:
             avg_s = tms.value / launches.value / 1e3
-            algo = n * FRAME_BYTES + comp                       # fp32 read + compressed bytes written, per launch
+            # fp32 read + compressed bytes written per launch (a batch runs as several concurrent slices,
+            # each with its own launch)
+            algo = (n * FRAME_BYTES + comp) * args.steps / launches.value
             ach = algo / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": "k_t1_encode", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4),

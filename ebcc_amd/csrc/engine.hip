@@ -2,6 +2,8 @@
 #include "engine.hpp"
 
 #include <cstdarg>
+#include <mutex>
+#include <string>
 #include <cstring>
 
 #include "../../include/ebcc_hip.h"
@@ -56,25 +58,31 @@ void push_frame_states(ebcc_hip_ctx *ctx, size_t n)
 }
 
 // ---- optional kernel timing -------------------------------------------------------------------------
-struct TimedSpan { std::string name; hipEvent_t a, b; };
+struct TimedSpan { std::string name; hipEvent_t a, b; hipStream_t s; bool closed; };
 static bool g_timing = false;
 static std::vector<TimedSpan> g_spans;
-static std::vector<hipEvent_t> g_open;
+static std::mutex g_spans_mutex;             // sub-batches are driven by their own host threads (and streams)
 
 void timing_begin(const char *name, hipStream_t s)
 {
     if (!g_timing) return;
-    TimedSpan t{name, nullptr, nullptr};
+    TimedSpan t{name, nullptr, nullptr, s, false};
     EBCC_HIP_CHECK(hipEventCreate(&t.a));
     EBCC_HIP_CHECK(hipEventCreate(&t.b));
     EBCC_HIP_CHECK(hipEventRecord(t.a, s));
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
     g_spans.push_back(t);
 }
 void timing_end(const char *name, hipStream_t s)
 {
     if (!g_timing) return;
+    std::lock_guard<std::mutex> lock(g_spans_mutex);
     for (size_t i = g_spans.size(); i-- > 0;)
-        if (g_spans[i].name == name) { EBCC_HIP_CHECK(hipEventRecord(g_spans[i].b, s)); return; }
+        if (!g_spans[i].closed && g_spans[i].s == s && g_spans[i].name == name) {
+            EBCC_HIP_CHECK(hipEventRecord(g_spans[i].b, s));
+            g_spans[i].closed = true;
+            return;
+        }
 }
 
 }  // namespace ebcc
@@ -103,11 +111,11 @@ void ebcc_hip_timing_enable(ebcc_hip_ctx *ctx, int on)
 
 int ebcc_hip_timing_read(ebcc_hip_ctx *ctx, const char *name, double *total_ms, long *launches)
 {
-    if (ctx) EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx) EBCC_HIP_CHECK(hipDeviceSynchronize());
     double tot = 0;
     long n = 0;
     for (auto &t : g_spans)
-        if (t.name == name) {
+        if (t.closed && t.name == name) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { tot += ms; n++; }
         }
@@ -191,6 +199,8 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (ebcc_hip_ctx *c : ctx->lanes) ebcc_hip_destroy(c);
+    ctx->lanes.clear();
     j2k_destroy(ctx);
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->h_u64a) hipHostFree(ctx->h_u64a);

@@ -14,6 +14,7 @@
 #include <map>
 #include <atomic>
 #include <mutex>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -448,13 +449,13 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         const bool want_pure = !pure_done && !env.no_fallback;
         const char *ps_env = getenv("EBCC_HIP_PURE_SEARCH");
         const bool concurrent = want_pure && !env.no_consistency && ps_env && !strcmp(ps_env, "concurrent");
-        Batch b2(ctx, d_frames, n, true);
+        std::unique_ptr<Batch> b2(concurrent ? new Batch(ctx, d_frames, n, true) : nullptr);
         for (size_t f = 0; f < n; f++) {
             if (jobs[f].const_field) continue;
             jobs[f].rs[0].start(cfg->base_cr, jobs[f].q, q_target);
-            if (concurrent) { jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0); b2.jf[f] = b.jf[f]; }
+            if (concurrent) { jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0); b2->jf[f] = b.jf[f]; }
         }
-        run_searches(&b, concurrent ? &b2 : nullptr, jobs, n_pix);
+        run_searches(&b, b2.get(), jobs, n_pix);
         for (size_t f = 0; f < n; f++) {
             b.active[f] = jobs[f].const_field ? 0 : 1;
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
@@ -780,6 +781,47 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
 // ================================================================================================
 // C API
 // ================================================================================================
+// Slices of a batch: EBCC_HIP_SLICES (default 2, 1 = off) engines of max_frames / slices frames each, created on
+// first use.  Small batches stay on the context's own engine.  More than two slices only pay when the HIP
+// runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the application's streams):
+// streams that share a queue run one after the other.
+static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames)
+{
+    size_t k = 2;
+    if (const char *e = getenv("EBCC_HIP_SLICES")) k = (size_t) std::max(1L, strtol(e, nullptr, 10));
+    k = std::min<size_t>(k, 8);
+    if (k < 2 || n_frames < 4 * k) return 1;
+    const size_t per = (ctx->max_frames + k - 1) / k;
+    while (ctx->lanes.size() + 1 < k) {                     // slice 0 runs on the context's own engine
+        ebcc_hip_ctx *c = ebcc_hip_create(ctx->device, per, (size_t) ctx->height, (size_t) ctx->width);
+        if (!c) return 1;                                   // out of memory: fall back to the single engine
+        ctx->lanes.push_back(c);
+    }
+    return k;
+}
+
+template <class Fn>
+static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn)
+{
+    const size_t k = slice_engines(ctx, n_frames);
+    if (k == 1) return fn(ctx, (size_t) 0, n_frames);
+    const size_t per = (n_frames + k - 1) / k;
+    std::vector<int> rc(k, 0);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < k; i++) {
+        const size_t lo = i * per, hi = std::min(n_frames, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([&, i, lo, hi]() {
+            EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+            rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo);
+        });
+    }
+    for (auto &t : th) t.join();
+    int worst = 0;
+    for (int r : rc) worst = std::max(worst, r);
+    return worst;
+}
+
 extern "C" {
 
 void free_buffer(void *p) { if (p) free(p); }
@@ -818,7 +860,11 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     std::lock_guard<std::mutex> lock(g_mutex);
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     log_set_level_from_env();
-    return encode_batch(ctx, d_frames, n_frames, config, out_streams, out_sizes);
+    if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+    const size_t n_pix = ctx->n_pix;
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt) {
+        return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo);
+    });
 }
 
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
@@ -827,7 +873,11 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_decode_frames: bad batch"); return 1; }
     std::lock_guard<std::mutex> lock(g_mutex);
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
-    return decode_batch(ctx, streams, sizes, n_frames, d_frames_out);
+    if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+    const size_t n_pix = ctx->n_pix;
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt) {
+        return decode_batch(c, streams + lo, sizes + lo, cnt, d_frames_out + lo * n_pix);
+    });
 }
 
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)

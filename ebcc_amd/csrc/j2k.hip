@@ -37,6 +37,9 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->SPS = ctx_alloc<unsigned long long>(ctx, groups * 64 * 64)) != nullptr;
     ok &= (jb->VISP = ctx_alloc<unsigned long long>(ctx, groups * kJ2kMaxPlanes * 64 * 64)) != nullptr;
     ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kCkptPerBlock * 40)) != nullptr;
+    jb->SYM = nullptr;                           // the decision streams of the two-phase encoder are large: only on request
+    if (const char *e = getenv("EBCC_T1_TWO_PHASE")) if (atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * 64 * (size_t) kJ2kSymCap + 256)) != nullptr;
+    ok &= (jb->nsym = ctx_alloc<uint32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->qplane = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;
     ok &= (jb->blkmax = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
@@ -80,7 +83,6 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     if (!ok) return false;
     EBCC_HIP_CHECK(hipMemsetAsync(alt->jf, 0, sizeof(J2kFrame) * F, s));
     EBCC_HIP_CHECK(hipMemsetAsync(alt->T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
-    EBCC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return true;
 }

@@ -45,6 +45,7 @@ struct J2kGeom {
     J2kBand bands[kJ2kBands];
 };
 
+constexpr int kJ2kSymCap = 4096 * (kJ2kMaxPlanes + 1) + 2048;  // decision stream of one code-block: at most planes + 1 decisions per sample, plus stripe markers
 constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
 
 // Checkpoint storage: structure of arrays, lane-interleaved like the tier-1 state, so that the 64 code-blocks
@@ -97,6 +98,8 @@ struct J2kBuffers {
     unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
     unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
     void *ckpt;                   // [frames*nblocks][passes][16 stripes] MQ-decoder checkpoints at every stripe start of every coding pass
+    uint8_t *SYM;                 // [frames*nblocks][kJ2kSymCap] decision streams of the two-phase encoder (t1_core.hpp)
+    std::uint32_t *nsym;          // [frames*nblocks] bytes in the stream
     int *qplane;                  // [frames*nblocks] coding pass at which the current probe's decode restarts (-1: nothing)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
     int *blkmax;                  // [frames*nblocks] max |q6|
@@ -122,7 +125,7 @@ struct J2kBuffers {
 // the SIMDs sit idle between dependent instructions.  Fewer code-blocks per wave = more waves in flight and
 // smaller unions.  Defaults measured on MI355X (profiles/): encode/checkpoint 32, probe restart 16, decode 8;
 // EBCC_T1_LPW=<8|16|32|64> overrides all four.
-enum T1Kernel { T1_ENCODE = 0, T1_CHECKPOINT = 1, T1_RESUME = 2, T1_DECODE = 3 };
+enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
 int t1_lanes_per_wave(int kernel);
 
 J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks);

@@ -6,6 +6,7 @@
 // frame with different rates (/root/reference/src/ebcc_codec.c:545-596).  None of it depends on the
 // rate, so here it runs once per frame.
 #include <array>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -29,9 +30,9 @@ static const double kNormsReal[4][10] = {
 
 int t1_lanes_per_wave(int kernel)
 {
-    // EBCC_T1_LPW = "<n>" (all kernels) or "<encode>,<unused>,<probe restart>,<decode>", each 8, 16, 32 or 64
+    // EBCC_T1_LPW = "<n>" (all kernels) or "<decision pass>,<MQ pass>,<probe restart>,<decode>", each 8, 16, 32 or 64
     static const std::array<int, 4> table = [] {
-        std::array<int, 4> t = {32, 32, 16, 8};
+        std::array<int, 4> t = {32, 64, 16, 8};
         if (const char *e = getenv("EBCC_T1_LPW")) {
             int v[4], n = sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
             for (int i = 0; i < 4; i++) {
@@ -501,7 +502,14 @@ struct CkObserver {
         u(0, i) = m.a; u(1, i) = m.c & 0xFFFFu; u(3, i) = m.shifts;
         w(0, i) = m.cx.w0; w(1, i) = m.cx.w1; w(2, i) = m.cx.w2;
     }
-    // CkArray of t1::finalize_checkpoints
+    // CkArray of t1::mq_encode_stream / t1::finalize_checkpoints
+    __device__ void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, unsigned long long w0, unsigned long long w1,
+                          unsigned long long w2)
+    {
+        const uint32_t i = (uint32_t) (p * 16 + s);
+        u(0, i) = a; u(1, i) = c16; u(3, i) = shifts;
+        w(0, i) = w0; w(1, i) = w1; w(2, i) = w2;
+    }
     __device__ uint32_t shifts(int p, int s) const { return u(3, (uint32_t) (p * 16 + s)); }
     __device__ uint32_t c16(int p, int s) const { return u(1, (uint32_t) (p * 16 + s)); }
     __device__ void finish(int p, int s, uint32_t c, int ct, int pos)
@@ -528,6 +536,7 @@ struct CkSrc {
     }
 };
 
+// ---- single-phase encoder: passes and MQ coder in one kernel
 __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const unsigned long long *BP,
                                                    const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax, int *numbps,
                                                    int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes,
@@ -561,6 +570,124 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     cblk_len[gid] = r.length;
     __threadfence();                                                    // the sweep below re-reads this lane's own bytes
     t1::finalize_checkpoints(obs, r.totalpasses, (blk.h + 3) >> 2, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
+}
+
+// ---- phase 1: the coding passes, emitting decisions instead of coding them (t1::emit_block)
+struct SymPutDev {
+    unsigned char *base;           // this code-block's slot in SYM
+    int *overflow;
+    unsigned long long win = 0;
+    __device__ void operator()(uint32_t i, uint32_t sym)
+    {
+        win |= (unsigned long long) sym << (8 * (i & 7u));
+        if ((i & 7u) == 7u) {
+            if (i < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (i & ~7u)) = win; else *overflow = 1;
+            win = 0;
+        }
+    }
+    __device__ void flush(uint32_t n)
+    {
+        if ((n & 7u) && n < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (n & ~7u)) = win;
+    }
+};
+struct EmitObserver {
+    unsigned char *visp;           // group base of the per-plane visited masks
+    uint32_t lane8;
+    template <class Em>
+    __device__ void pass_start(int, const Em &) {}
+    template <class Store>
+    __device__ void sigprop_done(int bp, Store &st)
+    {
+        for (int y = 0; y < 64; y++) *(unsigned long long *) (visp + ((uint32_t) (bp * 64 + y) * 512u + lane8)) = st.VIS(y);
+    }
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_t1_symbols(unsigned long long *T1S, const unsigned long long *BP,
+                                                    const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax,
+                                                    int *numbps, int *totalpasses, int *cblk_len, uint8_t *SYM,
+                                                    uint32_t *nsym, unsigned long long *VISP, const J2kGeom *geom,
+                                                    const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, int lpw)
+{
+    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
+    const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
+    const int gid = gid0 + threadIdx.x;
+    if (gid >= total) return;
+    const int nb = geom->nblocks;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if (fs[frame].const_field) return;
+    const J2kBlock blk = blocks[bi];
+    const int orient = geom->bands[blk.band].orient;
+    const int m = blkmax[gid];
+    int P = m ? (31 - __clz(m)) + 1 - 6 : 0;                         // opj_t1_encode_cblk: numbps
+    numbps[gid] = P;
+    if (P <= 0) { totalpasses[gid] = 0; cblk_len[gid] = 0; nsym[gid] = 0; return; }
+    const size_t grp = (size_t) (gid0 >> 6);
+    const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
+    DevStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64),
+                (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (SPS + grp * 64 * 64), lane8};
+    EmitObserver obs{(unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
+    t1::SymbolEmitter<SymPutDev> em{0, SymPutDev{SYM + (size_t) gid * kJ2kSymCap, &jf[frame].overflow}};
+    totalpasses[gid] = t1::emit_block(st, em, blk.w, blk.h, orient, P, obs);
+    em.put.flush(em.n);
+    nsym[gid] = em.n;
+}
+
+// ---- phase 2: arithmetic coding of the decision streams, one code-block per lane, every lane the same loop.
+// All lanes are at the same stream index, so the stream is staged through LDS 64 bytes per lane at a time:
+// one wave-wide refill every 64 symbols (with the next chunk's loads already in flight) instead of a global
+// load - and a wave-wide wait for it - whenever any single lane runs dry.
+struct SymSrcDev {
+    const unsigned char *base;     // this code-block's stream
+    uint32_t *ring;                // LDS, [16 words][64 lanes] of this wave
+    uint32_t lane;
+    uint4 n0, n1, n2, n3;          // the chunk after the one in LDS
+    __device__ void prefetch(uint32_t at)
+    {
+        const uint4 *p = (const uint4 *) (base + at);
+        n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3];
+    }
+    __device__ uint32_t get(uint32_t i)
+    {
+        if ((i & 63u) == 0u) {
+            uint32_t *r = ring + lane;
+            r[0 * 64] = n0.x; r[1 * 64] = n0.y; r[2 * 64] = n0.z; r[3 * 64] = n0.w;
+            r[4 * 64] = n1.x; r[5 * 64] = n1.y; r[6 * 64] = n1.z; r[7 * 64] = n1.w;
+            r[8 * 64] = n2.x; r[9 * 64] = n2.y; r[10 * 64] = n2.z; r[11 * 64] = n2.w;
+            r[12 * 64] = n3.x; r[13 * 64] = n3.y; r[14 * 64] = n3.z; r[15 * 64] = n3.w;
+            prefetch(i + 64u);
+        }
+        return ((const unsigned char *) (ring + ((i & 63u) >> 2) * 64u + lane))[i & 3u];
+    }
+};
+
+__global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t *nsym, const int *numbps,
+                                               const int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes, void *ckpt,
+                                               const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf,
+                                               int total, int lpw)
+{
+    EBCC_LDS_MQ_TABLE(tab);
+    __shared__ uint32_t ring[16 * 64];
+    if ((int) threadIdx.x >= lpw) return;
+    const int gid0 = blockIdx.x * lpw;
+    const int gid = gid0 + threadIdx.x;
+    if (gid >= total) return;
+    const int nb = geom->nblocks;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if (fs[frame].const_field) return;
+    const int np = totalpasses[gid];
+    if (numbps[gid] <= 0 || np <= 0) return;
+    const J2kBlock blk = blocks[bi];
+    const size_t grp = (size_t) (gid0 >> 6);
+    const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
+    uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
+    CkObserver ck{(unsigned char *) ckpt + grp * J2kCkptView::group_bytes(), nullptr, lane8};
+    SymSrcDev src{SYM + (size_t) gid * kJ2kSymCap, ring, threadIdx.x};
+    src.prefetch(0);
+    t1::EncodeResult r = t1::mq_encode_stream(src, nsym[gid], np, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow},
+                                              DevAt{out, kJ2kCblkBytes}, rates + (size_t) gid * kJ2kMaxPasses, ck, tab);
+    cblk_len[gid] = r.length;
+    __threadfence();                                                    // the sweep below re-reads this lane's own bytes
+    t1::finalize_checkpoints(ck, np, (blk.h + 3) >> 2, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
 }
 
 // ================================================================================================
@@ -635,6 +762,8 @@ void launch_input_stats(const float *data, int n_frames, size_t n_pix, FrameStat
 static short *g_luts = nullptr;
 static const short *nmsedec_luts(hipStream_t s)
 {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (!g_luts) {
         short h[4 * 128];
         for (int i = 0; i < 128; i++) {                                // t1_generate_luts: T.800 J.14.4 estimates
@@ -678,11 +807,25 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.SPS, 0, groups * 64 * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_encode", s);
-    int lpw = t1_lanes_per_wave(T1_ENCODE);
-    unsigned t1_grid = (unsigned) ceil_div(total, lpw);
-    hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
-                       jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.VISP, jb.d_geom,
-                       jb.d_blocks, fs, jb.jf, total, lpw);
+    if (!jb.SYM) {
+        int lpw = t1_lanes_per_wave(T1_ENCODE);
+        unsigned t1_grid = (unsigned) ceil_div(total, lpw);
+        hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
+                           jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.VISP, jb.d_geom,
+                           jb.d_blocks, fs, jb.jf, total, lpw);
+    } else {                                                             // EBCC_T1_TWO_PHASE=1
+        timing_begin("t1_symbols", s);
+        int lpw = t1_lanes_per_wave(T1_ENCODE);
+        hipLaunchKernelGGL(k_t1_symbols, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax,
+                           jb.numbps, jb.totalpasses, jb.cblk_len, jb.SYM, jb.nsym, jb.VISP, jb.d_geom, jb.d_blocks, fs, jb.jf,
+                           total, lpw);
+        timing_end("t1_symbols", s);
+        timing_begin("t1_mq", s);
+        lpw = t1_lanes_per_wave(T1_MQ);
+        hipLaunchKernelGGL(k_t1_mq, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.SYM, jb.nsym, jb.numbps,
+                           jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, lpw);
+        timing_end("t1_mq", s);
+    }
     timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);

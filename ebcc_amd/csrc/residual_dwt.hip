@@ -9,6 +9,7 @@
 // Rows: one row per workgroup iteration, HBM access is full contiguous rows (float2 per lane).
 // Columns: a tile of CW adjacent columns x full height is staged through LDS so that every HBM
 // access is a CW*4-byte row segment; the strided walk happens only in LDS.
+#include <mutex>
 #include "residual.hpp"
 
 namespace ebcc {
@@ -676,6 +677,8 @@ static int *g_step_table = nullptr;   // device copy of floor(log(2^k)/log(2.0))
 
 static const int *step_table(hipStream_t s)
 {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (!g_step_table) {
         int h[32];
         for (int k = 0; k < 32; k++) {

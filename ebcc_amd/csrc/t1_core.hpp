@@ -73,11 +73,25 @@ struct Contexts {
         w0 = w1 = w2 = 0;
         set(CTX_UNI, 46); set(CTX_AGG, 3); set(CTX_ZC0, 4);              // T.800 table D-7
     }
+    // Run-time context index: pure value arithmetic on the three words (no address-of-member selects, which
+    // would force the whole state into scratch memory on the GPU).
     T1_HD uint32_t get(int i) const
     {
-        int k = i >= 18 ? i - 18 : (i >= 9 ? i - 9 : i);
-        u64 w = i >= 18 ? w2 : (i >= 9 ? w1 : w0);
+        const int hi1 = i >= 9, hi2 = i >= 18;
+        const int k = i - 9 * (hi1 + hi2);
+        const u64 m2 = 0ull - (u64) hi2, m1 = (0ull - (u64) hi1) & ~m2, m0 = ~(m1 | m2);
+        const u64 w = (w0 & m0) | (w1 & m1) | (w2 & m2);
         return (uint32_t) (w >> (7 * k)) & 0x7Fu;
+    }
+    T1_HD void set(int i, uint32_t v)
+    {
+        const int hi1 = i >= 9, hi2 = i >= 18;
+        const int k = i - 9 * (hi1 + hi2);
+        const u64 m2 = 0ull - (u64) hi2, m1 = (0ull - (u64) hi1) & ~m2, m0 = ~(m1 | m2);
+        const u64 clr = 0x7Full << (7 * k), nv = (u64) (v & 0x7Fu) << (7 * k);
+        w0 = (w0 & ~(clr & m0)) | (nv & m0);
+        w1 = (w1 & ~(clr & m1)) | (nv & m1);
+        w2 = (w2 & ~(clr & m2)) | (nv & m2);
     }
     // The caller usually knows the word at compile time (zero-coding contexts live in w0, sign / magnitude /
     // run-length in w1, UNIFORM in w2): no selects between the three words then.
@@ -90,14 +104,6 @@ struct Contexts {
     {
         u64 &w = word<W>();
         w = (w & ~(0x7Full << (7 * k))) | ((u64) (v & 0x7Fu) << (7 * k));
-    }
-    T1_HD void set(int i, uint32_t v)
-    {
-        int k = i >= 18 ? i - 18 : (i >= 9 ? i - 9 : i);
-        u64 m = 0x7Full << (7 * k), nv = (u64) (v & 0x7Fu) << (7 * k);
-        if (i >= 18) w2 = (w2 & ~m) | nv;
-        else if (i >= 9) w1 = (w1 & ~m) | nv;
-        else w0 = (w0 & ~m) | nv;
     }
 };
 
@@ -168,6 +174,29 @@ struct MqEncoder {
             if (a < qe) c += qe; else a = qe;
             if (e >> 28) mps ^= 1;
             cx.template set_in<W>(k, ((e >> 22) & 0x3F) | (mps << 6));
+            renorm();
+        }
+    }
+    // any context, chosen at run time (selects between the three words): the stream coder's form
+    T1_HD void encode(int ctx, int d)
+    {
+        uint32_t st = cx.get(ctx);
+        uint32_t e = tab((int) (st & 0x3F));
+        uint32_t qe = e & 0xFFFF;
+        int mps = st >> 6;
+        a -= qe;
+        if (d == mps) {
+            if ((a & 0x8000) == 0) {
+                if (a < qe) a = qe; else c += qe;
+                cx.set(ctx, ((e >> 16) & 0x3F) | (mps << 6));
+                renorm();
+            } else {
+                c += qe;
+            }
+        } else {
+            if (a < qe) c += qe; else a = qe;
+            if (e >> 28) mps ^= 1;
+            cx.set(ctx, ((e >> 22) & 0x3F) | (mps << 6));
             renorm();
         }
     }
@@ -370,7 +399,7 @@ struct Passes {
     T1_HD Passes(Store &s, Coder &c, int w_, int h_, int o, Obs *ob = nullptr) : st(s), mq(c), w(w_), h(h_), orient(o), obs(ob) {}
     T1_HD void stripe_hook(int y0)
     {
-        if constexpr (!std::is_same<Obs, NoObserver>::value) obs->stripe_start(y0, mq);
+        if constexpr (!std::is_same<Obs, NoObserver>::value) obs->stripe_start(y0, mq);   // (may write to the coder: stream markers)
     }
 
     T1_HD void load(Stripe &sp, int y0)
@@ -690,6 +719,100 @@ T1_HD void finalize_checkpoints(CkArray &ck, int npasses, int nstripes, Source s
             }
             ck.finish(p, s, c - (ck.c16(p, s) << 16), ct, pos);
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-phase encoder.  The coding passes are branchy (which samples are coded depends on the data) while the
+// MQ coder is a long dependent chain; run together, a wave executes the union of both for all its lanes.
+//   phase 1 (emit_block): the passes with a "coder" that only appends the decisions (context, bit) to a byte
+//                         stream and notes where every (pass, stripe) starts in it;
+//   phase 2 (mq_encode_stream): one tight loop per code-block that reads decisions and arithmetic-codes them,
+//                         the same instruction sequence for every lane and every symbol kind.
+// Bytes, rates and checkpoints are identical to encode_block_observed().
+// ------------------------------------------------------------------------------------------------
+// Stream bytes: a decision is context | bit << 5 (< 0x40); 0x80 marks the start of a stripe, 0xC0 the start of
+// the first stripe of a coding pass - the stream coder checkpoints there and closes the previous pass.
+// Put: void operator()(uint32_t index, uint32_t byte)
+constexpr uint32_t kSymStripe = 0x80, kSymPass = 0x40;
+template <class Put>
+struct SymbolEmitter {
+    uint32_t n;
+    Put put;
+    T1_HD void emit(int ctx, int d) { put(n, (uint32_t) ctx | ((uint32_t) d << 5)); n++; }
+    T1_HD void mark(bool new_pass) { put(n, kSymStripe | (new_pass ? kSymPass : 0u)); n++; }
+    T1_HD void encode_zc(int ctx, int d) { emit(ctx, d); }
+    T1_HD void encode_sc(int ctx, int d) { emit(ctx, d); }
+    T1_HD void encode_mag(int ctx, int d) { emit(ctx, d); }
+    T1_HD void encode_agg(int d) { emit(CTX_AGG, d); }
+    T1_HD void encode_uni(int d) { emit(CTX_UNI, d); }
+};
+
+// Observer of emit_block(): stripe markers into the stream; Inner gets the remaining hooks
+template <class Inner>
+struct MarkingObserver {
+    Inner &in;
+    template <class Em>
+    T1_HD void pass_start(int p, const Em &e) { in.pass_start(p, e); }
+    template <class Em>
+    T1_HD void stripe_start(int y0, Em &e) { e.mark(y0 == 0); }
+    template <class Store>
+    T1_HD void sigprop_done(int bp, Store &st) { in.sigprop_done(bp, st); }
+};
+
+// Returns the number of coding passes; the length of the stream is in em.n afterwards.
+template <class Store, class Put, class Observer>
+T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient, int numbps, Observer &inner)
+{
+    MarkingObserver<Observer> obs{inner};
+    Passes<true, Store, SymbolEmitter<Put>, MarkingObserver<Observer>> ps(st, em, w, h, orient, &obs);
+    int passno = 0, passtype = 2;
+    for (int bp = numbps - 1; bp >= 0; passno++) {
+        obs.pass_start(passno, em);
+        if (passtype == 0) { ps.sigprop(bp); obs.sigprop_done(bp, st); }
+        else if (passtype == 1) ps.refine(bp);
+        else ps.cleanup(bp);
+        if (++passtype == 3) { passtype = 0; bp--; }
+    }
+    return passno;
+}
+
+// SymSrc: uint32_t get(uint32_t index), called with index = 0, 1, 2, ... (every lane of a wave is at the same
+// index, which lets a device source refill a staging buffer for all lanes at once);
+// CkArray additionally: void store(p, s, a, c16, shifts, w0, w1, w2).
+template <class SymSrc, class Sink, class ByteAt, class CkArray, class Table = ConstTable>
+T1_HD EncodeResult mq_encode_stream(SymSrc sym, uint32_t nsym, int npasses, Sink sink, ByteAt bytes, int *rates, CkArray &ck,
+                                    Table tab = Table())
+{
+    MqEncoder<Sink, Table> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink, tab, 0};
+    mq.init();
+    int p = 0, s = -1;
+    for (uint32_t pos = 0; pos < nsym; pos++) {
+        const uint32_t v = sym.get(pos);
+        if (v & kSymStripe) {
+            if (v & kSymPass) {
+                if (s >= 0) { rates[p] = (int) ((uint32_t) mq.numbytes() + 3u); p++; }
+                s = 0;
+            } else {
+                s++;
+            }
+            ck.store(p, s, mq.a, mq.c & 0xFFFFu, mq.shifts, mq.cx.w0, mq.cx.w1, mq.cx.w2);
+        } else {
+            mq.encode((int) (v & 31u), (int) (v >> 5));
+        }
+    }
+    mq.flush();
+    rates[p] = mq.numbytes();
+    int last = mq.numbytes();
+    for (int q = npasses; q > 0;) {
+        --q;
+        if (rates[q] > last) rates[q] = last; else last = rates[q];
+    }
+    for (int q = 0; q < npasses; q++)
+        if (rates[q] > 0 && bytes(rates[q] - 1) == 0xFF) rates[q]--;
+    EncodeResult r;
+    r.totalpasses = npasses;
+    r.length = mq.numbytes();
+    return r;
 }
 
 // index of the first coding pass of bit-plane `bp` in a code-block with P planes; plane / type of pass i

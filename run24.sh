@@ -1,4 +1,4 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-S='import json,sys; d=json.loads(sys.stdin.read()); k=d["kernels"]; print(d["ms_per_step"], d["value"], {n:k[n]["ms_avg"] for n in ("t1_encode","t1_probe_decode","t1_decode","rate_alloc","spiht_encode")})'
+S='import json,sys; d=json.loads(sys.stdin.read()); k=d["kernels"]; print(d["ms_per_step"], d["value"], {n:(k[n]["ms_avg"],k[n]["launches"]) for n in k})'
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$S"
 EBCC_HIP_PHASE_TIMING=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "phase" | tail -9

@@ -1,0 +1,3 @@
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+S='import json,sys; d=json.loads(sys.stdin.read()); k=d["kernels"]; print(d["ms_per_step"], d["value"], d["encode_GBps"], d["decode_GBps"], {n:(k[n]["ms_avg"],k[n]["launches"]) for n in k})'
+for K in 4 1 2 8; do echo "slices $K"; EBCC_HIP_SLICES=$K python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$S"; done

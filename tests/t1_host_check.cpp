@@ -58,11 +58,19 @@ struct EncObs {                   // the same, derived from the encoder
     template <class Mq> void stripe_start(int y0, const Mq &m) { ck[cur * nstr + (y0 >> 2)] = encoder_checkpoint(m); }
     template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
 };
+struct SymPut { std::vector<uint8_t> *v; void operator()(uint32_t i, uint32_t sym) { if (v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) sym; } };
+struct SymGet { const std::vector<uint8_t> *v; uint32_t get(uint32_t i) const { return (*v)[i]; } };
+struct EmitObs {                  // phase 1 observer (the stripe markers go into the stream itself)
+    u64 visp[40][64];
+    template <class Em> void pass_start(int, const Em &) {}
+    template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
+};
 struct CkView {                   // CkArray over a plain [pass * nstr + stripe] array
     MqCheckpoint *ck; int nstr;
     uint32_t shifts(int p, int s) const { return (uint32_t) ck[p * nstr + s].pos; }
     uint32_t c16(int p, int s) const { return ck[p * nstr + s].c; }
     void finish(int p, int s, uint32_t c, int ct, int pos) { MqCheckpoint &k = ck[p * nstr + s]; k.c = c; k.ct = ct; k.pos = pos; }
+    void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, u64 w0, u64 w1, u64 w2) { ck[p * nstr + s] = MqCheckpoint{a, c16, 0, (int) shifts, w0, w1, w2}; }
 };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
@@ -116,6 +124,26 @@ int main(int argc, char **argv)
         EncodeResult r = encode_block_observed(st, VecSink{&bytes}, VecAt{&bytes}, w, h, orient, numbps, rates, eobs);
         CkView ckv{eobs.ck, nstr};
         finalize_checkpoints(ckv, r.totalpasses, nstr, BufSrc{bytes.data(), r.length});
+        // ---- the two-phase encoder must give the same bytes, rates and checkpoints
+        {
+            HostStore st2 = st;
+            memset(st2.s, 0, sizeof st2.s); memset(st2.neg, 0, sizeof st2.neg); memset(st2.vis, 0, sizeof st2.vis);
+            memset(st2.ref, 0, sizeof st2.ref); memset(st2.sps, 0, sizeof st2.sps);
+            std::vector<uint8_t> syms, bytes2;
+            static EmitObs mobs;
+            SymbolEmitter<SymPut> em{0, SymPut{&syms}};
+            const int np2 = emit_block(st2, em, w, h, orient, numbps, mobs);
+            static MqCheckpoint ck2[120 * 16];
+            CkView ckv2{ck2, nstr};
+            int rates2[kMaxPasses];
+            EncodeResult r2 = mq_encode_stream(SymGet{&syms}, em.n, np2, VecSink{&bytes2}, VecAt{&bytes2}, rates2, ckv2);
+            finalize_checkpoints(ckv2, np2, nstr, BufSrc{bytes2.data(), r2.length});
+            bool same = np2 == r.totalpasses && r2.length == r.length && memcmp(bytes2.data(), bytes.data(), (size_t) r.length) == 0 &&
+                        memcmp(st2.sps, st.sps, sizeof st.sps) == 0;
+            for (int p = 0; same && p < np2; p++) same = rates2[p] == rates[p];
+            for (int i = 0; same && i < np2 * nstr; i++) same = memcmp(&ck2[i], &eobs.ck[i], sizeof(MqCheckpoint)) == 0;
+            if (!same) { printf("trial %d TWO-PHASE ENCODER mismatch (passes %d/%d len %d/%d)\n", t, np2, r.totalpasses, r2.length, r.length); bad++; continue; }
+        }
         bool ok = r.totalpasses == opasses && r.length == (opasses ? orates[opasses - 1] >= 0 ? r.length : 0 : 0);
         int olen = 0;
         // oracle's len is mq numbytes; recover it as the max rate (last pass rate equals it unless trimmed for FF)

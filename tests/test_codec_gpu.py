@@ -111,6 +111,26 @@ def test_era5_like_batch_matches_oracle(mode, err):
         assert np.abs(dec[f] - frames[f]).max() <= 1.01 * tgt + 1e-3
 
 
+def test_sliced_batches_equal_single_engine(monkeypatch):
+    """The frames API cuts a large batch into slices that run concurrently on their own engines / streams /
+    host threads (EBCC_HIP_SLICES): streams and decoded fields must not depend on the slicing."""
+    frames = np.stack([L.era5_like(96, 160, s, 1.0 + 0.1 * (s % 5), 0.5 + 0.2 * (s % 3)) for s in range(19)])
+    frames[5] = 2.5                                             # a constant field inside a slice
+    cfg = L.make_config((1, 96, 160), base_cr=20.0, error=0.05, residual_type=L.MAX_ERROR)
+    res = {}
+    for k in ("1", "2", "4"):
+        monkeypatch.setenv("EBCC_HIP_SLICES", k)
+        with L.Context(len(frames), 96, 160) as ctx:
+            got = ctx.encode_frames(frames, cfg)
+            res[k] = (got, ctx.decode_frames(got))
+    L.oracle().orc_set_j2k_backend(0)
+    for f in (0, 5, 18):
+        assert res["1"][0][f] == L.orc_encode(frames[f], cfg), f
+    for k in ("2", "4"):
+        assert res[k][0] == res["1"][0], k
+        assert np.array_equal(res[k][1], res["1"][1]), k
+
+
 def test_constant_and_zero_fields():
     for v in (3.25, 0.0):
         data = np.full((64, 64), v, np.float32)

@@ -25,12 +25,20 @@ struct HostStore {
     u64 &S(int y) { return s[y + 1]; } u64 &NEG(int y) { return neg[y]; } u64 &VIS(int y) { return vis[y]; } u64 &REF(int y) { return ref[y]; }
     u64 &SPS(int y) { return sps[y]; } u64 SGN(int y) { return y < 64 ? sgn[y] : 0; } u64 BP(int p, int y) { return y < 64 ? bp[(size_t) p * 64 + y] : 0; }
 };
+struct CountCoder;
+struct StripeObs {               // symbol count at every stripe start
+    std::vector<long> *marks; CountCoder *cc;
+    template <class Mq> void pass_start(int, const Mq &) {}
+    template <class Mq> void stripe_start(int, const Mq &m);
+    template <class St> void sigprop_done(int, St &) {}
+};
 struct CountCoder {      // counts decisions by kind; no arithmetic coding
     long n[5] = {0, 0, 0, 0, 0};   // zc, sc, mr, agg, uni
     void encode_zc(int c, int d) { encode(c, d); } void encode_sc(int c, int d) { encode(c, d); } void encode_mag(int c, int d) { encode(c, d); }
     void encode_agg(int d) { encode(CTX_AGG, d); } void encode_uni(int d) { encode(CTX_UNI, d); }
     void encode(int ctx, int) { if (ctx <= CTX_ZC0 + 8 && ctx >= CTX_ZC0) n[0]++; else if (ctx >= CTX_SC0 && ctx < CTX_SC0 + 5) n[1]++; else if (ctx >= CTX_MAG0 && ctx < CTX_MAG0 + 3) n[2]++; else if (ctx == CTX_AGG) n[3]++; else n[4]++; }
 };
+template <class Mq> void StripeObs::stripe_start(int, const Mq &m) { marks->push_back(m.n[0] + m.n[1] + m.n[2] + m.n[3] + m.n[4]); }
 int main(int argc, char **argv)
 {
     const int H = 721, W = 1440;
@@ -42,7 +50,7 @@ int main(int argc, char **argv)
     printf("%d blocks\n", n);
     long tot[5] = {0}, iters[3] = {0};
     // per block, per pass: symbols and iterations
-    std::vector<std::vector<long>> sym(n), it(n);
+    std::vector<std::vector<long>> sym(n), it(n), marks(n);
     long bytes = 0;
     for (int b = 0; b < n; b++) {
         Blk &B = blocks[b];
@@ -53,7 +61,8 @@ int main(int argc, char **argv)
         HostStore st; st.bp.assign((size_t) P * 64, 0);
         for (int y = 0; y < B.h; y++) for (int x = 0; x < B.w; x++) { int32_t v = B.q[y * B.w + x]; uint32_t a = (uint32_t) abs(v) >> 6; if (v < 0) st.sgn[y] |= 1ull << x; for (int p = 0; p < P; p++) if ((a >> p) & 1) st.bp[(size_t) p * 64 + y] |= 1ull << x; }
         CountCoder cc;
-        Passes<true, HostStore, CountCoder> ps(st, cc, B.w, B.h, B.orient);
+        StripeObs so{&marks[b], &cc};
+        Passes<true, HostStore, CountCoder, StripeObs> ps(st, cc, B.w, B.h, B.orient, &so);
         int type = 2;
         for (int bp = P - 1; bp >= 0;) {
             long before = cc.n[0] + cc.n[1] + cc.n[2] + cc.n[3] + cc.n[4], ib = g_stat[0] + g_stat[1] + g_stat[2];
@@ -63,6 +72,7 @@ int main(int argc, char **argv)
             if (++type == 3) { type = 0; bp--; }
         }
         for (int k = 0; k < 5; k++) tot[k] += cc.n[k];
+        marks[b].push_back(cc.n[0] + cc.n[1] + cc.n[2] + cc.n[3] + cc.n[4]);
     }
     for (int k = 0; k < 3; k++) iters[k] = g_stat[k];
     long S = tot[0] + tot[1] + tot[2] + tot[3] + tot[4];
@@ -84,6 +94,19 @@ int main(int argc, char **argv)
         }
         printf("G=%2d: waves %d, pass-locked iterations/wave %.0f, pass-locked symbols/wave %.0f, free-running max symbols/wave %.0f, mean symbols/lane %.0f\n",
                G, (n + G - 1) / G, lock_it / ((n + G - 1) / G), lock_sym / ((n + G - 1) / G), max_tot / ((n + G - 1) / G), sum_sym / n);
+    }
+    // slot-locked (pass, stripe) cost: blocks of a wave have the same number of stripes mostly; align by slot index
+    for (int G : {32, 64}) {
+        double tot_lock = 0; int waves = 0;
+        for (int b0 = 0; b0 < n; b0 += G, waves++) {
+            size_t ns = 0; for (int b = b0; b < std::min(n, b0 + G); b++) ns = std::max(ns, marks[b].size());
+            for (size_t k = 0; k + 1 < ns; k++) {
+                long m = 0;
+                for (int b = b0; b < std::min(n, b0 + G); b++) if (k + 1 < marks[b].size()) m = std::max(m, marks[b][k + 1] - marks[b][k]);
+                tot_lock += m;
+            }
+        }
+        printf("G=%d: stripe-locked symbols/wave %.0f\n", G, tot_lock / waves);
     }
     return 0;
 }

@@ -14,6 +14,7 @@
 #include <map>
 #include <atomic>
 #include <mutex>
+#include <condition_variable>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -203,6 +204,17 @@ struct PhaseTimer {
     }
 };
 
+// Hand-over point between the slices of a batch (run_slices): slice i + 1 starts when slice i has issued its
+// heavy first stage, so that the slices run out of phase and the GPU-bound stage of one overlaps the host- or
+// latency-bound stages of the other.
+struct SliceGate {
+    std::mutex m;
+    std::condition_variable cv;
+    bool open = false;
+    void release() { { std::lock_guard<std::mutex> l(m); open = true; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return open; }); }
+};
+
 struct ProbeRec { float cr = -1; unsigned long long nbad = 0; int stream_bytes = 0; double err_sum = 0; };
 
 struct Job {                     // host-side state of one frame being encoded
@@ -377,8 +389,10 @@ void run_searches(Batch *set0, Batch *set1, Jobs &jobs, size_t n_pix)
 // ------------------------------------------------------------------------------------------------
 // ebcc_encode for a batch of device-resident single-frame chunks.  Returns 0, 1 (error) or 2 (NaN/Inf).
 // ------------------------------------------------------------------------------------------------
-int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
+int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
+                 SliceGate *next = nullptr)
 {
+    struct Release { SliceGate *g; ~Release() { if (g) g->release(); } } release_on_exit{next};   // (error paths too)
     const EncodeEnv env;
     const double q_target = 1 - env.base_error_quantile;
     const int mode = (int) cfg->residual_compression_type;
@@ -393,6 +407,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     // ---- statistics, scaling, transform, tier-1: once per frame
     launch_input_stats(d_frames, (int) n, n_pix, ctx->rb.fs, s);
     launch_j2k_analysis(d_frames, jb, (int) n, s);
+    if (next) {                                   // the next slice may start: this one's first stage is queued
+        const char *e = getenv("EBCC_HIP_SLICE_GATE");
+        if (e && atoi(e) == 1) { EBCC_HIP_CHECK(hipStreamSynchronize(s)); }
+        next->release(); release_on_exit.g = nullptr;
+    }
     fetch_frame_states(ctx, n);
     b.fetch_jf();
     for (size_t f = 0; f < n; f++) {
@@ -670,8 +689,10 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
 // ------------------------------------------------------------------------------------------------
 // ebcc_decode for a batch of single-frame EBCC streams -> device buffer d_out [n][H*W]
 // ------------------------------------------------------------------------------------------------
-int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n, float *d_out)
+int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n, float *d_out,
+                 SliceGate *next = nullptr)
 {
+    struct Release { SliceGate *g; ~Release() { if (g) g->release(); } } release_on_exit{next};
     J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
     hipStream_t s = ctx->stream;
     const size_t n_pix = ctx->n_pix;
@@ -725,6 +746,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     push_frame_states(ctx, n);
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
     launch_j2k_decode(jb, (int) n, s);
+    if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
     if (any_resid) {
         const size_t slot = ctx->rb.stream_words * 4;
         for (size_t f = 0; f < n; f++) {
@@ -804,16 +826,18 @@ template <class Fn>
 static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn)
 {
     const size_t k = slice_engines(ctx, n_frames);
-    if (k == 1) return fn(ctx, (size_t) 0, n_frames);
+    if (k == 1) return fn(ctx, (size_t) 0, n_frames, (SliceGate *) nullptr);
     const size_t per = (n_frames + k - 1) / k;
     std::vector<int> rc(k, 0);
+    std::vector<SliceGate> gates(k);
     std::vector<std::thread> th;
     for (size_t i = 0; i < k; i++) {
         const size_t lo = i * per, hi = std::min(n_frames, lo + per);
         if (lo >= hi) break;
         th.emplace_back([&, i, lo, hi]() {
             EBCC_HIP_CHECK(hipSetDevice(ctx->device));
-            rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo);
+            if (i > 0) gates[i - 1].wait();
+            rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i]);
         });
     }
     for (auto &t : th) t.join();
@@ -862,8 +886,8 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     log_set_level_from_env();
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     const size_t n_pix = ctx->n_pix;
-    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt) {
-        return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo);
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
+        return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo, next);
     });
 }
 
@@ -875,8 +899,8 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     const size_t n_pix = ctx->n_pix;
-    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt) {
-        return decode_batch(c, streams + lo, sizes + lo, cnt, d_frames_out + lo * n_pix);
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
+        return decode_batch(c, streams + lo, sizes + lo, cnt, d_frames_out + lo * n_pix, next);
     });
 }
 

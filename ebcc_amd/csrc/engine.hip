@@ -208,6 +208,8 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_u64c) hipHostFree(ctx->h_u64c);
     if (ctx->h_active) hipHostFree(ctx->h_active);
     if (ctx->h_fs) hipHostFree(ctx->h_fs);
+    if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

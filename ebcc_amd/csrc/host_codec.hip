@@ -242,6 +242,14 @@ struct Job {                     // host-side state of one frame being encoded
     }
 };
 
+// The engine's second stream is created on first use: every stream beyond the runtime's few hardware queues
+// shares one, and kernels that share a queue run one after the other.
+hipStream_t second_stream(ebcc_hip_ctx *c)
+{
+    if (!c->stream2) EBCC_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    return c->stream2;
+}
+
 struct Batch {
     ebcc_hip_ctx *ctx;
     J2kBuffers &jb;
@@ -254,7 +262,7 @@ struct Batch {
     hipStream_t s;
     Batch(ebcc_hip_ctx *c, const float *d, size_t n_, bool alt = false)
         : ctx(c), jb(*static_cast<J2kBuffers *>(alt ? c->j2k_alt : c->j2k)), d_frames(d), n(n_), jf(n_), active(n_, 0),
-          state_cr(n_, -1.f), d_active(alt ? c->d_active2 : c->d_active), s(alt ? c->stream2 : c->stream) {}
+          state_cr(n_, -1.f), d_active(alt ? c->d_active2 : c->d_active), s(alt ? second_stream(c) : c->stream) {}
     void fetch_jf()
     {
         EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n, hipMemcpyDeviceToHost, s));
@@ -744,6 +752,18 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         }
     }
     push_frame_states(ctx, n);
+    // The residual layer (SPIHT decode + synthesis: one wave per frame, latency-bound) does not depend on the
+    // base layer until the final addition, so it runs on the engine's second stream beside the tier-1 decode.
+    hipStream_t s2 = s;
+    if (any_resid && getenv("EBCC_HIP_CONCURRENT_RESIDUAL_DECODE")) {    // (no gain measured once batches run as slices)
+        s2 = second_stream(ctx);
+        if (!ctx->ev_a) {
+            EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+            EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+        }
+        EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));                       // frame states are on the device
+        EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
+    }
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
     launch_j2k_decode(jb, (int) n, s);
     if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
@@ -754,13 +774,17 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
             ctx->h_u64b[f] = coeffs[f].size() * 8;
             if (ctx->h_active[f])
                 EBCC_HIP_CHECK(hipMemcpyAsync((uint8_t *) ctx->rb.stream + f * slot, coeffs[f].data(), coeffs[f].size(),
-                                              hipMemcpyHostToDevice, s));
+                                              hipMemcpyHostToDevice, s2));
         }
-        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, n * sizeof(int), hipMemcpyHostToDevice, s));
-        launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n, ctx->d_active, s);
-        launch_synthesis(ctx->rb, (int) n, ctx->d_active, s);
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s2));
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s2));
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, n * sizeof(int), hipMemcpyHostToDevice, s2));
+        launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n, ctx->d_active, s2);
+        launch_synthesis(ctx->rb, (int) n, ctx->d_active, s2);
+        if (s2 != s) {
+            EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
+            EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
+        }
         launch_add_residual(jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "j2k.hpp"
 #include "t1_core.hpp"
@@ -21,7 +22,7 @@ namespace {
 
 constexpr int kMainHeaderBytes = 135;
 constexpr int kRateThreads = 512;     // k_rate: one workgroup per frame, about one code-block per thread
-constexpr int kWriteThreads = 64;     // k_write: one wave per frame
+constexpr int kWriteThreads = 256;    // k_write: one workgroup per frame (headers by one lane per resolution, bodies by all)
 
 __device__ inline int floorlog2d(int a) { return a > 1 ? 31 - __clz(a) : 0; }
 
@@ -123,6 +124,11 @@ __device__ int packet_header(int r, const J2kGeom &g, const Trees &t, const shor
     return bio.n;
 }
 
+__host__ __device__ inline size_t rate_lds_bytes(int nblocks, int nodes)
+{
+    return 2 * ((((size_t) nblocks * 2 + 7) / 8) * 8) + (size_t) nodes * 16 + (size_t) nblocks * 20 + 128;
+}
+
 // LDS carve-up shared by the rate and write kernels
 struct RateLds {
     short *npass;
@@ -167,13 +173,36 @@ __device__ inline void tree_setmin(const J2kBand &bd, short *val, int cx, int cy
 template <int NT>
 __device__ void trees_static(const J2kGeom &g, RateLds &L, const int *numbps, int gid0, int lane)
 {
-    for (int i = lane; i < g.tree_nodes; i += NT) L.mval0[i] = 999;
+    // leaves, then every level from its (up to four) children: a node's value is the minimum below it
+    for (int b = lane; b < g.nblocks; b += NT) {
+        int bi = 0;
+        while (bi + 1 < g.nbands && g.bands[bi + 1].first_block <= b) bi++;
+        const J2kBand &bd = g.bands[bi];
+        const int k = b - bd.first_block, cy = k / bd.ncw, cx = k - cy * bd.ncw;
+        L.mval0[bd.tree_off + bd.lvl_off[0] + cy * bd.lvl_w[0] + cx] = (short) (bd.numbps - numbps[gid0 + b]);
+    }
     __syncthreads();
-    if (lane < g.nbands) {                                           // one lane per band: sequential min propagation
-        const J2kBand &bd = g.bands[lane];
-        for (int cy = 0; cy < bd.nch; cy++)
-            for (int cx = 0; cx < bd.ncw; cx++)
-                tree_setmin(bd, L.mval0, cx, cy, bd.numbps - numbps[gid0 + bd.first_block + cy * bd.ncw + cx]);
+    for (int l = 1; l < 12; l++) {
+        bool any = false;
+        for (int bi = 0; bi < g.nbands; bi++) {
+            const J2kBand &bd = g.bands[bi];
+            if (l >= bd.tree_levels) continue;
+            any = true;
+            const int w = bd.lvl_w[l], h = bd.lvl_h[l], cw = bd.lvl_w[l - 1], ch = bd.lvl_h[l - 1];
+            for (int n = lane; n < w * h; n += NT) {
+                const int j = n / w, i = n - j * w;
+                const short *c = L.mval0 + bd.tree_off + bd.lvl_off[l - 1];
+                int m = c[(2 * j) * cw + 2 * i];
+                if (2 * i + 1 < cw) m = min(m, (int) c[(2 * j) * cw + 2 * i + 1]);
+                if (2 * j + 1 < ch) {
+                    m = min(m, (int) c[(2 * j + 1) * cw + 2 * i]);
+                    if (2 * i + 1 < cw) m = min(m, (int) c[(2 * j + 1) * cw + 2 * i + 1]);
+                }
+                L.mval0[bd.tree_off + bd.lvl_off[l] + n] = (short) m;
+            }
+        }
+        if (!any) break;
+        __syncthreads();
     }
     __syncthreads();
 }
@@ -195,23 +224,34 @@ __device__ void trees_reset(const J2kGeom &g, RateLds &L, int lane)
     __syncthreads();
 }
 
+// Per-pass rate / distortion tables of one frame.  k_rate walks them ~60 times per call, so they are staged in
+// LDS when all code-blocks of the frame fit (12 bytes per coding pass); otherwise they are read from global
+// memory as they are.
+struct PassTab {
+    const int *rates;              // [nblocks][kJ2kMaxPasses] of this frame
+    const double *disto;
+    const double *l_disto;         // LDS copies, code-block b at l_off[b] .. + totalpasses
+    const int *l_rate;
+    const int *l_off;
+    bool lds;
+    __device__ int rate(int b, int p) const { return lds ? l_rate[l_off[b] + p] : rates[(size_t) b * kJ2kMaxPasses + p]; }
+    __device__ double dist(int b, int p) const { return lds ? l_disto[l_off[b] + p] : disto[(size_t) b * kJ2kMaxPasses + p]; }
+};
+
 // opj_tcd_makelayer for one quality layer
 template <int NT>
-__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const int *rates, const double *disto,
-                           int gid0, double thresh, int lane)
+__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane)
 {
     for (int b = lane; b < g.nblocks; b += NT) {
         const int tp = totalpasses[gid0 + b];
-        const int *rt = rates + (size_t) (gid0 + b) * kJ2kMaxPasses;
-        const double *ds = disto + (size_t) (gid0 + b) * kJ2kMaxPasses;
         int n = 0;
         if (thresh < 0) n = tp;
         else {
             int rbase = 0;                                           // rate / distortion of the last pass taken
             double dbase = 0;
             for (int p = 0; p < tp; p++) {
-                const int rp = rt[p];
-                const double dp = ds[p];
+                const int rp = pt.rate(b, p);
+                const double dp = pt.dist(b, p);
                 unsigned int dr;
                 double dd;
                 if (n == 0) { dr = (unsigned int) rp; dd = dp; }
@@ -300,7 +340,8 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
     if (lane < kJ2kRes) atomicOr(&L.raw[(g.res_first[lane] * 128) >> 5], 0x80000000u);   // leading "packet present" bit
     __syncthreads();
     // per-leaf header bits: A = inclusion + zero-bit-plane bits, B = passes + Lblock comma code + length
-    int body = 0;
+    __shared__ int s_wave[NT / 64];
+    int body = 0, running = 0;
     for (int base = 0; base < g.nblocks; base += NT) {
         const int b = base + lane;
         unsigned long long A = 0, B = 0;
@@ -344,29 +385,40 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
                 nbb += lb;
                 body += seglen;
             }
-            L.leafbits[b] = na + nbb;
+        }
+        // exclusive scan of the header bit counts over all leaves (packet order): L.leafbits[b] = bits before leaf b
+        {
+            const int v = b < g.nblocks ? na + nbb : 0;
+            int x = v;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((lane & 63) >= d) x += y; }
+            if ((lane & 63) == 63) s_wave[lane >> 6] = x;
+            __syncthreads();
+            int before = running;
+            for (int w = 0; w < (lane >> 6); w++) before += s_wave[w];
+            if (b < g.nblocks) L.leafbits[b] = before + x - v;
+            int tot = 0;
+            for (int w = 0; w < NT / 64; w++) tot += s_wave[w];
+            running += tot;
         }
         __syncthreads();
-        // exclusive offsets inside the resolution: leaves are in packet order, resolutions are contiguous
+        // offsets inside the resolution: leaves are in packet order, resolutions are contiguous
         if (b < g.nblocks) {
-            int off = 1;                                                           // the leading "packet present" bit
-            for (int j = g.res_first[res]; j < b; j++) off += L.leafbits[j];
+            const int off = 1 + L.leafbits[b] - L.leafbits[g.res_first[res]];      // 1: the leading "packet present" bit
             const int region = g.res_first[res] * 128;
             raw_put(L.raw, region + off, A, na);
             raw_put(L.raw, region + off + na, B, nbb);
         }
         __syncthreads();
     }
+    if (lane == 0) L.leafbits[g.nblocks] = running;
+    __syncthreads();
     for (int d = 32; d >= 1; d >>= 1) body += __shfl_xor(body, d);
     // stuffing-aware byte count: one wave per resolution (the search for the next 0xFF byte is a chain)
     const int wl = lane & 63;
     int count = 0;
     for (int r = lane >> 6; r < kJ2kRes; r += NT / 64) {
         const int region = g.res_first[r] * 128;
-        int T = 0;
-        for (int j = g.res_first[r] + wl; j < g.res_first[r + 1]; j += 64) T += L.leafbits[j];
-        for (int d = 32; d >= 1; d >>= 1) T += __shfl_xor(T, d);
-        T += 1;
+        const int T = 1 + L.leafbits[g.res_first[r + 1]] - L.leafbits[g.res_first[r]];
         int p = 0;
         for (;;) {
             // first full byte == 0xFF at or after bit p (8-bit groups)
@@ -397,7 +449,7 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
 __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ numbps, const int *__restrict__ totalpasses,
                                                         const int *__restrict__ rates, const double *__restrict__ disto,
                                                         int *__restrict__ npass_out, const J2kGeom *geom, J2kFrame *jf,
-                                                        const FrameState *fs, const int *active)
+                                                        const FrameState *fs, const int *active, int pass_capacity)
 {
     extern __shared__ unsigned char lds_raw[];
     __shared__ int s_sum, s_changed;
@@ -410,6 +462,32 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
     trees_static<kRateThreads>(g, L, numbps, gid0, lane);
     for (int b = lane; b < g.nblocks; b += kRateThreads) L.prev[b] = -1;
+    // pass tables into LDS (behind the RateLds carve-up) when they fit
+    __shared__ int s_fit;
+    unsigned char *extra = lds_raw + ((rate_lds_bytes(g.nblocks, g.tree_nodes) + 15) & ~(size_t) 15);
+    int *l_off = (int *) extra;
+    double *l_disto = (double *) (extra + (((size_t) g.nblocks * 4 + 15) & ~(size_t) 15));
+    for (int b = lane; b < g.nblocks; b += kRateThreads) l_off[b] = totalpasses[gid0 + b];
+    __syncthreads();
+    if (lane == 0) {
+        int acc = 0;
+        for (int b = 0; b < g.nblocks; b++) { const int tp = l_off[b]; l_off[b] = acc; acc += tp; }
+        s_fit = acc <= pass_capacity ? acc : -1;
+    }
+    __syncthreads();
+    const int n_entries = s_fit;
+    int *l_rate = (int *) (l_disto + (n_entries > 0 ? n_entries : 0));
+    PassTab pt{rates + (size_t) gid0 * kJ2kMaxPasses, disto + (size_t) gid0 * kJ2kMaxPasses, l_disto, l_rate, l_off, n_entries >= 0};
+    if (pt.lds) {
+        for (int b = lane; b < g.nblocks; b += kRateThreads) {
+            const int tp = totalpasses[gid0 + b], o = l_off[b];
+            for (int p = 0; p < tp; p++) {
+                l_rate[o + p] = pt.rates[(size_t) b * kJ2kMaxPasses + p];
+                l_disto[o + p] = pt.disto[(size_t) b * kJ2kMaxPasses + p];
+            }
+        }
+        __syncthreads();
+    }
     int prev_bytes = 0;
     // size of the current assignment; identical assignments (late bisection steps) reuse the previous result
     auto sized = [&]() -> int {
@@ -445,11 +523,11 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     double mn = DBL_MAX, mx = 0;
     for (int b = lane; b < g.nblocks; b += kRateThreads) {
         const int tp = totalpasses[gid0 + b];
-        const int *rt = rates + (size_t) (gid0 + b) * kJ2kMaxPasses;
-        const double *ds = disto + (size_t) (gid0 + b) * kJ2kMaxPasses;
+        int rprev = 0; double dprev = 0;
         for (int p = 0; p < tp; p++) {
-            int dr; double dd;
-            if (p == 0) { dr = rt[0]; dd = ds[0]; } else { dr = rt[p] - rt[p - 1]; dd = ds[p] - ds[p - 1]; }
+            const int rp = pt.rate(b, p); const double dp = pt.dist(b, p);
+            const int dr = rp - rprev; const double dd = dp - dprev;
+            rprev = rp; dprev = dp;
             if (dr == 0) continue;
             double sl = dd / dr;
             if (sl < mn) mn = sl;
@@ -472,7 +550,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             thresh = (lo + hi) / 2;
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
-            make_layer<kRateThreads>(g, L, totalpasses, rates, disto, gid0, thresh, lane);
+            make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane);
             const int bytes = sized();
             if ((long long) bytes > maxlen) { lo = thresh; continue; }
             hi = thresh;
@@ -480,7 +558,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         }
         good = stable == 0 ? thresh : stable;
     }
-    make_layer<kRateThreads>(g, L, totalpasses, rates, disto, gid0, good, lane);
+    make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, good, lane);
     const int body = sized();
     for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
     if (lane == 0) {
@@ -527,7 +605,7 @@ __global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__
     // pass 2: headers
     trees_reset<kWriteThreads>(g, L, lane);
     if (lane < kJ2kRes) { int body = 0; packet_header(lane, g, L.t, L.npass, rates, gid0, base + s_off[lane], &body); }
-    // bodies: every lane copies code-block segments; offsets by a serial walk per resolution (cheap)
+    // bodies: destination offsets by a serial walk per resolution (cheap), then every thread copies
     __syncthreads();
     if (lane < kJ2kRes) {
         int off = s_off[lane] + s_hdr[lane];
@@ -536,12 +614,21 @@ __global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__
             if (bd.res != lane) continue;
             for (int k = 0; k < bd.ncw * bd.nch; k++) {
                 const int blk = bd.first_block + k, n = L.npass[blk];
-                if (!n) continue;
-                const int seglen = rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
-                const uint8_t *src = cblk_bytes + (size_t) (gid0 + blk) * kJ2kCblkBytes;
-                for (int i = 0; i < seglen; i++) base[off + i] = src[i];
-                off += seglen;
+                L.leafbits[blk] = off;
+                if (n) off += rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
             }
+        }
+    }
+    __syncthreads();
+    {
+        const int wave = lane >> 6, wl = lane & 63;
+        for (int blk = wave; blk < g.nblocks; blk += kWriteThreads / 64) {           // one wave per code-block segment
+            const int n = L.npass[blk];
+            if (!n) continue;
+            const int seglen = rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
+            const uint8_t *src = cblk_bytes + (size_t) (gid0 + blk) * kJ2kCblkBytes;
+            uint8_t *dst = base + L.leafbits[blk];
+            for (int i = wl; i < seglen; i += 64) dst[i] = src[i];
         }
     }
     if (lane == 0) {
@@ -869,10 +956,7 @@ __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, 
         b[i] = (float) v[i] * (0.5f * geom->bands[blocks[blkmap[i]].band].step_dec);
 }
 
-size_t rate_lds(const J2kGeom &g)
-{
-    return 2 * ((((size_t) g.nblocks * 2 + 7) / 8) * 8) + (size_t) g.tree_nodes * 16 + (size_t) g.nblocks * 20 + 128;
-}
+size_t rate_lds(const J2kGeom &g) { return rate_lds_bytes(g.nblocks, g.tree_nodes); }
 
 }  // namespace
 
@@ -880,8 +964,18 @@ size_t rate_lds(const J2kGeom &g)
 void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
     ScopedTiming t("rate_alloc", s);
-    hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), rate_lds(jb.geom), s, jb.numbps, jb.totalpasses, jb.rates,
-                       jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active);
+    // dynamic LDS: the carve-up, the per-block table offsets, then as many (rate, distortion) entries as fit
+    const size_t head = ((rate_lds(jb.geom) + 15) & ~(size_t) 15) + (((size_t) jb.geom.nblocks * 4 + 15) & ~(size_t) 15);
+    const size_t budget = 150 * 1024;
+    size_t want = (size_t) jb.geom.nblocks * kJ2kMaxPasses;
+    if (head + want * 12 > budget) want = head < budget ? (budget - head) / 12 : 0;
+    const size_t lds = head + want * 12;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        EBCC_HIP_CHECK(hipFuncSetAttribute((const void *) k_rate, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    });
+    hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), lds, s, jb.numbps, jb.totalpasses, jb.rates,
+                       jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want);
 }
 
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)

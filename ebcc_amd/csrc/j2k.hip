@@ -36,9 +36,14 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->SUF = ctx_alloc<unsigned long long>(ctx, groups * (kJ2kMaxPlanes + 2) * 64 * 64)) != nullptr;
     ok &= (jb->SPS = ctx_alloc<unsigned long long>(ctx, groups * 64 * 64)) != nullptr;
     ok &= (jb->VISP = ctx_alloc<unsigned long long>(ctx, groups * kJ2kMaxPlanes * 64 * 64)) != nullptr;
-    ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kCkptPerBlock * 40)) != nullptr;
-    jb->SYM = nullptr;                           // the decision streams of the two-phase encoder are large: only on request
-    if (const char *e = getenv("EBCC_T1_TWO_PHASE")) if (atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * 64 * (size_t) kJ2kSymCap + 256)) != nullptr;
+    ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * j2k_ckpt_group_bytes())) != nullptr;
+    // decision streams of the two-phase tier-1 encoder (default; EBCC_T1_TWO_PHASE=0 selects the single-kernel encoder
+    // and saves this buffer)
+    jb->SYM = nullptr;
+    {
+        const char *e = getenv("EBCC_T1_TWO_PHASE");
+        if (!e || atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * 64 * (size_t) kJ2kSymCap + 256)) != nullptr;
+    }
     ok &= (jb->nsym = ctx_alloc<uint32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->qplane = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;

@@ -48,27 +48,21 @@ struct J2kGeom {
 constexpr int kJ2kSymCap = 4096 * (kJ2kMaxPlanes + 1) + 2048;  // decision stream of one code-block: at most planes + 1 decisions per sample, plus stripe markers
 constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
 
-// Checkpoint storage: structure of arrays, lane-interleaved like the tier-1 state, so that the 64 code-blocks
-// of a group - which reach the same (pass, stripe) together - store one slot with coalesced writes.
-//   group base + field array + slot * 64 + lane
+// Checkpoint storage: nine 32-bit field arrays per group of 64 code-blocks (a, c, ct, pos, then the 19 context
+// states one byte each in five words), lane-interleaved like the tier-1 state:
+//   group base + (field * kJ2kCkptPerBlock + slot) * 64 * 4 + lane * 4          slot = pass * 16 + stripe
+constexpr int kJ2kCkptFields = 9;
+__host__ __device__ inline size_t j2k_ckpt_group_bytes() { return (size_t) kJ2kCkptFields * kJ2kCkptPerBlock * 64 * 4; }
 struct J2kCkptView {
-    std::uint32_t *a, *c;          // [slots][64]
-    int *ct, *pos;
-    unsigned long long *w0, *w1, *w2;
-    __host__ __device__ static size_t group_bytes() { return (size_t) kJ2kCkptPerBlock * 64 * 40; }
-    __host__ __device__ static J2kCkptView of(void *base, size_t group, int lane)
+    unsigned char *base;           // group base
+    std::uint32_t lane4;           // lane * 4
+    __host__ __device__ std::uint32_t &at(int field, std::uint32_t slot) const
     {
-        unsigned char *g = (unsigned char *) base + group * group_bytes();
-        const size_t n = (size_t) kJ2kCkptPerBlock * 64;
-        J2kCkptView v;
-        v.w0 = (unsigned long long *) g + lane;
-        v.w1 = v.w0 + n;
-        v.w2 = v.w1 + n;
-        v.a = (std::uint32_t *) ((unsigned long long *) g + 3 * n) + lane;
-        v.c = v.a + n;
-        v.ct = (int *) (v.c + n);
-        v.pos = v.ct + n;
-        return v;
+        return *(std::uint32_t *) (base + (((std::uint32_t) field * kJ2kCkptPerBlock + slot) * 256u + lane4));
+    }
+    __host__ __device__ static J2kCkptView of(void *all, size_t group, int lane)
+    {
+        return J2kCkptView{(unsigned char *) all + group * j2k_ckpt_group_bytes(), (std::uint32_t) lane * 4u};
     }
 };
 

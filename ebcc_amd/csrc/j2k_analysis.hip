@@ -486,36 +486,32 @@ struct DevAt {
 // before the point where its truncated segment ends (j2k_rate.hip).  They are derived from the encoder's own registers - see t1::finalize_checkpoints - so no
 // decode of the segment is needed.
 struct CkObserver {
-    unsigned char *ck;             // group base of the checkpoint arrays (J2kCkptView layout)
+    J2kCkptView ck;                // checkpoint slots of this code-block (slot = pass * 16 + stripe)
     unsigned char *visp;           // group base of the per-plane visited masks
     uint32_t lane8;                // lane * 8
     int cur = 0;
-    static constexpr uint32_t kN = (uint32_t) kJ2kCkptPerBlock * 64;     // elements per field array
-    __device__ unsigned long long &w(int k, uint32_t slot) const { return *(unsigned long long *) (ck + ((kN * k + slot * 64u) * 8u + lane8)); }
-    __device__ uint32_t &u(int k, uint32_t slot) const { return *(uint32_t *) (ck + (kN * 24u + (kN * k + slot * 64u) * 4u + (lane8 >> 1))); }
     template <class Mq>
     __device__ void pass_start(int p, const Mq &) { cur = p * 16; }
     template <class Mq>
-    __device__ void stripe_start(int y0, const Mq &m)
+    __device__ void stripe_start(int y0, const Mq &m)                       // (single-phase encoder: packed contexts)
     {
-        const uint32_t i = (uint32_t) (cur + (y0 >> 2));
-        u(0, i) = m.a; u(1, i) = m.c & 0xFFFFu; u(3, i) = m.shifts;
-        w(0, i) = m.cx.w0; w(1, i) = m.cx.w1; w(2, i) = m.cx.w2;
+        uint32_t x[5];
+        m.cx.to_bytes(x);
+        store(0, cur + (y0 >> 2), m.a, m.c & 0xFFFFu, m.shifts, x);
     }
     // CkArray of t1::mq_encode_stream / t1::finalize_checkpoints
-    __device__ void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, unsigned long long w0, unsigned long long w1,
-                          unsigned long long w2)
+    __device__ void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, const uint32_t x[5])
     {
         const uint32_t i = (uint32_t) (p * 16 + s);
-        u(0, i) = a; u(1, i) = c16; u(3, i) = shifts;
-        w(0, i) = w0; w(1, i) = w1; w(2, i) = w2;
+        ck.at(0, i) = a; ck.at(1, i) = c16; ck.at(3, i) = shifts;
+        for (int j = 0; j < 5; j++) ck.at(4 + j, i) = x[j];
     }
-    __device__ uint32_t shifts(int p, int s) const { return u(3, (uint32_t) (p * 16 + s)); }
-    __device__ uint32_t c16(int p, int s) const { return u(1, (uint32_t) (p * 16 + s)); }
+    __device__ uint32_t shifts(int p, int s) const { return ck.at(3, (uint32_t) (p * 16 + s)); }
+    __device__ uint32_t c16(int p, int s) const { return ck.at(1, (uint32_t) (p * 16 + s)); }
     __device__ void finish(int p, int s, uint32_t c, int ct, int pos)
     {
         const uint32_t i = (uint32_t) (p * 16 + s);
-        u(1, i) = c; u(2, i) = (uint32_t) ct; u(3, i) = (uint32_t) pos;
+        ck.at(1, i) = c; ck.at(2, i) = (uint32_t) ct; ck.at(3, i) = (uint32_t) pos;
     }
     template <class Store>
     __device__ void sigprop_done(int bp, Store &st)
@@ -563,7 +559,7 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     DevStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64),
                 (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (SPS + grp * 64 * 64), lane8};
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    CkObserver obs{(unsigned char *) ckpt + grp * J2kCkptView::group_bytes(), (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
+    CkObserver obs{J2kCkptView{(unsigned char *) ckpt + grp * j2k_ckpt_group_bytes(), lane8 >> 1}, (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
     t1::EncodeResult r = t1::encode_block_observed(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
                                                    blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, obs, tab);
     totalpasses[gid] = r.totalpasses;
@@ -660,6 +656,22 @@ struct SymSrcDev {
     }
 };
 
+struct CtxLds {
+    // the 19 context states of every lane, one byte each: word j of lane l at (j * 64 + l) * 4 (bank = lane)
+    unsigned char *base;           // LDS, already offset by lane * 4
+    __device__ uint32_t ld(int c) const { return base[(uint32_t) (c >> 2) * 256u + (uint32_t) (c & 3)]; }
+    __device__ void st(int c, uint32_t v) { base[(uint32_t) (c >> 2) * 256u + (uint32_t) (c & 3)] = (unsigned char) v; }
+    __device__ void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = *(const uint32_t *) (base + j * 256); }
+};
+struct MqSink {
+    uint8_t *p; int *overflow;
+    __device__ void put(int i, uint32_t b)
+    {
+        if (i >= kJ2kCblkBytes) { *overflow = 1; return; }
+        if (i >= 0) p[i] = (uint8_t) b;
+    }
+};
+
 __global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t *nsym, const int *numbps,
                                                const int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes, void *ckpt,
                                                const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf,
@@ -667,6 +679,7 @@ __global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t
 {
     EBCC_LDS_MQ_TABLE(tab);
     __shared__ uint32_t ring[16 * 64];
+    __shared__ uint32_t ctxw[5 * 64];
     if ((int) threadIdx.x >= lpw) return;
     const int gid0 = blockIdx.x * lpw;
     const int gid = gid0 + threadIdx.x;
@@ -680,11 +693,12 @@ __global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t
     const size_t grp = (size_t) (gid0 >> 6);
     const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    CkObserver ck{(unsigned char *) ckpt + grp * J2kCkptView::group_bytes(), nullptr, lane8};
+    CkObserver ck{J2kCkptView{(unsigned char *) ckpt + grp * j2k_ckpt_group_bytes(), lane8 >> 1}, nullptr, lane8};
     SymSrcDev src{SYM + (size_t) gid * kJ2kSymCap, ring, threadIdx.x};
     src.prefetch(0);
-    t1::EncodeResult r = t1::mq_encode_stream(src, nsym[gid], np, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow},
-                                              DevAt{out, kJ2kCblkBytes}, rates + (size_t) gid * kJ2kMaxPasses, ck, tab);
+    t1::EncodeResult r = t1::mq_encode_stream(src, CtxLds{(unsigned char *) (ctxw + threadIdx.x)}, nsym[gid], np,
+                                              MqSink{out, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
+                                              rates + (size_t) gid * kJ2kMaxPasses, ck, tab);
     cblk_len[gid] = r.length;
     __threadfence();                                                    // the sweep below re-reads this lane's own bytes
     t1::finalize_checkpoints(ck, np, (blk.h + 3) >> 2, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});

@@ -838,7 +838,7 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             const int mp = mid / nstr, ms = mid - mp * nstr;
-            if (ck.pos[(size_t) (mp * 16 + ms) * 64] + 1 < len) lo = mid; else hi = mid - 1;
+            if ((int) ck.at(3, (uint32_t) (mp * 16 + ms)) + 1 < len) lo = mid; else hi = mid - 1;
         }
         const int r = lo / nstr, st = lo - r * nstr;
         plan = r | (st << 8);
@@ -937,8 +937,11 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
         st.VIS(y) = Vv;
     }
     const J2kCkptView cv = J2kCkptView::of(ckpt, grp, gl);
-    const size_t ci = (size_t) (r * 16 + stripe) * 64;
-    const t1::MqCheckpoint ck{cv.a[ci], cv.c[ci], cv.ct[ci], cv.pos[ci], cv.w0[ci], cv.w1[ci], cv.w2[ci]};
+    const uint32_t ci = (uint32_t) (r * 16 + stripe);
+    uint32_t cxb[5];
+    for (int j = 0; j < 5; j++) cxb[j] = cv.at(4 + j, ci);
+    const t1::Contexts cxp = t1::Contexts::from_bytes(cxb);
+    const t1::MqCheckpoint ck{cv.at(0, ci), cv.at(1, ci), (int) cv.at(2, ci), (int) cv.at(3, ci), cxp.w0, cxp.w1, cxp.w2};
     t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
                       np, r, stripe, ck, tab);
 }

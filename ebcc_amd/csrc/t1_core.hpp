@@ -93,6 +93,19 @@ struct Contexts {
         w1 = (w1 & ~(clr & m1)) | (nv & m1);
         w2 = (w2 & ~(clr & m2)) | (nv & m2);
     }
+    // byte-per-context form (context i in byte i & 3 of word i >> 2): what the checkpoints store and what the
+    // stream coder keeps in LDS
+    T1_HD void to_bytes(uint32_t x[5]) const
+    {
+        for (int j = 0; j < 5; j++) x[j] = 0;
+        for (int i = 0; i < NCTX; i++) x[i >> 2] |= get(i) << (8 * (i & 3));
+    }
+    T1_HD static Contexts from_bytes(const uint32_t x[5])
+    {
+        Contexts c{0, 0, 0};
+        for (int i = 0; i < NCTX; i++) c.set(i, (x[i >> 2] >> (8 * (i & 3))) & 0x7Fu);
+        return c;
+    }
     // The caller usually knows the word at compile time (zero-coding contexts live in w0, sign / magnitude /
     // run-length in w1, UNIFORM in w2): no selects between the three words then.
     template <int W>
@@ -777,32 +790,79 @@ T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient
 }
 
 // SymSrc: uint32_t get(uint32_t index), called with index = 0, 1, 2, ... (every lane of a wave is at the same
-// index, which lets a device source refill a staging buffer for all lanes at once);
-// CkArray additionally: void store(p, s, a, c16, shifts, w0, w1, w2).
-template <class SymSrc, class Sink, class ByteAt, class CkArray, class Table = ConstTable>
-T1_HD EncodeResult mq_encode_stream(SymSrc sym, uint32_t nsym, int npasses, Sink sink, ByteAt bytes, int *rates, CkArray &ck,
-                                    Table tab = Table())
+//         index, which lets a device source refill a staging buffer for all lanes at once);
+// CtxMem: uint32_t ld(int ctx), void st(int ctx, uint32_t state), void words(uint32_t out[5]) - the 19 context
+//         states, one byte each (6-bit table index | mps << 6); LDS on the device;
+// Sink:   void put(int index, uint32_t byte), ignored for index < 0;
+// CkArray additionally: void store(p, s, a, c16, shifts, const uint32_t cx[5]).
+// The coder is written for SIMT execution: one code path for MPS and LPS, renormalisation by count, a
+// branch-free BYTEOUT, and the next decision / context state fetched while the current one is coded.
+template <class SymSrc, class CtxMem, class Sink, class ByteAt, class CkArray, class Table = ConstTable>
+T1_HD EncodeResult mq_encode_stream(SymSrc sym, CtxMem cx, uint32_t nsym, int npasses, Sink sink, ByteAt bytes, int *rates,
+                                    CkArray &ck, Table tab = Table())
 {
-    MqEncoder<Sink, Table> mq{0, 0, 0, 0, 0, {0, 0, 0}, sink, tab, 0};
-    mq.init();
+    uint32_t a = 0x8000, c = 0, cur = 0, shifts = 0;
+    int ct = 12, n = -1;
+    for (int i = 0; i < NCTX; i++) cx.st(i, i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u)));
+    auto byteout = [&]() {
+        // C.2.7 without branches: a carry goes into the byte being held unless that byte is 0xFF; a byte that is
+        // (or becomes) 0xFF is followed by a 7-bit byte
+        const uint32_t carry = cur != 0xFFu ? (c >> 27) & 1u : 0u;
+        cur += carry;
+        c &= ~(carry << 27);
+        const bool stuff = cur == 0xFFu;
+        sink.put(n, cur);
+        n++;
+        const int sh = stuff ? 20 : 19;
+        cur = (c >> sh) & 0xFFu;
+        c &= (1u << sh) - 1u;
+        ct = stuff ? 7 : 8;
+    };
     int p = 0, s = -1;
+    uint32_t v = nsym ? sym.get(0) : 0u;
+    uint32_t st = cx.ld((int) (v & 31u));
     for (uint32_t pos = 0; pos < nsym; pos++) {
-        const uint32_t v = sym.get(pos);
+        const uint32_t vn = pos + 1 < nsym ? sym.get(pos + 1) : 0u;
         if (v & kSymStripe) {
             if (v & kSymPass) {
-                if (s >= 0) { rates[p] = (int) ((uint32_t) mq.numbytes() + 3u); p++; }
+                if (s >= 0) { rates[p] = (int) ((uint32_t) n + 3u); p++; }
                 s = 0;
             } else {
                 s++;
             }
-            ck.store(p, s, mq.a, mq.c & 0xFFFFu, mq.shifts, mq.cx.w0, mq.cx.w1, mq.cx.w2);
+            uint32_t x[5];
+            cx.words(x);
+            ck.store(p, s, a, c & 0xFFFFu, shifts, x);
         } else {
-            mq.encode((int) (v & 31u), (int) (v >> 5));
+            const uint32_t e = tab((int) (st & 0x3Fu)), qe = e & 0xFFFFu;
+            const uint32_t mps = st >> 6, lps = (v >> 5) ^ mps;
+            a -= qe;
+            const bool renorm = lps || (a & 0x8000u) == 0;
+            const bool lower = (a < qe) != (lps != 0);                    // which sub-interval the symbol is coded in
+            if (lower) a = qe; else c += qe;
+            if (renorm) {
+                const uint32_t nidx = lps ? (e >> 22) & 0x3Fu : (e >> 16) & 0x3Fu;
+                cx.st((int) (v & 31u), nidx | ((mps ^ (lps & (e >> 28))) << 6));
+            }
+            int k = renorm_shifts(a);                                     // 0 when bit 15 is set
+            shifts += (uint32_t) k;
+            while (k >= ct) { a <<= ct; c <<= ct; k -= ct; byteout(); }
+            a <<= k; c <<= k; ct -= k;
         }
+        v = vn;
+        st = cx.ld((int) (v & 31u));
     }
-    mq.flush();
-    rates[p] = mq.numbytes();
-    int last = mq.numbytes();
+    {                                                                     // FLUSH (C.2.9)
+        const uint32_t tempc = c + a;
+        c |= 0xFFFFu;
+        if (c >= tempc) c -= 0x8000u;
+        c <<= ct; byteout();
+        c <<= ct; byteout();
+        sink.put(n, cur);
+        if (cur != 0xFFu) n++;
+    }
+    rates[p] = n;
+    int last = n;
     for (int q = npasses; q > 0;) {
         --q;
         if (rates[q] > last) rates[q] = last; else last = rates[q];
@@ -811,7 +871,7 @@ T1_HD EncodeResult mq_encode_stream(SymSrc sym, uint32_t nsym, int npasses, Sink
         if (rates[q] > 0 && bytes(rates[q] - 1) == 0xFF) rates[q]--;
     EncodeResult r;
     r.totalpasses = npasses;
-    r.length = mq.numbytes();
+    r.length = n;
     return r;
 }
 

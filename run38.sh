@@ -1,0 +1,6 @@
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+EBCC_T1_TWO_PHASE=1 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+S='import json,sys; d=json.loads(sys.stdin.read()); k=d["kernels"]; print(d["ms_per_step"], d["value"], d["encode_GBps"], d["decode_GBps"], {n:(k[n]["ms_avg"],k[n]["launches"]) for n in k})'
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$S"
+EBCC_T1_TWO_PHASE=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$S"
+EBCC_T1_TWO_PHASE=1 EBCC_T1_LPW=32,32,16,8 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$S"

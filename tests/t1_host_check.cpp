@@ -41,6 +41,7 @@ struct HostStore {
     }
 };
 struct VecSink { std::vector<uint8_t> *v; void put(int i, uint8_t b) { if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = b; } };
+struct VecSink2 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } };
 struct VecAt { std::vector<uint8_t> *v; uint8_t operator()(int i) const { return i < (int) v->size() ? (*v)[i] : 0; } };
 struct Obs {                      // decoder registers at the start of every (pass, stripe)
     MqCheckpoint ck[120 * 16];
@@ -65,12 +66,18 @@ struct EmitObs {                  // phase 1 observer (the stripe markers go int
     template <class Em> void pass_start(int, const Em &) {}
     template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
 };
+struct CtxBytes { uint8_t *b; uint32_t ld(int c) const { return b[c]; } void st(int c, uint32_t v) { b[c] = (uint8_t) v; }
+                  void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= (uint32_t) b[i] << (8 * (i & 3)); } };
 struct CkView {                   // CkArray over a plain [pass * nstr + stripe] array
     MqCheckpoint *ck; int nstr;
     uint32_t shifts(int p, int s) const { return (uint32_t) ck[p * nstr + s].pos; }
     uint32_t c16(int p, int s) const { return ck[p * nstr + s].c; }
     void finish(int p, int s, uint32_t c, int ct, int pos) { MqCheckpoint &k = ck[p * nstr + s]; k.c = c; k.ct = ct; k.pos = pos; }
-    void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, u64 w0, u64 w1, u64 w2) { ck[p * nstr + s] = MqCheckpoint{a, c16, 0, (int) shifts, w0, w1, w2}; }
+    void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, const uint32_t x[5])
+    {
+        const Contexts c = Contexts::from_bytes(x);
+        ck[p * nstr + s] = MqCheckpoint{a, c16, 0, (int) shifts, c.w0, c.w1, c.w2};
+    }
 };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
@@ -136,7 +143,8 @@ int main(int argc, char **argv)
             static MqCheckpoint ck2[120 * 16];
             CkView ckv2{ck2, nstr};
             int rates2[kMaxPasses];
-            EncodeResult r2 = mq_encode_stream(SymGet{&syms}, em.n, np2, VecSink{&bytes2}, VecAt{&bytes2}, rates2, ckv2);
+            uint8_t ctxb[32] = {0};
+            EncodeResult r2 = mq_encode_stream(SymGet{&syms}, CtxBytes{ctxb}, em.n, np2, VecSink2{&bytes2}, VecAt{&bytes2}, rates2, ckv2);
             finalize_checkpoints(ckv2, np2, nstr, BufSrc{bytes2.data(), r2.length});
             bool same = np2 == r.totalpasses && r2.length == r.length && memcmp(bytes2.data(), bytes.data(), (size_t) r.length) == 0 &&
                         memcmp(st2.sps, st.sps, sizeof st.sps) == 0;

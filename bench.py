@@ -173,8 +173,7 @@ def main():
 
     # parity guard on the timed data: the error bound holds on every frame (size-independent property)
     max_err = float((out - frames).abs().amax())
-    if not os.environ.get("EBCC_DEBUG_RESUME_RES"):        # (diagnostic runs that deliberately skip work)
-        assert max_err <= MAX_ERR * 1.01 + 1e-3, max_err
+    assert max_err <= MAX_ERR * 1.01 + 1e-3, max_err
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -185,7 +184,8 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         total_frames = n * world
         value = total_frames * FRAME_BYTES / (elapsed / args.steps) / 1e9
-        # dominant kernel: tier-1 coding of every code-block (HIP events recorded on the engine's stream)
+        # dominant kernel by total time: tier-1 coding of every code-block (HIP events recorded on the launching
+        # stream of each slice engine around both of its phases)
         tms, launches = ctypes.c_double(), ctypes.c_long()
         lib.ebcc_hip_timing_read(ctx, b"t1_encode", ctypes.byref(tms), ctypes.byref(launches))
         kern = {}
@@ -201,7 +201,7 @@ def main():
             # each with its own launch)
             algo = (n * FRAME_BYTES + comp) * args.steps / launches.value
             ach = algo / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "k_t1_encode", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "tier-1 encoder (k_t1_symbols + k_t1_mq)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4),
                     "algorithmic_bytes_per_launch": algo}
         line = {

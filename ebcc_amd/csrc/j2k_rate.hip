@@ -769,16 +769,11 @@ struct DecSrc {
     }
 };
 
-// PROBE = true: decode the first npass[gid] passes straight from the encoder's code-block slots (the rate
-// search needs exactly what OpenJPEG would decode from the truncated segment - including the rare
-// cases where the "+3 bytes" truncation heuristic makes the decoder mis-read the tail of the last pass,
-// so the result cannot be derived from the encoder's coefficients alone).
-// PROBE = false: decode the segments located by the host-side packet parser (dec_table).
-template <bool PROBE>
+// Decodes the segments located by the host-side packet parser (dec_table): offset, length, numbps, passes.
+// (Rate probes do not come through here: they restart from checkpoints, k_t1_resume below.)
 __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const uint8_t *bytes, size_t stream_cap,
-                                                   const int *dec_table, const int *numbps, const int *npass,
-                                                   const int *rates, int32_t *V, const J2kGeom *geom,
-                                                   const J2kBlock *blocks, const FrameState *fs, const int *active, int total, int lpw)
+                                                   const int *dec_table, int32_t *V, const J2kGeom *geom,
+                                                   const J2kBlock *blocks, const FrameState *fs, int total, int lpw)
 {
     EBCC_LDS_MQ_TABLE(tab);
     if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
@@ -787,18 +782,10 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
     if (gid >= total) return;
     const int nb = geom->nblocks;
     const int frame = gid / nb, bi = gid - frame * nb;
-    if ((active && !active[frame]) || fs[frame].const_field) return;
-    int len, P, np;
-    const uint8_t *src;
-    if (PROBE) {
-        np = npass[gid]; P = numbps[gid];
-        len = np > 0 ? rates[(size_t) gid * kJ2kMaxPasses + np - 1] : 0;
-        src = bytes + (size_t) gid * kJ2kCblkBytes;
-    } else {
-        const int *e = dec_table + (size_t) gid * 4;
-        len = e[1]; P = e[2]; np = e[3];
-        src = bytes + (size_t) frame * stream_cap + e[0];
-    }
+    if (fs[frame].const_field) return;
+    const int *e = dec_table + (size_t) gid * 4;
+    const int len = e[1], P = e[2], np = e[3];
+    const uint8_t *src = bytes + (size_t) frame * stream_cap + e[0];
     if (np <= 0 || P <= 0) return;
     const J2kBlock blk = blocks[bi];
     const size_t grp = (size_t) (gid0 >> 6);
@@ -1030,9 +1017,8 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
     timing_begin("t1_decode", s);
     const int lpw = t1_lanes_per_wave(T1_DECODE);
-    hipLaunchKernelGGL(k_t1_decode<false>, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
-                       jb.dec_table, jb.numbps, jb.npass, jb.rates, jb.V, jb.d_geom, jb.d_blocks, jb.fs, (const int *) nullptr,
-                       total, lpw);
+    hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
+                       jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);
 }

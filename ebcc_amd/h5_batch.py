@@ -1,0 +1,159 @@
+"""HDF5 direct-chunk batch path.
+
+HDF5 calls a filter once per chunk (`H5Z_filter_ebcc`, /root/reference/src/h5z_ebcc.c:124-148): one frame per
+call, which leaves a GPU codec launch-latency-bound.  For datasets whose chunks are single frames (1, H, W) the
+chunks can instead be coded as one batch on the device and handed to HDF5 already filtered
+(`H5Dwrite_chunk` / `H5Dread_chunk`, h5py's `write_direct_chunk` / `read_direct_chunk`).  The file is an ordinary
+EBCC-filtered dataset: the bytes of every chunk are exactly what the filter callback would have produced, so
+any HDF5 reader with the plugin on `HDF5_PLUGIN_PATH` (this build or the reference's) reads it, and files
+written through the callback are read here.
+
+Only numpy and ctypes are needed (h5py objects are passed in by the caller).
+"""
+import ctypes
+
+import numpy as np
+
+from . import load
+from .filter_wrapper import EBCC_Filter, _MODES
+
+
+class CodecConfig(ctypes.Structure):
+    """codec_config_t, include/ebcc_codec.h (reference src/ebcc_codec.h:32-39)."""
+    _fields_ = [("dims", ctypes.c_size_t * 3), ("base_cr", ctypes.c_float), ("residual_compression_type", ctypes.c_int),
+                ("residual_cr", ctypes.c_float), ("error", ctypes.c_float), ("chunk_dims", ctypes.c_size_t * 3)]
+
+
+def frame_config(height, width, base_cr, residual_opt=("none", None)):
+    mode, value = residual_opt if residual_opt is not None else ("none", None)
+    c = CodecConfig()
+    c.dims[:] = (1, height, width)
+    c.base_cr = base_cr
+    c.residual_compression_type = _MODES[mode]
+    c.residual_cr = 0.0
+    c.error = float(value) if _MODES[mode] else 0.0
+    c.chunk_dims[:] = (0, 0, 0)
+    return c
+
+
+class BatchCodec:
+    """Device engine for stacks of (H, W) float32 frames held in host memory."""
+
+    def __init__(self, height, width, max_frames=256, device=0):
+        lib = self.lib = load()
+        lib.ebcc_hip_create.restype = ctypes.c_void_p
+        lib.ebcc_hip_create.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
+        lib.ebcc_hip_destroy.argtypes = [ctypes.c_void_p]
+        lib.ebcc_hip_malloc.restype = ctypes.c_void_p
+        lib.ebcc_hip_malloc.argtypes = [ctypes.c_size_t]
+        lib.ebcc_hip_free.argtypes = [ctypes.c_void_p]
+        lib.ebcc_hip_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ebcc_hip_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ebcc_hip_encode_frames.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CodecConfig),
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        lib.ebcc_hip_decode_frames.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                               ctypes.c_size_t, ctypes.c_void_p]
+        lib.ebcc_hip_last_error.restype = ctypes.c_char_p
+        lib.free_buffer.argtypes = [ctypes.c_void_p]
+        self.h, self.w, self.max_frames = int(height), int(width), int(max_frames)
+        self.ctx = lib.ebcc_hip_create(device, self.max_frames, self.h, self.w)
+        if not self.ctx:
+            raise RuntimeError("EBCC MI355X engine: " + (lib.ebcc_hip_last_error() or b"?").decode())
+        self.d_buf = lib.ebcc_hip_malloc(self.max_frames * self.h * self.w * 4)
+        if not self.d_buf:
+            raise MemoryError("device frame buffer")
+
+    def close(self):
+        if self.ctx:
+            self.lib.ebcc_hip_free(self.d_buf)
+            self.lib.ebcc_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def encode(self, frames, cfg):
+        """frames: (n, H, W) float32, n <= max_frames -> list of EBCC frame streams (bytes)."""
+        frames = np.ascontiguousarray(frames, np.float32)
+        n = frames.shape[0]
+        assert frames.shape[1:] == (self.h, self.w) and 1 <= n <= self.max_frames
+        self.lib.ebcc_hip_memcpy_h2d(self.d_buf, frames.ctypes.data, frames.nbytes)
+        outs = (ctypes.c_void_p * n)()
+        sizes = (ctypes.c_size_t * n)()
+        if self.lib.ebcc_hip_encode_frames(self.ctx, self.d_buf, n, ctypes.byref(cfg), outs, sizes):
+            raise RuntimeError("ebcc_hip_encode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+        res = []
+        for i in range(n):
+            res.append(ctypes.string_at(outs[i], sizes[i]))
+            self.lib.free_buffer(outs[i])
+        return res
+
+    def decode(self, streams):
+        """list of EBCC frame streams -> (n, H, W) float32."""
+        n = len(streams)
+        assert 1 <= n <= self.max_frames
+        bufs = [ctypes.create_string_buffer(bytes(s), len(s)) for s in streams]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(b, ctypes.c_void_p).value for b in bufs])
+        sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
+        if self.lib.ebcc_hip_decode_frames(self.ctx, ptrs, sizes, n, self.d_buf):
+            raise RuntimeError("ebcc_hip_decode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+        out = np.empty((n, self.h, self.w), np.float32)
+        self.lib.ebcc_hip_memcpy_d2h(out.ctypes.data, self.d_buf, out.nbytes)
+        return out
+
+
+def create_dataset(group, name, shape, base_cr, residual_opt=("none", None), **kw):
+    """An EBCC-filtered float32 dataset of shape (..., H, W) with one frame per chunk."""
+    h, w = shape[-2:]
+    chunks = (1,) * (len(shape) - 2) + (h, w)
+    return group.create_dataset(name, shape=shape, dtype="f4", chunks=chunks,
+                                **EBCC_Filter(base_cr=base_cr, height=h, width=w, residual_opt=residual_opt), **kw)
+
+
+def write_frames(dset, data, base_cr, residual_opt=("none", None), batch=256, codec=None):
+    """Code `data` (same shape as `dset`, frames in its last two axes) in device batches and store every frame
+    as a pre-filtered chunk.  `base_cr` / `residual_opt` must be the dataset's filter parameters."""
+    data = np.asarray(data, np.float32)
+    assert tuple(data.shape) == tuple(dset.shape) and dset.chunks == (1,) * (data.ndim - 2) + data.shape[-2:]
+    h, w = data.shape[-2:]
+    flat = data.reshape((-1, h, w))
+    lead = data.shape[:-2]
+    cfg = frame_config(h, w, base_cr, residual_opt)
+    own = codec is None
+    codec = codec or BatchCodec(h, w, min(batch, len(flat)))
+    try:
+        for lo in range(0, len(flat), codec.max_frames):
+            streams = codec.encode(flat[lo:lo + codec.max_frames], cfg)
+            for i, s in enumerate(streams):
+                idx = np.unravel_index(lo + i, lead) if lead else ()
+                dset.id.write_direct_chunk(tuple(int(v) for v in idx) + (0, 0), s, filter_mask=0)
+    finally:
+        if own:
+            codec.close()
+
+
+def read_frames(dset, batch=256, codec=None):
+    """Read an EBCC-filtered one-frame-per-chunk dataset by decoding its raw chunks in device batches."""
+    h, w = dset.shape[-2:]
+    lead = dset.shape[:-2]
+    n = int(np.prod(lead)) if lead else 1
+    out = np.empty((n, h, w), np.float32)
+    own = codec is None
+    codec = codec or BatchCodec(h, w, min(batch, n))
+    try:
+        for lo in range(0, n, codec.max_frames):
+            raw = []
+            for i in range(lo, min(n, lo + codec.max_frames)):
+                idx = np.unravel_index(i, lead) if lead else ()
+                mask, chunk = dset.id.read_direct_chunk(tuple(int(v) for v in idx) + (0, 0))
+                if mask:
+                    raise ValueError(f"chunk {idx} was stored with filters disabled (mask {mask})")
+                raw.append(chunk)
+            out[lo:lo + len(raw)] = codec.decode(raw)
+    finally:
+        if own:
+            codec.close()
+    return out.reshape(dset.shape)

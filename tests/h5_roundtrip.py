@@ -1,0 +1,44 @@
+"""Run under an interpreter that has h5py (here /opt/conda/bin/python3.9) with HDF5_PLUGIN_PATH=<repo>/ebcc_amd:
+the real HDF5 filter pipeline (filter id 308 loaded from this build) and the direct-chunk batch path against each
+other.  Prints 'OK' lines; tests/test_hdf5_gpu.py drives it."""
+import os
+import sys
+
+import h5py
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ebcc_amd import EBCC_Filter, h5_batch  # noqa: E402
+
+out = sys.argv[1]
+H, W, N = 96, 160, 6
+rng = np.random.default_rng(5)
+y, x = np.mgrid[0:H, 0:W]
+data = np.stack([(280 + 10 * np.sin(x / (9.0 + k)) * np.cos(y / (7.0 + k)) + rng.normal(0, 0.4, (H, W))).astype(np.float32)
+                 for k in range(N)])
+data[3] = 1.5                                                    # constant field
+opt = ("max_error", 0.1)
+
+# (1) through the HDF5 filter callback, one chunk per call
+with h5py.File(os.path.join(out, "cb.h5"), "w") as f:
+    f.create_dataset("t", data=data, chunks=(1, H, W), **EBCC_Filter(base_cr=20, height=H, width=W, residual_opt=opt))
+with h5py.File(os.path.join(out, "cb.h5"), "r") as f:
+    back = f["t"][...]
+    raw_cb = [f["t"].id.read_direct_chunk((k, 0, 0))[1] for k in range(N)]
+assert np.abs(back - data).max() <= 0.1 * 1.01 + 1e-4, np.abs(back - data).max()
+print("OK callback round trip, max error", float(np.abs(back - data).max()))
+
+# (2) direct-chunk batch path: same bytes, readable through the callback and in batch
+with h5py.File(os.path.join(out, "dc.h5"), "w") as f:
+    d = h5_batch.create_dataset(f, "t", data.shape, 20, opt)
+    h5_batch.write_frames(d, data, 20, opt)
+with h5py.File(os.path.join(out, "dc.h5"), "r") as f:
+    raw_dc = [f["t"].id.read_direct_chunk((k, 0, 0))[1] for k in range(N)]
+    via_callback = f["t"][...]
+    via_batch = h5_batch.read_frames(f["t"])
+assert raw_dc == raw_cb, [len(a) - len(b) for a, b in zip(raw_dc, raw_cb)]
+print("OK direct-chunk bytes == callback bytes", sum(len(r) for r in raw_dc))
+assert np.array_equal(via_callback, back) and np.array_equal(via_batch, back)
+print("OK batch read == callback read")
+np.save(os.path.join(out, "chunks.npy"), np.array([np.frombuffer(r, np.uint8) for r in raw_cb], dtype=object), allow_pickle=True)
+np.save(os.path.join(out, "data.npy"), data)

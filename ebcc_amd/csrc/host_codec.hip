@@ -694,6 +694,56 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     return 0;
 }
 
+// One frame stream, either format: the 48-byte "EBCC" header (:190-202, :1234-1260) or the legacy header-less
+// prefix `f32 min, f32 max, u64 coeffs_size, f32 rmin, f32 rmax, u64 compressed_size` (ebcc_decode_legacy,
+// :1147-1213), where a constant field is signalled by min == max.
+struct ParsedFrame {
+    float minv = 0, maxv = 0, rmin = 0, rmax = 0;
+    bool const_field = false;
+    size_t coeffs_size = 0, compressed_size = 0, tail_size = 0;
+    const uint8_t *z = nullptr, *tail = nullptr;
+};
+
+bool parse_frame(const uint8_t *d, size_t len, ParsedFrame &pf)
+{
+    if (len >= sizeof(FrameHeader) && memcmp(d, EBCC_HEADER_MAGIC, 4) == 0) {
+        FrameHeader hd;
+        memcpy(&hd, d, sizeof hd);
+        if (hd.version != EBCC_HEADER_VERSION) { log_fatal("Unsupported EBCC header version: %u", hd.version); return false; }
+        size_t used = sizeof hd;
+        if (hd.compressed_size > len - used) { log_fatal("Invalid encoded data: truncated payload"); return false; }   // :1249
+        used += hd.compressed_size;
+        if (hd.tail_size > len - used) { log_fatal("Invalid encoded data: truncated payload"); return false; }         // :1254
+        used += hd.tail_size;
+        if (used != len) { log_fatal("Invalid encoded data: payload size mismatch"); return false; }                  // :1314
+        pf.minv = u2f(hd.minval_bits); pf.maxv = u2f(hd.maxval_bits);
+        pf.rmin = u2f(hd.rmin_bits); pf.rmax = u2f(hd.rmax_bits);
+        pf.const_field = (hd.flags & EBCC_HEADER_FLAG_CONST_FIELD) != 0;
+        pf.coeffs_size = hd.coeffs_size; pf.compressed_size = hd.compressed_size; pf.tail_size = hd.tail_size;
+        pf.z = d + sizeof hd; pf.tail = pf.z + hd.compressed_size;
+        if (pf.const_field && hd.tail_size != sizeof(uint64_t)) {
+            log_fatal("Invalid encoded data: const-field payload must contain uint64_t length");
+            return false;
+        }
+    } else {
+        const size_t prefix = 4 + 4 + 8 + 4 + 4 + 8;
+        if (len < prefix) { log_fatal("Invalid legacy encoded data: truncated header"); return false; }
+        uint64_t cs, zs;
+        memcpy(&pf.minv, d, 4); memcpy(&pf.maxv, d + 4, 4); memcpy(&cs, d + 8, 8);
+        memcpy(&pf.rmin, d + 16, 4); memcpy(&pf.rmax, d + 20, 4); memcpy(&zs, d + 24, 8);
+        if (zs > len - prefix) { log_fatal("Invalid legacy encoded data: truncated residual payload"); return false; }
+        pf.coeffs_size = cs; pf.compressed_size = zs;
+        pf.z = d + prefix; pf.tail = pf.z + zs; pf.tail_size = len - prefix - zs;
+        pf.const_field = pf.minv == pf.maxv;
+        if (pf.const_field && pf.tail_size < sizeof(uint64_t)) { log_fatal("Invalid legacy encoded data: missing const-field length"); return false; }
+    }
+    if (pf.const_field && pf.compressed_size > 0 && pf.coeffs_size > 0) {
+        log_fatal("Invalid encoded data: residual data cannot be applied to const field");
+        return false;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ebcc_decode for a batch of single-frame EBCC streams -> device buffer d_out [n][H*W]
 // ------------------------------------------------------------------------------------------------
@@ -713,30 +763,17 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         const uint8_t *d = streams[f];
         const size_t len = sizes[f];
         ctx->h_active[f] = 0;
-        if (len < sizeof(FrameHeader) || memcmp(d, EBCC_HEADER_MAGIC, 4) != 0) {
-            log_fatal("legacy header-less EBCC streams are not supported by the MI355X build");
-            return 1;
-        }
-        FrameHeader hd;
-        memcpy(&hd, d, sizeof hd);
-        if (hd.version != EBCC_HEADER_VERSION) { log_fatal("Unsupported EBCC header version: %u", hd.version); return 1; }
-        size_t used = sizeof hd;
-        if (hd.compressed_size > len - used) { log_fatal("Invalid encoded data: truncated payload"); return 1; }   // :1249
-        used += hd.compressed_size;
-        if (hd.tail_size > len - used) { log_fatal("Invalid encoded data: truncated payload"); return 1; }         // :1254
-        used += hd.tail_size;
-        if (used != len) { log_fatal("Invalid encoded data: payload size mismatch"); return 1; }                  // :1314
+        ParsedFrame hd;
+        if (!parse_frame(d, len, hd)) return 1;
         FrameState &fs = ctx->h_fs[f];
-        fs.minv = u2f(hd.minval_bits); fs.maxv = u2f(hd.maxval_bits);
-        fs.rmin = u2f(hd.rmin_bits); fs.rmax = u2f(hd.rmax_bits);
-        fs.const_field = (hd.flags & EBCC_HEADER_FLAG_CONST_FIELD) ? 1 : 0;
-        const uint8_t *z = d + sizeof hd, *tail = z + hd.compressed_size;
+        fs.minv = hd.minv; fs.maxv = hd.maxv;
+        fs.rmin = hd.rmin; fs.rmax = hd.rmax;
+        fs.const_field = hd.const_field ? 1 : 0;
+        const uint8_t *z = hd.z, *tail = hd.tail;
         if (fs.const_field) {
             uint64_t cnt = 0;
-            if (hd.tail_size != sizeof(uint64_t)) { log_fatal("Invalid encoded data: const-field payload must contain uint64_t length"); return 1; }
             memcpy(&cnt, tail, 8);
             if (cnt != n_pix) { log_fatal("const-field length %llu does not match the frame", (unsigned long long) cnt); return 1; }
-            if (hd.compressed_size > 0 && hd.coeffs_size > 0) { log_fatal("Invalid encoded data: residual data cannot be applied to const field"); return 1; }
         } else {
             if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return 1; }
             if (!j2k_parse_codestream(tail, hd.tail_size, g, table.data() + f * g.nblocks * 4)) return 1;
@@ -962,27 +999,15 @@ static int peek_j2k_dims(const uint8_t *d, size_t n, int *H, int *W)
 
 size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
 {
-    if (data_size < sizeof(FrameHeader) || memcmp(data, EBCC_HEADER_MAGIC, 4) != 0) {
-        log_fatal("legacy header-less EBCC streams are not supported by the MI355X build");
-        return 0;
-    }
-    FrameHeader hd;
-    memcpy(&hd, data, sizeof hd);
-    if (hd.version != EBCC_HEADER_VERSION) { log_fatal("Unsupported EBCC header version: %u", hd.version); return 0; }
-    if (hd.compressed_size > data_size - sizeof hd || hd.tail_size > data_size - sizeof hd - hd.compressed_size) {
-        log_fatal("Invalid encoded data: truncated payload");
-        return 0;
-    }
-    const uint8_t *tail = data + sizeof hd + hd.compressed_size;
-    if (hd.flags & EBCC_HEADER_FLAG_CONST_FIELD) {                                             // :1265-1281, no device work
-        if (hd.tail_size != sizeof(uint64_t)) { log_fatal("Invalid encoded data: const-field payload must contain uint64_t length"); return 0; }
+    ParsedFrame hd;                                                                             // both stream formats
+    if (!parse_frame(data, data_size, hd)) return 0;
+    const uint8_t *tail = hd.tail;
+    if (hd.const_field) {                                                                      // :1265-1281 / :1175-1183, no device work
         uint64_t cnt;
         memcpy(&cnt, tail, 8);
-        if (hd.compressed_size > 0 && hd.coeffs_size > 0) { log_fatal("Invalid encoded data: residual data cannot be applied to const field"); return 0; }
-        if (sizeof hd + hd.compressed_size + hd.tail_size != data_size) { log_fatal("Invalid encoded data: payload size mismatch"); return 0; }
         float *o = (float *) malloc(cnt * sizeof(float));
-        float v = u2f(hd.minval_bits);
-        for (uint64_t i = 0; i < cnt; i++) o[i] = v;
+        if (!o) { log_fatal("out of memory"); return 0; }
+        for (uint64_t i = 0; i < cnt; i++) o[i] = hd.minv;
         *out_buffer = o;
         return (size_t) cnt;
     }

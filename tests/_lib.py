@@ -375,6 +375,15 @@ class Context:
         return res
 
 
+def legacy_repack(stream):
+    """The same frame in the reference's legacy header-less layout (src/ebcc_codec.c:1147-1213):
+    f32 min, f32 max, u64 coeffs_size, f32 rmin, f32 rmax, u64 compressed_size, zstd payload, tail."""
+    import struct
+    magic, ver, flags, _r, mn, mx, coeffs, rmn, rmx, zsize, tsize = struct.unpack("<4sBBHIIQIIQQ", stream[:48])
+    assert magic == b"EBCC" and ver == 1 and len(stream) == 48 + zsize + tsize
+    return struct.pack("<IIQIIQ", mn, mx, coeffs, rmn, rmx, zsize) + stream[48:]
+
+
 # ------------------------------------------------------------------------------------------ inputs
 def scale_u16(field):
     """ebcc_codec.c:686-689 in float32 arithmetic."""

@@ -131,6 +131,14 @@ def test_sliced_batches_equal_single_engine(monkeypatch):
         assert np.array_equal(res[k][1], res["1"][1]), k
 
 
+@pytest.mark.parametrize("name", [n for n in sorted(_streams)][::9], ids=str)
+def test_legacy_headerless_streams_decode(name):
+    """ebcc_decode_legacy (reference :1147-1213): the same payload behind the old header-less prefix."""
+    want = bytes.fromhex(_streams[name]["stream_hex"])
+    dec = api_decode(L.legacy_repack(want))
+    assert sha(dec.tobytes()) == _streams[name]["decoded_sha256"]
+
+
 def test_constant_and_zero_fields():
     for v in (3.25, 0.0):
         data = np.full((64, 64), v, np.float32)
@@ -138,6 +146,7 @@ def test_constant_and_zero_fields():
         s = api_encode(data, cfg)
         assert len(s) == 56 and s[5] == 1                      # const-field flag, 8-byte count tail
         assert np.array_equal(api_decode(s), data.ravel())
+        assert np.array_equal(api_decode(L.legacy_repack(s)), data.ravel())      # legacy: min == max marks the constant field
 
 
 def test_malformed_streams_are_rejected():

@@ -132,3 +132,28 @@ def test_j2k_nmsedec_tables_match_openjpeg_binary_dump():
     assert sig0[-6:] == [29824, 30208, 30720, 31232, 31744, 32256]
     assert ref[:4] == [6144, 6016, 5888, 5760] and ref[-6:] == [5376, 5504, 5632, 5760, 5888, 6016]
     assert ref0[:4] == [8192, 7936, 7680, 7424] and ref0[-6:] == [6784, 6912, 7168, 7424, 7680, 7936]
+
+
+def test_legacy_repack_is_what_the_reference_decodes():
+    """tests/_lib.legacy_repack (used by the GPU legacy-stream test) against the oracle's ebcc_decode_legacy
+    restatement and, in the dev container, the reference build itself."""
+    import hashlib
+    import json
+    streams = json.load(open(os.path.join(L.GOLDEN, "codec_streams.json")))
+    names = sorted(streams)[::9]
+    ref = None
+    if os.path.exists(L.REF_SO):
+        ref = ctypes.CDLL(L.REF_SO)
+        ref.ebcc_decode.restype = ctypes.c_size_t
+        ref.ebcc_decode.argtypes = [ctypes.c_void_p, ctypes.c_size_t, L.c_void_pp]
+    for name in names:
+        s = bytes.fromhex(streams[name]["stream_hex"])
+        leg = L.legacy_repack(s)
+        dec = L.orc_decode(leg)
+        assert hashlib.sha256(np.asarray(dec, np.float32).tobytes()).hexdigest() == streams[name]["decoded_sha256"], name
+        if ref is not None:
+            b = ctypes.create_string_buffer(leg, len(leg))
+            out = ctypes.c_void_p()
+            n = ref.ebcc_decode(b, len(leg), ctypes.byref(out))
+            got = np.frombuffer(ctypes.string_at(out.value, 4 * n), np.float32)
+            assert hashlib.sha256(got.tobytes()).hexdigest() == streams[name]["decoded_sha256"], name

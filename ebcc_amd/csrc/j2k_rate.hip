@@ -228,43 +228,63 @@ __device__ void trees_reset(const J2kGeom &g, RateLds &L, int lane)
 // LDS when all code-blocks of the frame fit (12 bytes per coding pass); otherwise they are read from global
 // memory as they are.
 struct PassTab {
-    const int *rates;              // [nblocks][kJ2kMaxPasses] of this frame
+    const int *rates;              // [nblocks][kJ2kMaxPasses] of this frame (global memory)
     const double *disto;
-    const double *l_disto;         // LDS copies, code-block b at l_off[b] .. + totalpasses
-    const int *l_rate;
-    const int *l_off;
+    const __attribute__((address_space(3))) double *l_disto;   // LDS copies, code-block b at l_off[b] .. + totalpasses
+    const __attribute__((address_space(3))) int *l_rate;
+    const __attribute__((address_space(3))) int *l_off;
     bool lds;
-    __device__ int rate(int b, int p) const { return lds ? l_rate[l_off[b] + p] : rates[(size_t) b * kJ2kMaxPasses + p]; }
-    __device__ double dist(int b, int p) const { return lds ? l_disto[l_off[b] + p] : disto[(size_t) b * kJ2kMaxPasses + p]; }
+    // (kept in their own address spaces: a pointer that may be either would turn every access into a flat load)
+    template <bool LDS> __device__ int rate(int base, int p) const { if constexpr (LDS) return l_rate[base + p]; else return rates[base + p]; }
+    template <bool LDS> __device__ double dist(int base, int p) const { if constexpr (LDS) return l_disto[base + p]; else return disto[base + p]; }
+    template <bool LDS> __device__ int base_of(int b) const { if constexpr (LDS) return l_off[b]; else return b * kJ2kMaxPasses; }
 };
 
 // opj_tcd_makelayer for one quality layer
-template <int NT>
-__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane)
+template <int NT, bool LDS>
+__device__ void make_layer_impl(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane)
 {
     for (int b = lane; b < g.nblocks; b += NT) {
-        const int tp = totalpasses[gid0 + b];
+        int tp;
+        if constexpr (LDS) tp = pt.l_off[b + 1] - pt.l_off[b]; else tp = totalpasses[gid0 + b];
+        const int base = pt.base_of<LDS>(b);
         int n = 0;
         if (thresh < 0) n = tp;
         else {
             int rbase = 0;                                           // rate / distortion of the last pass taken
             double dbase = 0;
             for (int p = 0; p < tp; p++) {
-                const int rp = pt.rate(b, p);
-                const double dp = pt.dist(b, p);
+                const int rp = pt.rate<LDS>(base, p);
+                const double dp = pt.dist<LDS>(base, p);
                 unsigned int dr;
                 double dd;
                 if (n == 0) { dr = (unsigned int) rp; dd = dp; }
                 else { dr = (unsigned int) (rp - rbase); dd = dp - dbase; }
+                // OpenJPEG's test is  thresh - fl(dd / dr) < DBL_EPSILON.  The outcome is already certain whenever dd
+                // and thresh * dr differ by more than rounding can bridge (1e-11 relative, against 2^-52 per
+                // operation); only the narrow band in between is divided.  (The reject shortcut also needs
+                // DBL_EPSILON to be negligible next to thresh.)
                 bool take;
                 if (!dr) take = dd != 0;
-                else take = thresh - (dd / dr) < DBL_EPSILON;
+                else {
+                    const double tdr = thresh * (double) dr;
+                    if (dd >= tdr * 1.00000000001) take = true;
+                    else if (thresh >= 1e-4 && dd <= tdr * 0.99999999999) take = false;
+                    else take = thresh - (dd / dr) < DBL_EPSILON;
+                }
                 if (take) { n = p + 1; rbase = rp; dbase = dp; }
             }
         }
         L.npass[b] = (short) n;
     }
     __syncthreads();
+}
+
+template <int NT>
+__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane)
+{
+    if (pt.lds) make_layer_impl<NT, true>(g, L, totalpasses, pt, gid0, thresh, lane);
+    else make_layer_impl<NT, false>(g, L, totalpasses, pt, gid0, thresh, lane);
 }
 
 // total packet bytes of the current assignment (one lane per resolution)
@@ -453,6 +473,9 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
 {
     extern __shared__ unsigned char lds_raw[];
     __shared__ int s_sum, s_changed;
+#ifdef EBCC_RATE_PROFILE
+    const long long t_start = wall_clock64();                        // 100 MHz
+#endif
     __shared__ double s_min[kRateThreads / 64], s_max[kRateThreads / 64];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
@@ -466,18 +489,22 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     __shared__ int s_fit;
     unsigned char *extra = lds_raw + ((rate_lds_bytes(g.nblocks, g.tree_nodes) + 15) & ~(size_t) 15);
     int *l_off = (int *) extra;
-    double *l_disto = (double *) (extra + (((size_t) g.nblocks * 4 + 15) & ~(size_t) 15));
+    double *l_disto = (double *) (extra + (((size_t) (g.nblocks + 1) * 4 + 15) & ~(size_t) 15));
     for (int b = lane; b < g.nblocks; b += kRateThreads) l_off[b] = totalpasses[gid0 + b];
     __syncthreads();
     if (lane == 0) {
         int acc = 0;
         for (int b = 0; b < g.nblocks; b++) { const int tp = l_off[b]; l_off[b] = acc; acc += tp; }
+        l_off[g.nblocks] = acc;
         s_fit = acc <= pass_capacity ? acc : -1;
     }
     __syncthreads();
     const int n_entries = s_fit;
     int *l_rate = (int *) (l_disto + (n_entries > 0 ? n_entries : 0));
-    PassTab pt{rates + (size_t) gid0 * kJ2kMaxPasses, disto + (size_t) gid0 * kJ2kMaxPasses, l_disto, l_rate, l_off, n_entries >= 0};
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) int lds_int;
+    PassTab pt{rates + (size_t) gid0 * kJ2kMaxPasses, disto + (size_t) gid0 * kJ2kMaxPasses, (const lds_double *) l_disto,
+               (const lds_int *) l_rate, (const lds_int *) l_off, n_entries >= 0};
     if (pt.lds) {
         for (int b = lane; b < g.nblocks; b += kRateThreads) {
             const int tp = totalpasses[gid0 + b], o = l_off[b];
@@ -525,7 +552,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         const int tp = totalpasses[gid0 + b];
         int rprev = 0; double dprev = 0;
         for (int p = 0; p < tp; p++) {
-            const int rp = pt.rate(b, p); const double dp = pt.dist(b, p);
+            const int rp = pt.rates[(size_t) b * kJ2kMaxPasses + p]; const double dp = pt.disto[(size_t) b * kJ2kMaxPasses + p];
             const int dr = rp - rprev; const double dd = dp - dprev;
             rprev = rp; dprev = dp;
             if (dr == 0) continue;
@@ -542,6 +569,14 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     __syncthreads();
     for (int i = 0; i < kRateThreads / 64; i++) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
 
+#ifdef EBCC_RATE_PROFILE
+    long long t_setup = wall_clock64() - t_start, t_ml = 0, t_sz = 0; int n_it = 0, n_real = 0;
+#define RP_T0 const long long rp0 = wall_clock64()
+#define RP_ADD(acc) acc += wall_clock64() - rp0
+#else
+#define RP_T0
+#define RP_ADD(acc)
+#endif
     double good = -1;                                                // rate 0: every pass
     if (rate > 0.0f) {
         const long long maxlen = (long long) ceil((double) rate);
@@ -550,8 +585,12 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             thresh = (lo + hi) / 2;
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
-            make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane);
-            const int bytes = sized();
+            { RP_T0; make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane); RP_ADD(t_ml); }
+            int bytes;
+            { RP_T0; bytes = sized(); RP_ADD(t_sz); }
+#ifdef EBCC_RATE_PROFILE
+            n_it++; n_real += s_changed;
+#endif
             if ((long long) bytes > maxlen) { lo = thresh; continue; }
             hi = thresh;
             stable = thresh;
@@ -565,6 +604,10 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         jf[frame].body_bytes = body;
         jf[frame].stream_bytes = kMainHeaderBytes + 12 + 2 + body + 2;
         jf[frame].maxlen = (int) (rate > 0.0f ? ceil((double) rate) : 0);
+#ifdef EBCC_RATE_PROFILE
+        if (frame == 0) printf("k_rate frame0: setup %lld us, make_layer %lld us, sized %lld us, iterations %d (real sizings %d), total %lld us\n",
+                               t_setup / 100, t_ml / 100, t_sz / 100, n_it, n_real, (wall_clock64() - t_start) / 100);
+#endif
     }
 }
 
@@ -955,7 +998,7 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
 {
     ScopedTiming t("rate_alloc", s);
     // dynamic LDS: the carve-up, the per-block table offsets, then as many (rate, distortion) entries as fit
-    const size_t head = ((rate_lds(jb.geom) + 15) & ~(size_t) 15) + (((size_t) jb.geom.nblocks * 4 + 15) & ~(size_t) 15);
+    const size_t head = ((rate_lds(jb.geom) + 15) & ~(size_t) 15) + (((size_t) (jb.geom.nblocks + 1) * 4 + 15) & ~(size_t) 15);
     const size_t budget = 150 * 1024;
     size_t want = (size_t) jb.geom.nblocks * kJ2kMaxPasses;
     if (head + want * 12 > budget) want = head < budget ? (budget - head) / 12 : 0;

@@ -139,6 +139,26 @@ def test_legacy_headerless_streams_decode(name):
     assert sha(dec.tobytes()) == _streams[name]["decoded_sha256"]
 
 
+def test_extreme_frame_sizes():
+    """Smallest and most ragged legal frames bit-exact against the oracle; the largest legal frame (2047 x 2047,
+    EBCC_MAX_INTERNAL_IMAGE_DIM) through the size-independent property: decode(encode(x)) within the bound."""
+    L.oracle().orc_set_j2k_backend(0)
+    for h, w, seed in ((32, 32, 1), (33, 2047, 2), (2047, 32, 3), (65, 127, 4)):
+        data = L.era5_like(h, w, seed, 1.2, 1.0)
+        cfg = L.make_config((1, h, w), base_cr=15.0, error=0.05, residual_type=L.MAX_ERROR)
+        s = api_encode(data, cfg)
+        assert s == L.orc_encode(data, cfg), (h, w)
+        assert np.abs(api_decode(s).reshape(h, w) - data).max() <= 0.05 * 1.01 + 1e-4
+    big = L.era5_like(2047, 2047, 11, 1.5, 2.5)
+    for mode, err in ((L.MAX_ERROR, 0.25), (L.RELATIVE_ERROR, 2e-3)):
+        cfg = L.make_config((1, 2047, 2047), base_cr=40.0, error=err, residual_type=mode)
+        s = api_encode(big, cfg)
+        dec = api_decode(s).reshape(2047, 2047)
+        tgt = err if mode == L.MAX_ERROR else err * float(big.max() - big.min())
+        assert np.abs(dec - big).max() <= tgt * 1.01 + 1e-4
+        assert len(s) < big.nbytes / 8
+
+
 def test_constant_and_zero_fields():
     for v in (3.25, 0.0):
         data = np.full((64, 64), v, np.float32)

@@ -792,7 +792,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     // The residual layer (SPIHT decode + synthesis: one wave per frame, latency-bound) does not depend on the
     // base layer until the final addition, so it runs on the engine's second stream beside the tier-1 decode.
     hipStream_t s2 = s;
-    if (any_resid && getenv("EBCC_HIP_CONCURRENT_RESIDUAL_DECODE")) {    // (no gain measured once batches run as slices)
+    if (any_resid && !getenv("EBCC_HIP_SERIAL_DECODE")) {
         s2 = second_stream(ctx);
         if (!ctx->ev_a) {
             EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
@@ -864,14 +864,13 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
 // ================================================================================================
 // C API
 // ================================================================================================
-// Slices of a batch: EBCC_HIP_SLICES (default 2, 1 = off) engines of max_frames / slices frames each, created on
+// Slices of a batch: EBCC_HIP_SLICES (encode, default 2, 1 = off) / EBCC_HIP_DECODE_SLICES (default 1) engines of max_frames / slices frames each, created on
 // first use.  Small batches stay on the context's own engine.  More than two slices only pay when the HIP
 // runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the application's streams):
 // streams that share a queue run one after the other.
-static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames)
+static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames, const char *env_name, size_t k)
 {
-    size_t k = 2;
-    if (const char *e = getenv("EBCC_HIP_SLICES")) k = (size_t) std::max(1L, strtol(e, nullptr, 10));
+    if (const char *e = getenv(env_name)) k = (size_t) std::max(1L, strtol(e, nullptr, 10));
     k = std::min<size_t>(k, 8);
     if (k < 2 || n_frames < 4 * k) return 1;
     const size_t per = (ctx->max_frames + k - 1) / k;
@@ -884,9 +883,9 @@ static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames)
 }
 
 template <class Fn>
-static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn)
+static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env_name, size_t default_slices)
 {
-    const size_t k = slice_engines(ctx, n_frames);
+    const size_t k = slice_engines(ctx, n_frames, env_name, default_slices);
     if (k == 1) return fn(ctx, (size_t) 0, n_frames, (SliceGate *) nullptr);
     const size_t per = (n_frames + k - 1) / k;
     std::vector<int> rc(k, 0);
@@ -949,7 +948,7 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     const size_t n_pix = ctx->n_pix;
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
         return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo, next);
-    });
+    }, "EBCC_HIP_SLICES", 2);
 }
 
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
@@ -962,7 +961,7 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     const size_t n_pix = ctx->n_pix;
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
         return decode_batch(c, streams + lo, sizes + lo, cnt, d_frames_out + lo * n_pix, next);
-    });
+    }, "EBCC_HIP_DECODE_SLICES", 1);      // decode overlaps its two layers on the engine's two streams instead (decode_batch)
 }
 
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)

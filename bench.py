@@ -194,6 +194,18 @@ def main():
             lib.ebcc_hip_timing_read(ctx, name, ctypes.byref(a), ctypes.byref(c))
             if c.value:
                 kern[name.decode()] = {"ms_avg": round(a.value / c.value, 4), "launches": c.value}
+        def pmc_traffic(frames_per_launch):
+            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r01_pmc_*.json,
+            tools/gpu/profile.sh: separate FETCH_SIZE and WRITE_SIZE runs of `--frames 64` = 32 frames per dispatch).
+            gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB."""
+            try:
+                f = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))["kernels"]
+                w = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write_size.json")))["kernels"]
+                per_frame = sum(2.0 * f[k]["per_dispatch"] + w[k]["per_dispatch"] for k in ("k_t1_symbols", "k_t1_mq")) * 1024.0 / 32.0
+                return int(per_frame * frames_per_launch)
+            except Exception:
+                return None
+
         roof = None
         if launches.value:
             avg_s = tms.value / launches.value / 1e3
@@ -202,7 +214,7 @@ def main():
             algo = (n * FRAME_BYTES + comp) * args.steps / launches.value
             ach = algo / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": "tier-1 encoder (k_t1_symbols + k_t1_mq)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(n * args.steps / launches.value), "avg_launch_ms": round(avg_s * 1e3, 4),
                     "algorithmic_bytes_per_launch": algo}
         line = {
             "metric": "fp32 GB/s encode+decode, 721x1440 ERA5 frames MAX_ERROR=0.5",

@@ -36,7 +36,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->SUF = ctx_alloc<unsigned long long>(ctx, groups * (kJ2kMaxPlanes + 2) * 64 * 64)) != nullptr;
     ok &= (jb->SPS = ctx_alloc<unsigned long long>(ctx, groups * 64 * 64)) != nullptr;
     ok &= (jb->VISP = ctx_alloc<unsigned long long>(ctx, groups * kJ2kMaxPlanes * 64 * 64)) != nullptr;
-    ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * j2k_ckpt_group_bytes())) != nullptr;
+    ok &= (jb->ckpt = ctx_alloc<uint8_t>(ctx, groups * 64 * j2k_ckpt_block_bytes())) != nullptr;
     // decision streams of the two-phase tier-1 encoder (default; EBCC_T1_TWO_PHASE=0 selects the single-kernel encoder
     // and saves this buffer)
     jb->SYM = nullptr;

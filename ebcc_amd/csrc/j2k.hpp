@@ -48,21 +48,19 @@ struct J2kGeom {
 constexpr int kJ2kSymCap = 4096 * (kJ2kMaxPlanes + 1) + 2048;  // decision stream of one code-block: at most planes + 1 decisions per sample, plus stripe markers
 constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
 
-// Checkpoint storage: nine 32-bit field arrays per group of 64 code-blocks (a, c, ct, pos, then the 19 context
-// states one byte each in five words), lane-interleaved like the tier-1 state:
-//   group base + (field * kJ2kCkptPerBlock + slot) * 64 * 4 + lane * 4          slot = pass * 16 + stripe
+// Checkpoint storage: one 36-byte record (a, c, ct, pos, then the 19 context states one byte each in five words)
+// per slot, the slots of a code-block contiguous: [code-block][slot = pass * 16 + stripe][9 words].  Writers
+// (the MQ pass, one code-block per lane, every lane at its own slot) and readers (the restart planner's binary
+// search, the restart itself, the finalising sweep) all walk one code-block's records, so a record is one or two
+// memory transactions instead of nine scattered ones.
 constexpr int kJ2kCkptFields = 9;
-__host__ __device__ inline size_t j2k_ckpt_group_bytes() { return (size_t) kJ2kCkptFields * kJ2kCkptPerBlock * 64 * 4; }
+__host__ __device__ inline size_t j2k_ckpt_block_bytes() { return (size_t) kJ2kCkptFields * kJ2kCkptPerBlock * 4; }
 struct J2kCkptView {
-    unsigned char *base;           // group base
-    std::uint32_t lane4;           // lane * 4
-    __host__ __device__ std::uint32_t &at(int field, std::uint32_t slot) const
+    std::uint32_t *rec;            // first record of this code-block
+    __host__ __device__ std::uint32_t &at(int field, std::uint32_t slot) const { return rec[slot * kJ2kCkptFields + (std::uint32_t) field]; }
+    __host__ __device__ static J2kCkptView of(void *all, size_t gid)
     {
-        return *(std::uint32_t *) (base + (((std::uint32_t) field * kJ2kCkptPerBlock + slot) * 256u + lane4));
-    }
-    __host__ __device__ static J2kCkptView of(void *all, size_t group, int lane)
-    {
-        return J2kCkptView{(unsigned char *) all + group * j2k_ckpt_group_bytes(), (std::uint32_t) lane * 4u};
+        return J2kCkptView{(std::uint32_t *) ((unsigned char *) all + gid * j2k_ckpt_block_bytes())};
     }
 };
 
@@ -91,7 +89,7 @@ struct J2kBuffers {
     unsigned long long *SUF;      // [groups][planes+2][64][64] suffix-OR of BP over planes >= p (significance above a plane)
     unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
     unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
-    void *ckpt;                   // [frames*nblocks][passes][16 stripes] MQ-decoder checkpoints at every stripe start of every coding pass
+    void *ckpt;                   // [frames*nblocks][passes * 16 stripes][9 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
     uint8_t *SYM;                 // [frames*nblocks][kJ2kSymCap] decision streams of the two-phase encoder (t1_core.hpp)
     std::uint32_t *nsym;          // [frames*nblocks] bytes in the stream
     int *qplane;                  // [frames*nblocks] coding pass at which the current probe's decode restarts (-1: nothing)

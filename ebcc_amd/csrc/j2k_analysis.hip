@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     DevStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64),
                 (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (SPS + grp * 64 * 64), lane8};
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    CkObserver obs{J2kCkptView{(unsigned char *) ckpt + grp * j2k_ckpt_group_bytes(), lane8 >> 1}, (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
+    CkObserver obs{J2kCkptView::of(ckpt, (size_t) gid), (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
     t1::EncodeResult r = t1::encode_block_observed(st, DevSink{out, kJ2kCblkBytes, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
                                                    blk.w, blk.h, orient, P, rates + (size_t) gid * kJ2kMaxPasses, obs, tab);
     totalpasses[gid] = r.totalpasses;
@@ -690,10 +690,9 @@ __global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t
     const int np = totalpasses[gid];
     if (numbps[gid] <= 0 || np <= 0) return;
     const J2kBlock blk = blocks[bi];
-    const size_t grp = (size_t) (gid0 >> 6);
     const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
     uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    CkObserver ck{J2kCkptView{(unsigned char *) ckpt + grp * j2k_ckpt_group_bytes(), lane8 >> 1}, nullptr, lane8};
+    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, lane8};
     SymSrcDev src{SYM + (size_t) gid * kJ2kSymCap, ring, threadIdx.x};
     src.prefetch(0);
     t1::EncodeResult r = t1::mq_encode_stream(src, CtxLds{(unsigned char *) (ctxw + threadIdx.x)}, nsym[gid], np,

@@ -861,7 +861,7 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
     if (n > 0 && P > 0) {
         const int len = rates[(size_t) gid * kJ2kMaxPasses + n - 1];
         const int nstr = (blocks[gid - frame * geom->nblocks].h + 3) >> 2;
-        const J2kCkptView ck = J2kCkptView::of(ckpt, (size_t) (gid >> 6), gid & 63);
+        const J2kCkptView ck = J2kCkptView::of(ckpt, (size_t) gid);
         // latest checkpoint taken before the decoder touched a byte at/after the truncation point (pos is
         // non-decreasing in coding order); slot 0 is the initial state and always usable
         int lo = 0, hi = n * nstr - 1;
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
         st.REF(y) = R;
         st.VIS(y) = Vv;
     }
-    const J2kCkptView cv = J2kCkptView::of(ckpt, grp, gl);
+    const J2kCkptView cv = J2kCkptView::of(ckpt, (size_t) gid);
     const uint32_t ci = (uint32_t) (r * 16 + stripe);
     uint32_t cxb[5];
     for (int j = 0; j < 5; j++) cxb[j] = cv.at(4 + j, ci);

@@ -626,6 +626,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     totalpasses[gid] = t1::emit_block(st, em, blk.w, blk.h, orient, P, obs);
     em.put.flush(em.n);
     nsym[gid] = em.n;
+#ifdef EBCC_T1_PROFILE
+    if (gid == 64 * 40) printf("k_t1_symbols lane profile: propagation %lld us, refinement %lld us, cleanup %lld us\n",
+                               t1::t1_profile[0] / 100, t1::t1_profile[1] / 100, t1::t1_profile[2] / 100);
+#endif
 }
 
 // ---- phase 2: arithmetic coding of the decision streams, one code-block per lane, every lane the same loop.

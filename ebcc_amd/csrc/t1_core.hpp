@@ -772,6 +772,9 @@ struct MarkingObserver {
     T1_HD void sigprop_done(int bp, Store &st) { in.sigprop_done(bp, st); }
 };
 
+#ifdef EBCC_T1_PROFILE
+__device__ long long t1_profile[4];
+#endif
 // Returns the number of coding passes; the length of the stream is in em.n afterwards.
 template <class Store, class Put, class Observer>
 T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient, int numbps, Observer &inner)
@@ -781,9 +784,15 @@ T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient
     int passno = 0, passtype = 2;
     for (int bp = numbps - 1; bp >= 0; passno++) {
         obs.pass_start(passno, em);
+#ifdef EBCC_T1_PROFILE
+        const long long t0_ = wall_clock64();
+#endif
         if (passtype == 0) { ps.sigprop(bp); obs.sigprop_done(bp, st); }
         else if (passtype == 1) ps.refine(bp);
         else ps.cleanup(bp);
+#ifdef EBCC_T1_PROFILE
+        t1_profile[passtype] += wall_clock64() - t0_;
+#endif
         if (++passtype == 3) { passtype = 0; bp--; }
     }
     return passno;

@@ -159,6 +159,28 @@ def test_extreme_frame_sizes():
         assert len(s) < big.nbytes / 8
 
 
+def test_zarr_codec_class():
+    """ebcc_amd.zarr_filter.EBCCZarrFilter: the reference codec's contract (encode -> bytes, decode -> flat f32 or
+    `out=`, config round trip) on top of the C API."""
+    from ebcc_amd import EBCC_Filter
+    from ebcc_amd.zarr_filter import EBCCZarrFilter
+    data = L.era5_like(64, 96, 9)
+    opts = EBCC_Filter(base_cr=12, height=64, width=96, residual_opt=("max_error", 0.05))["compression_opts"]
+    codec = EBCCZarrFilter(opts)
+    assert EBCCZarrFilter.from_config(codec.get_config()).get_config() == {"id": "ebcc_filter", "arglist": [int(v) for v in opts]}
+    s = codec.encode(data)
+    cfg = L.make_config((1, 64, 96), base_cr=12, error=0.05, residual_type=L.MAX_ERROR)
+    assert s == api_encode(data, cfg)
+    flat = codec.decode(s)
+    assert flat.shape == (64 * 96,) and np.abs(flat.reshape(64, 96) - data).max() <= 0.05 * 1.01 + 1e-4
+    out = np.zeros((64, 96), np.float32)
+    assert codec.decode(s, out=out) is out and np.array_equal(out.ravel(), flat)
+    const = np.full((64, 96), 7.0, np.float32)
+    out[:] = 0
+    codec.decode(codec.encode(const), out=out)
+    assert np.array_equal(out, const)
+
+
 def test_constant_and_zero_fields():
     for v in (3.25, 0.0):
         data = np.full((64, 64), v, np.float32)

@@ -598,7 +598,7 @@ struct EmitObserver {
     }
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_t1_symbols(unsigned long long *T1S, const unsigned long long *BP,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_t1_symbols(unsigned long long *T1S, const unsigned long long *BP,
                                                     const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax,
                                                     int *numbps, int *totalpasses, int *cblk_len, uint8_t *SYM,
                                                     uint32_t *nsym, unsigned long long *VISP, const J2kGeom *geom,

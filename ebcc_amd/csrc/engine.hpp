@@ -23,9 +23,7 @@ struct ebcc_hip_ctx {
     ebcc::FrameState *h_fs = nullptr;      // pinned
     std::vector<void *> allocs;
     void *j2k = nullptr;                   // base-layer state (j2k.hpp)
-    void *j2k_alt = nullptr;               // same inputs, second set of probe outputs (concurrent second rate search)
-    hipStream_t stream2 = nullptr;
-    int *d_active2 = nullptr;
+    hipStream_t stream2 = nullptr;          // second stream of the engine (decode: residual layer beside the base layer)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;   // ordering between the two streams (created on first use)
     // Sub-batch engines of the frames API: a batch is cut into a few slices that run concurrently, each on its
     // own stream and host thread (the kernels of one slice are latency-bound and leave most of the chip idle).

@@ -260,9 +260,9 @@ struct Batch {
     std::vector<float> state_cr;   // rate of the decode this set holds for every frame (-1: none)
     int *d_active;
     hipStream_t s;
-    Batch(ebcc_hip_ctx *c, const float *d, size_t n_, bool alt = false)
-        : ctx(c), jb(*static_cast<J2kBuffers *>(alt ? c->j2k_alt : c->j2k)), d_frames(d), n(n_), jf(n_), active(n_, 0),
-          state_cr(n_, -1.f), d_active(alt ? c->d_active2 : c->d_active), s(alt ? second_stream(c) : c->stream) {}
+    Batch(ebcc_hip_ctx *c, const float *d, size_t n_)
+        : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), jf(n_), active(n_, 0), state_cr(n_, -1.f),
+          d_active(c->d_active), s(c->stream) {}
     void fetch_jf()
     {
         EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n, hipMemcpyDeviceToHost, s));
@@ -296,99 +296,69 @@ struct Batch {
     }
 };
 
-// Drive rate searches to completion; every round runs at most one probe per frame and probe set.
-//   set[k]   : probe set search k decodes into (null = search k is not run); both may name the same set only
-//              if one of them is null
-//   A search first advances through the probes already on record for its frame (the other search, or the
-//   first encode, usually made them) and only asks the GPU for rates not seen yet.  The final probe of
-//   search 0 (:590) must leave its decode in the set - the residual layer is computed from it - so it is
-//   re-run unless that set's last decode of the frame was at exactly that rate.
+// Drive rate search k (0: error-bounded :728, 1: pure base layer :836) of every frame to completion; every
+// round runs at most one probe per frame.  A search first advances through the probes already on record for its
+// frame (the other search, or the first encode, usually made them) and only asks the GPU for rates not seen yet.
+// The final probe of search 0 (:590) must leave its decode in the engine - the residual layer is computed from
+// it - so it is re-run unless the engine's last decode of the frame was at exactly that rate.
 template <class Jobs>
-void run_searches(Batch *set0, Batch *set1, Jobs &jobs, size_t n_pix)
+void run_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
 {
-    Batch *sets[2] = {set0, set1};
-    const size_t n = (set0 ? set0 : set1)->n;
-    auto advance = [&](Job &j, int k, size_t f) {
+    const size_t n = b.n;
+    auto needs_state = [&](const Job &j, size_t f, float cr) { return k == 0 && j.rs[0].phase == 3 && b.state_cr[f] != cr; };
+    auto feed = [&](Job &j, const ProbeRec &rec) {
         RateSearch &rs = j.rs[k];
-        while (!j.want[k] && !rs.done()) {
-            float cr;
-            if (!rs.next(cr)) break;
-            const ProbeRec *rec = j.find_probe(cr);
-            const bool need_state = k == 0 && rs.phase == 3 && sets[k]->state_cr[f] != cr;
-            if (rec && !need_state) {
-                if (rs.phase == 3) j.last[k] = *rec;
-                const double q = 1. - ((double) rec->nbad / (double) n_pix);                   // :512
-                if (k == 0) j.q = q;
-                rs.feed(q);
-            } else {
-                j.want[k] = true; j.want_cr[k] = cr;
-            }
-        }
+        if (rs.phase == 3) j.last[k] = rec;
+        const double q = 1. - ((double) rec.nbad / (double) n_pix);                            // :512
+        if (k == 0) j.q = q;
+        rs.feed(q);
     };
     for (;;) {
-        bool any[2] = {false, false};
-        for (int k = 0; k < 2; k++)
-            if (sets[k]) std::fill(sets[k]->active.begin(), sets[k]->active.end(), 0);
+        bool any = false;
         for (size_t f = 0; f < n; f++) {
             Job &j = jobs[f];
+            b.active[f] = 0;
             if (j.const_field) continue;
-            for (int k = 0; k < 2; k++) {
-                if (!sets[k]) continue;
-                advance(j, k, f);
-                if (!j.want[k]) continue;
-                // the other search asks for the same rate this round: one probe serves both
-                if (k == 1 && sets[0] && j.want[0] && j.want_cr[0] == j.want_cr[1] && sets[0]->active[f]) continue;
-                sets[k]->active[f] = 1; sets[k]->jf[f].cr = j.want_cr[k]; any[k] = true;
+            while (!j.want[k] && !j.rs[k].done()) {
+                float cr;
+                if (!j.rs[k].next(cr)) break;
+                const ProbeRec *rec = j.find_probe(cr);
+                if (rec && !needs_state(j, f, cr)) feed(j, *rec);
+                else { j.want[k] = true; j.want_cr[k] = cr; }
             }
+            if (j.want[k]) { b.active[f] = 1; b.jf[f].cr = j.want_cr[k]; any = true; }
         }
-        if (!any[0] && !any[1]) break;
-        for (int k = 0; k < 2; k++) if (any[k]) sets[k]->launch_probe(true);
-        for (int k = 0; k < 2; k++) if (any[k]) sets[k]->fetch_jf();
+        if (!any) break;
+        b.probe(true);
         for (size_t f = 0; f < n; f++) {
+            if (!b.active[f]) continue;
             Job &j = jobs[f];
-            for (int k = 0; k < 2; k++) {
-                if (!any[k] || !sets[k]->active[f]) continue;
-                const J2kFrame &r = sets[k]->jf[f];
-                sets[k]->state_cr[f] = r.cr;
-                if (!j.find_probe(r.cr)) j.probes.push_back(ProbeRec{r.cr, r.nbad, r.stream_bytes, r.err_sum});
-                log_trace("frame %zu (search %d): cr %f 1-quantile %.1e jp2_length %d", f, k, r.cr,
-                          (double) r.nbad / (double) n_pix, r.stream_bytes);
-            }
-            for (int k = 0; k < 2; k++) {
-                if (!sets[k] || !j.want[k]) continue;
-                const ProbeRec *rec = j.find_probe(j.want_cr[k]);
-                if (!rec) continue;
-                if (k == 0 && j.rs[0].phase == 3 && sets[0]->state_cr[f] != j.want_cr[0]) continue;
-                RateSearch &rs = j.rs[k];
-                if (rs.phase == 3) j.last[k] = *rec;
-                const double q = 1. - ((double) rec->nbad / (double) n_pix);
-                if (k == 0) j.q = q;
-                rs.feed(q);
-                j.want[k] = false;
-            }
+            const J2kFrame &r = b.jf[f];
+            b.state_cr[f] = r.cr;
+            if (!j.find_probe(r.cr)) j.probes.push_back(ProbeRec{r.cr, r.nbad, r.stream_bytes, r.err_sum});
+            log_trace("frame %zu (search %d): cr %f 1-quantile %.1e jp2_length %d", f, k, r.cr, (double) r.nbad / (double) n_pix,
+                      r.stream_bytes);
+            feed(j, *j.find_probe(r.cr));
+            j.want[k] = false;
         }
     }
-    // A search that leaves through the rate > 1000 exit (:571-574) makes no final probe: its result is the
-    // last doubling step.  Take that probe's record, and for search 0 make sure its decode is in the set.
+    // A search that leaves through the rate > 1000 exit (:571-574) makes no final probe: its result is the last
+    // doubling step.  Take that probe's record, and for search 0 make sure its decode is in the engine.
     bool redo = false;
-    for (int k = 0; k < 2; k++) if (sets[k]) std::fill(sets[k]->active.begin(), sets[k]->active.end(), 0);
     for (size_t f = 0; f < n; f++) {
         Job &j = jobs[f];
+        b.active[f] = 0;
         if (j.const_field) continue;
-        for (int k = 0; k < 2; k++) {
-            if (!sets[k] || j.last[k].cr == j.rs[k].result) continue;
+        if (j.last[k].cr != j.rs[k].result)
             if (const ProbeRec *rec = j.find_probe(j.rs[k].result)) j.last[k] = *rec;
-        }
-        if (sets[0] && sets[0]->state_cr[f] != j.rs[0].result) {
-            sets[0]->active[f] = 1; sets[0]->jf[f].cr = j.rs[0].result; redo = true;
-        }
+        if (k == 0 && b.state_cr[f] != j.rs[0].result) { b.active[f] = 1; b.jf[f].cr = j.rs[0].result; redo = true; }
     }
     if (redo) {
-        sets[0]->probe(true);
+        b.probe(true);
         for (size_t f = 0; f < n; f++)
-            if (sets[0]->active[f]) {
-                const J2kFrame &r = sets[0]->jf[f];
-                sets[0]->state_cr[f] = r.cr;
+            if (b.active[f]) {
+                const J2kFrame &r = b.jf[f];
+                b.state_cr[f] = r.cr;
                 jobs[f].last[0] = ProbeRec{r.cr, r.nbad, r.stream_bytes, r.err_sum};
             }
     }
@@ -467,22 +437,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     pt.mark("first probe");
     if (searching) {
         // ---- rate search #1 (:728)
-        //      The pure-base-layer search (:836) restarts from base_cr with the quantile of a re-encode at
-        //      base_cr (:829-833), i.e. of the first probe above, so unless that consistency step is disabled
-        //      it does not depend on search #1.  It either runs beside search #1 on the second probe set
-        //      (EBCC_HIP_PURE_SEARCH=concurrent) or later, while host cores run zstd (default); either way it
-        //      re-uses every probe search #1 already made.
         const bool pure_done = q_target == 1.0;                                               // :738
         const bool want_pure = !pure_done && !env.no_fallback;
-        const char *ps_env = getenv("EBCC_HIP_PURE_SEARCH");
-        const bool concurrent = want_pure && !env.no_consistency && ps_env && !strcmp(ps_env, "concurrent");
-        std::unique_ptr<Batch> b2(concurrent ? new Batch(ctx, d_frames, n, true) : nullptr);
-        for (size_t f = 0; f < n; f++) {
-            if (jobs[f].const_field) continue;
-            jobs[f].rs[0].start(cfg->base_cr, jobs[f].q, q_target);
-            if (concurrent) { jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0); b2->jf[f] = b.jf[f]; }
-        }
-        run_searches(&b, b2.get(), jobs, n_pix);
+        for (size_t f = 0; f < n; f++)
+            if (!jobs[f].const_field) jobs[f].rs[0].start(cfg->base_cr, jobs[f].q, q_target);
+        run_search(b, 0, jobs, n_pix);
         for (size_t f = 0; f < n; f++) {
             b.active[f] = jobs[f].const_field ? 0 : 1;
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
@@ -624,14 +583,15 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)
         if (want_pure) {
-            if (!concurrent) {
-                for (size_t f = 0; f < n; f++) {
-                    if (jobs[f].const_field) continue;
-                    if (env.no_consistency) jobs[f].rs[1].start(jobs[f].cr, jobs[f].q, 1.0);  // from search #1's state
-                    else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);             // :829-833 == the first probe
-                }
-                run_searches((Batch *) nullptr, &b, jobs, n_pix);                             // :836
+            // The pure-base-layer search restarts from base_cr with the quantile of a re-encode at base_cr
+            // (:829-833), i.e. of the first probe above (unless that consistency step is disabled), and re-uses
+            // every probe search #1 made; it runs here, while host cores do the level-22 zstd.
+            for (size_t f = 0; f < n; f++) {
+                if (jobs[f].const_field) continue;
+                if (env.no_consistency) jobs[f].rs[1].start(jobs[f].cr, jobs[f].q, 1.0);      // from search #1's state
+                else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);                 // :829-833 == the first probe
             }
+            run_search(b, 1, jobs, n_pix);                                                    // :836
             zjoin();
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {

@@ -71,23 +71,6 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blocks, blocks.data(), sizeof(J2kBlock) * blocks.size(), hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blkmap, map.data(), n_pix * sizeof(uint16_t), hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
-    // second set of probe outputs: the pure-base-layer search (:836) does not depend on the first search when
-    // the consistency re-encode is on (default), so both searches advance in the same rounds on two streams
-    J2kBuffers *alt = new J2kBuffers(*jb);
-    ctx->j2k_alt = alt;
-    ok &= (alt->npass = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
-    ok &= (alt->qplane = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
-    ok &= (alt->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;
-    ok &= (alt->V = ctx_alloc<int32_t>(ctx, F * n_pix)) != nullptr;
-    ok &= (alt->B = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
-    ok &= (alt->DEC = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
-    ok &= (alt->jf = (J2kFrame *) ctx_alloc<uint8_t>(ctx, sizeof(J2kFrame) * F)) != nullptr;
-    ok &= (alt->partial = ctx_alloc<double>(ctx, F * kPartials)) != nullptr;
-    ok &= (alt->partial_u = ctx_alloc<unsigned long long>(ctx, F * kPartials)) != nullptr;
-    ok &= (ctx->d_active2 = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
-    if (!ok) return false;
-    EBCC_HIP_CHECK(hipMemsetAsync(alt->jf, 0, sizeof(J2kFrame) * F, s));
-    EBCC_HIP_CHECK(hipMemsetAsync(alt->T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return true;
 }
@@ -95,8 +78,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
 void j2k_destroy(ebcc_hip_ctx *ctx)
 {
     delete static_cast<J2kBuffers *>(ctx->j2k);
-    delete static_cast<J2kBuffers *>(ctx->j2k_alt);
-    ctx->j2k = ctx->j2k_alt = nullptr;
+    ctx->j2k = nullptr;
     if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); ctx->stream2 = nullptr; }
 }
 

@@ -92,7 +92,7 @@ struct J2kBuffers {
     void *ckpt;                   // [frames*nblocks][passes * 16 stripes][9 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
     uint8_t *SYM;                 // [frames*nblocks][kJ2kSymCap] decision streams of the two-phase encoder (t1_core.hpp)
     std::uint32_t *nsym;          // [frames*nblocks] bytes in the stream
-    int *qplane;                  // [frames*nblocks] coding pass at which the current probe's decode restarts (-1: nothing)
+    int *qplane;                  // [frames*nblocks] where the current probe's decode restarts: pass | stripe << 8 (-1: nothing)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
     int *blkmax;                  // [frames*nblocks] max |q6|
     int *numbps;                  // [frames*nblocks]
@@ -115,8 +115,8 @@ struct J2kBuffers {
 // Code-blocks per wavefront in the tier-1 kernels.  The coders are serial and branchy: a wave executes the
 // union of its lanes' paths, and with 76 288 code-blocks a full 64-lane mapping leaves ~1 wave per SIMD, so
 // the SIMDs sit idle between dependent instructions.  Fewer code-blocks per wave = more waves in flight and
-// smaller unions.  Defaults measured on MI355X (profiles/): encode/checkpoint 32, probe restart 16, decode 8;
-// EBCC_T1_LPW=<8|16|32|64> overrides all four.
+// smaller unions.  Defaults measured on MI355X (profiles/): decision pass 32, MQ pass 64 (its lanes share one
+// instruction stream), probe restart 16, decode 8; EBCC_T1_LPW="<n>" or "<a>,<b>,<c>,<d>" overrides them.
 enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
 int t1_lanes_per_wave(int kernel);
 

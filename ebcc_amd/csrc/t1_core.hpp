@@ -62,8 +62,6 @@ struct ConstTable {
     T1_HD uint32_t operator()(int i) const { return mq_entry(i); }
 };
 
-// Context states: 19 contexts x (6-bit state index + mps) packed in two u64 words would need dynamic
-// bit-field updates; a small per-lane byte array in registers/scratch is simpler: state | mps << 7.
 struct Contexts {
     // 19 contexts x 7 bits (6-bit state index | mps << 6) packed 9 per word: no dynamically indexed
     // array, so the state stays in registers on the GPU.

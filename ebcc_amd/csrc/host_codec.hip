@@ -167,15 +167,25 @@ ebcc_hip_ctx *get_context(int H, int W, size_t frames)
     if (it != g_ctx.end() && it->second->max_frames >= frames) return it->second;
     if (it != g_ctx.end()) { ebcc_hip_destroy(it->second); g_ctx.erase(it); }
     ebcc_hip_ctx *c = ebcc_hip_create(0, frames, (size_t) H, (size_t) W);
+    if (!c && !g_ctx.empty()) {                                 // out of device memory: drop the engines of other geometries
+        for (auto &kv : g_ctx) ebcc_hip_destroy(kv.second);
+        g_ctx.clear();
+        c = ebcc_hip_create(0, frames, (size_t) H, (size_t) W);
+    }
     if (c) g_ctx[key] = c;
     return c;
 }
 
-size_t batch_capacity()
+// Frames per device batch of the host-pointer entry points: EBCC_HIP_MAX_BATCH (default 256), reduced for large
+// frames so that an engine's workspace (about 160 bytes per pixel and frame with the worst-case slots) stays
+// under ~48 GB.
+size_t batch_capacity(size_t n_pix)
 {
     const char *e = getenv("EBCC_HIP_MAX_BATCH");
     size_t v = e ? strtoul(e, nullptr, 10) : 256;
-    return v ? v : 256;
+    if (!v) v = 256;
+    const size_t fit = ((size_t) 48 << 30) / (n_pix * 160 + 1);
+    return std::max<size_t>(1, std::min(v, fit));
 }
 
 struct EncodeEnv {
@@ -800,7 +810,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
 size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
 {
     std::lock_guard<std::mutex> lock(g_mutex);
-    const size_t cap = std::min(n, batch_capacity());
+    const size_t cap = std::min(n, batch_capacity((size_t) H * W));
     ebcc_hip_ctx *ctx = get_context(H, W, cap);
     if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
     const size_t n_pix = (size_t) H * W;
@@ -1126,7 +1136,7 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     std::vector<float> chunks(nchunks * csize);
     {
         std::lock_guard<std::mutex> lock(g_mutex);
-        const size_t cap = std::min(nchunks, batch_capacity());
+        const size_t cap = std::min(nchunks, batch_capacity((size_t) H * W));
         ebcc_hip_ctx *ctx = get_context(H, W, cap);
         if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
         float *d = nullptr;

@@ -668,12 +668,20 @@ struct CtxLds {
     __device__ void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = *(const uint32_t *) (base + j * 256); }
 };
 struct MqSink {
+    // coded bytes leave in aligned 8-byte words (a byte store per BYTEOUT costs a whole memory transaction each)
     uint8_t *p; int *overflow;
+    unsigned long long win = 0;
+    int base = 0;                  // index of the first byte held in win
     __device__ void put(int i, uint32_t b)
     {
+        if (i < 0) return;
         if (i >= kJ2kCblkBytes) { *overflow = 1; return; }
-        if (i >= 0) p[i] = (uint8_t) b;
+        const int w = i & ~7;
+        if (w != base) { *(unsigned long long *) (p + base) = win; win = 0; base = w; }
+        const int sh = 8 * (i & 7);
+        win = (win & ~(0xFFull << sh)) | ((unsigned long long) (b & 0xFFu) << sh);
     }
+    __device__ void finish() { *(unsigned long long *) (p + base) = win; }
 };
 
 __global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t *nsym, const int *numbps,

@@ -800,7 +800,8 @@ T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient
 //         index, which lets a device source refill a staging buffer for all lanes at once);
 // CtxMem: uint32_t ld(int ctx), void st(int ctx, uint32_t state), void words(uint32_t out[5]) - the 19 context
 //         states, one byte each (6-bit table index | mps << 6); LDS on the device;
-// Sink:   void put(int index, uint32_t byte), ignored for index < 0;
+// Sink:   void put(int index, uint32_t byte), ignored for index < 0, indices come in increasing order (the last
+//         one possibly twice); void finish() once at the end;
 // CkArray additionally: void store(p, s, a, c16, shifts, const uint32_t cx[5]).
 // The coder is written for SIMT execution: one code path for MPS and LPS, renormalisation by count, a
 // branch-free BYTEOUT, and the next decision / context state fetched while the current one is coded.
@@ -867,6 +868,7 @@ T1_HD EncodeResult mq_encode_stream(SymSrc sym, CtxMem cx, uint32_t nsym, int np
         c <<= ct; byteout();
         sink.put(n, cur);
         if (cur != 0xFFu) n++;
+        sink.finish();                                                    // (a buffering sink writes out its tail)
     }
     rates[p] = n;
     int last = n;

@@ -41,7 +41,7 @@ struct HostStore {
     }
 };
 struct VecSink { std::vector<uint8_t> *v; void put(int i, uint8_t b) { if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = b; } };
-struct VecSink2 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } };
+struct VecSink2 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void finish() {} };
 struct VecAt { std::vector<uint8_t> *v; uint8_t operator()(int i) const { return i < (int) v->size() ? (*v)[i] : 0; } };
 struct Obs {                      // decoder registers at the start of every (pass, stripe)
     MqCheckpoint ck[120 * 16];

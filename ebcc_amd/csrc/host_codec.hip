@@ -916,6 +916,7 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     log_set_level_from_env();
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     const size_t n_pix = ctx->n_pix;
+    for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }   // on error: free the non-null ones
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
         return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo, next);
     }, "EBCC_HIP_SLICES", 2);

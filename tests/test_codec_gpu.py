@@ -111,6 +111,31 @@ def test_era5_like_batch_matches_oracle(mode, err):
         assert np.abs(dec[f] - frames[f]).max() <= 1.01 * tgt + 1e-3
 
 
+def test_full_size_batch_is_configuration_independent(monkeypatch):
+    """A 48-frame batch of 721x1440 frames (BASELINE configs[1] shape): the streams must not depend on how the
+    engine is configured (slices, single- or two-phase tier-1 encoder, lanes per wave) - a checksum of checksums
+    over the batch - and sampled frames must equal the oracle's streams."""
+    frames = np.stack([L.era5_like(721, 1440, 100 + s, 1.5, 2.5) for s in range(6)] * 8)
+    frames = frames + np.arange(48, dtype=np.float32)[:, None, None] * np.float32(0.37)        # 48 distinct frames
+    cfg = L.make_config((1, 721, 1440), base_cr=30.0, error=0.5, residual_type=L.MAX_ERROR)
+    digests = {}
+    for name, env in (("default", {}), ("one slice", {"EBCC_HIP_SLICES": "1"}),
+                      ("single-kernel tier-1, 16 lanes", {"EBCC_T1_TWO_PHASE": "0", "EBCC_T1_LPW": "16"})):
+        for k in ("EBCC_HIP_SLICES", "EBCC_T1_TWO_PHASE", "EBCC_T1_LPW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with L.Context(len(frames), 721, 1440) as ctx:
+            got = ctx.encode_frames(frames, cfg)
+            dec = ctx.decode_frames(got)
+        assert np.abs(dec - frames).max() <= 0.5 * 1.01 + 1e-3, name
+        digests[name] = (sha(b"".join(sha(s).encode() for s in got)), sha(dec.tobytes()), got[0], got[47])
+    assert digests["default"][:2] == digests["one slice"][:2] == digests["single-kernel tier-1, 16 lanes"][:2]
+    L.oracle().orc_set_j2k_backend(0)
+    assert digests["default"][2] == L.orc_encode(frames[0], cfg)
+    assert digests["default"][3] == L.orc_encode(frames[47], cfg)
+
+
 def test_sliced_batches_equal_single_engine(monkeypatch):
     """The frames API cuts a large batch into slices that run concurrently on their own engines / streams /
     host threads (EBCC_HIP_SLICES): streams and decoded fields must not depend on the slicing."""

@@ -579,6 +579,14 @@ struct SymPutDev {
             win = 0;
         }
     }
+    __device__ void put_if(bool on, uint32_t i, uint32_t sym)           // branch-free unless a word completes
+    {
+        win |= (unsigned long long) (on ? sym : 0u) << (8 * (i & 7u));
+        if (on && (i & 7u) == 7u) {
+            if (i < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (i & ~7u)) = win; else *overflow = 1;
+            win = 0;
+        }
+    }
     __device__ void flush(uint32_t n)
     {
         if ((n & 7u) && n < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (n & ~7u)) = win;
@@ -596,7 +604,7 @@ struct EmitObserver {
     }
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_t1_symbols(unsigned long long *T1S, const unsigned long long *BP,
+__global__ __launch_bounds__(64) void k_t1_symbols(unsigned long long *T1S, const unsigned long long *BP,
                                                     const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax,
                                                     int *numbps, int *totalpasses, int *cblk_len, uint8_t *SYM,
                                                     uint32_t *nsym, unsigned long long *VISP, const J2kGeom *geom,

@@ -619,6 +619,199 @@ struct Passes {
             store(sp, y0);
         }
     }
+
+    // =============================================================================================
+    // Encoder passes computed on the row masks (decision emitter only).  For the encoder every outcome is known
+    // in advance, so which samples a pass codes, which of them become significant and every context follow
+    // from mask arithmetic over the whole stripe; only writing the decisions out in scan order stays a loop
+    // over columns - one code path for all lanes, no per-sample branching.
+    //   * membership of the propagation pass: a sample is coded if it is insignificant and has a significant
+    //     neighbour WHEN IT IS VISITED, i.e. counting samples that became significant earlier in this pass
+    //     (same column above, previous column).  Along a row this is a carry chain - one addition
+    //     (flood()) - and the coupling between rows converges in a few sweeps.
+    //   * contexts: the eight neighbours' significance at visit time as eight masks, their sums bit-sliced
+    //     (T.800 tables D-1..D-3 as boolean functions).
+    // =============================================================================================
+    T1_HD static u64 flood(u64 p, u64 g)                                 // n(x) = g(x) | (p(x) & n(x-1)),  g subset of p
+    {
+        const u64 sum = p + g;
+        return g | (p & (sum ^ p ^ g));
+    }
+    struct RowCtx { u64 n0, n1, n2, n3; };                                // zero-coding context number, bit-sliced
+    struct RowSgn { u64 c0, c1, c2, sb; };                                // sign context number and the coded bit (sign ^ xor bit)
+
+    // at-visit significance of the eight neighbours of every column of a row -> table D-1
+    T1_HD RowCtx zc_bits(u64 l, u64 r, u64 u, u64 d, u64 ul, u64 ur, u64 dl, u64 dr) const
+    {
+        u64 h0 = l ^ r, h1 = l & r, v0 = u ^ d, v1 = u & d;
+        const u64 a = ul ^ ur, b = ul & ur, c = dl ^ dr, e = dl & dr, k = a & c;
+        const u64 d0 = a ^ c, d1 = b ^ e ^ k, d2 = b & e;
+        const u64 dge1 = d0 | d1 | d2, dge2 = d1 | d2, dge3 = (d1 & d0) | d2;
+        RowCtx o;
+        if (orient == 3) {
+            const u64 hvge1 = h0 | h1 | v0 | v1, hvge2 = h1 | v1 | (h0 & v0);
+            const u64 e0 = ~dge1, e1 = dge1 & ~dge2, e2 = dge2 & ~dge3;
+            o.n3 = dge3;
+            o.n2 = e2 | (e1 & hvge1);
+            o.n1 = e2 | (e1 & ~hvge1) | (e0 & hvge2);
+            o.n0 = (e2 & hvge1) | (e1 & hvge2) | (e1 & ~hvge1) | (e0 & hvge1 & ~hvge2);
+        } else {
+            if (orient == 1) { u64 t = h0; h0 = v0; v0 = t; t = h1; h1 = v1; v1 = t; }
+            const u64 hz = ~(h0 | h1), vz = ~(v0 | v1);
+            o.n3 = h1;
+            o.n2 = h0 | (hz & v1);
+            o.n1 = (h0 & (~vz | dge1)) | (hz & (v0 | (vz & dge2)));
+            o.n0 = (h0 & (~vz | ~dge1)) | (hz & (v0 | (vz & dge1 & ~dge2)));
+        }
+        return o;
+    }
+    // horizontal / vertical neighbours: significance at visit time and their signs -> tables D-2, D-3
+    T1_HD static RowSgn sc_bits(u64 l, u64 ln, u64 r, u64 rn, u64 u, u64 un, u64 d, u64 dn, u64 sgn)
+    {
+        const u64 lp = l & ~ln, lm = l & ln, rp = r & ~rn, rm = r & rn;
+        const u64 up = u & ~un, um = u & un, dp = d & ~dn, dm = d & dn;
+        const u64 hp = (lp | rp) & ~(lm | rm), hn = (lm | rm) & ~(lp | rp), hz = ~(hp | hn);
+        const u64 vp = (up | dp) & ~(um | dm), vn = (um | dm) & ~(up | dp), vz = ~(vp | vn);
+        const u64 n4 = (hp & vp) | (hn & vn), n3 = (hp | hn) & vz, n2 = (hp & vn) | (hn & vp), n1 = hz & (vp | vn);
+        RowSgn o;
+        o.c2 = n4; o.c1 = n3 | n2; o.c0 = n3 | n1;
+        o.sb = sgn ^ (hn | (hz & vn));
+        return o;
+    }
+    T1_HD static uint32_t bit_at(u64 m, int x) { return (uint32_t) (m >> x) & 1u; }
+
+    // contexts of all four rows given the samples that become significant in this pass (n[r], signs from sgn)
+    T1_HD void row_contexts(const Stripe &sp, const u64 n[4], RowCtx zc[4], RowSgn sc[4]) const
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const u64 nu = r > 0 ? n[r - 1] : 0ull, nd = r < 3 ? n[r + 1] : 0ull;     // new significance of the rows above / below
+            const u64 up = sp.s[r] | nu, mid = sp.s[r + 1] | n[r], dn = sp.s[r + 2];
+            // earlier in the scan: the row above in this column, everything in the previous column
+            zc[r] = zc_bits(mid << 1, sp.s[r + 1] >> 1, up, dn, up << 1, sp.s[r] >> 1, (dn | nd) << 1, dn >> 1);
+            const u64 upn = sp.neg[r] | (nu & (r > 0 ? sp.sgn[r > 0 ? r - 1 : 0] : 0ull));
+            const u64 midn = sp.neg[r + 1] | (n[r] & sp.sgn[r]);
+            sc[r] = sc_bits(mid << 1, midn << 1, sp.s[r + 1] >> 1, sp.neg[r + 1] >> 1, up, upn, dn, sp.neg[r + 2], sp.sgn[r]);
+        }
+    }
+
+    T1_HD void sigprop_bits(int plane, int ystart = 0)
+    {
+        for (int y0 = ystart; y0 < h; y0 += 4) {
+            stripe_hook(y0);
+            Stripe sp;
+            load(sp, y0);
+            const u64 b[4] = {st.BP(plane, y0), st.BP(plane, y0 + 1), st.BP(plane, y0 + 2), st.BP(plane, y0 + 3)};
+            u64 cand[4], p[4], nbo[4], n[4] = {0, 0, 0, 0}, m[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                cand[r] = ~sp.s[r + 1] & (r < sp.nrows ? sp.wmask : 0ull);
+                p[r] = cand[r] & b[r];
+                nbo[r] = neighbours(sp.s[r], sp.s[r + 1], sp.s[r + 2]);
+            }
+            bool changed;
+            do {
+                changed = false;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const u64 ext = (r > 0 ? n[r - 1] | (n[r - 1] << 1) : 0ull) | (r < 3 ? n[r + 1] << 1 : 0ull);
+                    const u64 v = flood(p[r], p[r] & (nbo[r] | ext));
+                    changed |= v != n[r];
+                    n[r] = v;
+                }
+            } while (changed);
+            u64 pending = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const u64 ext = (r > 0 ? n[r - 1] | (n[r - 1] << 1) : 0ull) | (r < 3 ? n[r + 1] << 1 : 0ull);
+                m[r] = cand[r] & (nbo[r] | ext | (n[r] << 1));
+                pending |= m[r];
+            }
+            if (pending) {
+                RowCtx zc[4];
+                RowSgn sc[4];
+                row_contexts(sp, n, zc, sc);
+                while (pending) {
+                    T1_STAT(0);
+                    const int x = ctz64(pending);
+                    pending &= pending - 1;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t on = bit_at(m[r], x), d = bit_at(b[r], x);
+                        mq.emit_if(on != 0, bit_at(zc[r].n0, x) | (bit_at(zc[r].n1, x) << 1) | (bit_at(zc[r].n2, x) << 2) | (bit_at(zc[r].n3, x) << 3), d);
+                        mq.emit_if((on & d) != 0, (uint32_t) CTX_SC0 + (bit_at(sc[r].c0, x) | (bit_at(sc[r].c1, x) << 1) | (bit_at(sc[r].c2, x) << 2)),
+                                   bit_at(sc[r].sb, x));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                sp.s[r + 1] |= n[r];
+                sp.neg[r + 1] |= n[r] & sp.sgn[r];
+                sp.vis[r] |= m[r];
+                sp.sps[r] |= n[r];
+            }
+            store(sp, y0);
+        }
+    }
+
+    T1_HD void cleanup_bits(int plane, int ystart = 0)
+    {
+        for (int y0 = ystart; y0 < h; y0 += 4) {
+            stripe_hook(y0);
+            Stripe sp;
+            load(sp, y0);
+            const u64 b[4] = {st.BP(plane, y0), st.BP(plane, y0 + 1), st.BP(plane, y0 + 2), st.BP(plane, y0 + 3)};
+            u64 m[4], n[4], pending = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                m[r] = ~(sp.s[r + 1] | sp.vis[r]) & (r < sp.nrows ? sp.wmask : 0ull);
+                n[r] = m[r] & b[r];
+                pending |= m[r];
+            }
+            if (pending) {
+                // run-length mode: all four samples of the column are coded here and nothing in the 3 x 6
+                // neighbourhood is significant when the column is entered (previous column's news included)
+                u64 agg = 0;
+                if (y0 + 3 < h) {
+                    u64 any = (n[0] | n[1] | n[2] | n[3]) << 1;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) any |= sp.s[r] | (sp.s[r] << 1) | (sp.s[r] >> 1);
+                    agg = m[0] & m[1] & m[2] & m[3] & ~any;
+                }
+                RowCtx zc[4];
+                RowSgn sc[4];
+                row_contexts(sp, n, zc, sc);
+                while (pending) {
+                    T1_STAT(2);
+                    const int x = ctz64(pending);
+                    pending &= pending - 1;
+                    const uint32_t a = bit_at(agg, x);
+                    const uint32_t d0 = bit_at(b[0], x), d1 = bit_at(b[1], x), d2 = bit_at(b[2], x), d3 = bit_at(b[3], x);
+                    const uint32_t run = d0 ? 0u : (d1 ? 1u : (d2 ? 2u : (d3 ? 3u : 4u)));
+                    const bool hit = a && run != 4u;
+                    mq.emit_if(a != 0, (uint32_t) CTX_AGG, run != 4u ? 1u : 0u);
+                    mq.emit_if(hit, (uint32_t) CTX_UNI, run >> 1);
+                    mq.emit_if(hit, (uint32_t) CTX_UNI, run & 1u);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t on = bit_at(m[r], x), d = bit_at(b[r], x);
+                        const bool zc_on = on && !(a && (uint32_t) r <= run);          // rows up to the run's end carry no own decision
+                        mq.emit_if(zc_on, bit_at(zc[r].n0, x) | (bit_at(zc[r].n1, x) << 1) | (bit_at(zc[r].n2, x) << 2) | (bit_at(zc[r].n3, x) << 3), d);
+                        mq.emit_if((on & d) != 0, (uint32_t) CTX_SC0 + (bit_at(sc[r].c0, x) | (bit_at(sc[r].c1, x) << 1) | (bit_at(sc[r].c2, x) << 2)),
+                                   bit_at(sc[r].sb, x));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                sp.s[r + 1] |= n[r];
+                sp.neg[r + 1] |= n[r] & sp.sgn[r];
+                sp.vis[r] = 0;                                           // the visited flags die with the plane
+            }
+            store(sp, y0);
+        }
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -750,6 +943,8 @@ struct SymbolEmitter {
     uint32_t n;
     Put put;
     T1_HD void emit(int ctx, int d) { put(n, (uint32_t) ctx | ((uint32_t) d << 5)); n++; }
+    // the same when `on`, nothing otherwise - without a branch around it (bit-parallel passes below)
+    T1_HD void emit_if(bool on, uint32_t ctx, uint32_t d) { put.put_if(on, n, ctx | (d << 5)); n += on ? 1u : 0u; }
     T1_HD void mark(bool new_pass) { put(n, kSymStripe | (new_pass ? kSymPass : 0u)); n++; }
     T1_HD void encode_zc(int ctx, int d) { emit(ctx, d); }
     T1_HD void encode_sc(int ctx, int d) { emit(ctx, d); }
@@ -774,7 +969,7 @@ struct MarkingObserver {
 __device__ long long t1_profile[4];
 #endif
 // Returns the number of coding passes; the length of the stream is in em.n afterwards.
-template <class Store, class Put, class Observer>
+template <bool BITS = true, class Store, class Put, class Observer>
 T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient, int numbps, Observer &inner)
 {
     MarkingObserver<Observer> obs{inner};
@@ -785,9 +980,9 @@ T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient
 #ifdef EBCC_T1_PROFILE
         const long long t0_ = wall_clock64();
 #endif
-        if (passtype == 0) { ps.sigprop(bp); obs.sigprop_done(bp, st); }
+        if (passtype == 0) { if constexpr (BITS) ps.sigprop_bits(bp); else ps.sigprop(bp); obs.sigprop_done(bp, st); }
         else if (passtype == 1) ps.refine(bp);
-        else ps.cleanup(bp);
+        else { if constexpr (BITS) ps.cleanup_bits(bp); else ps.cleanup(bp); }
 #ifdef EBCC_T1_PROFILE
         t1_profile[passtype] += wall_clock64() - t0_;
 #endif

@@ -59,7 +59,8 @@ struct EncObs {                   // the same, derived from the encoder
     template <class Mq> void stripe_start(int y0, const Mq &m) { ck[cur * nstr + (y0 >> 2)] = encoder_checkpoint(m); }
     template <class Store> void sigprop_done(int bp, Store &st) { for (int y = 0; y < 64; y++) visp[bp][y] = st.VIS(y); }
 };
-struct SymPut { std::vector<uint8_t> *v; void operator()(uint32_t i, uint32_t sym) { if (v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) sym; } };
+struct SymPut { std::vector<uint8_t> *v; void operator()(uint32_t i, uint32_t sym) { if (v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) sym; }
+                void put_if(bool on, uint32_t i, uint32_t sym) { if (on) (*this)(i, sym); } };
 struct SymGet { const std::vector<uint8_t> *v; uint32_t get(uint32_t i) const { return (*v)[i]; } };
 struct EmitObs {                  // phase 1 observer (the stripe markers go into the stream itself)
     u64 visp[40][64];
@@ -138,8 +139,26 @@ int main(int argc, char **argv)
             memset(st2.ref, 0, sizeof st2.ref); memset(st2.sps, 0, sizeof st2.sps);
             std::vector<uint8_t> syms, bytes2;
             static EmitObs mobs;
+            memset(mobs.visp, 0, sizeof mobs.visp);
             SymbolEmitter<SymPut> em{0, SymPut{&syms}};
-            const int np2 = emit_block(st2, em, w, h, orient, numbps, mobs);
+            const int np2 = emit_block<true>(st2, em, w, h, orient, numbps, mobs);
+            {
+                HostStore st3 = st;
+                memset(st3.s, 0, sizeof st3.s); memset(st3.neg, 0, sizeof st3.neg); memset(st3.vis, 0, sizeof st3.vis);
+                memset(st3.ref, 0, sizeof st3.ref); memset(st3.sps, 0, sizeof st3.sps);
+                std::vector<uint8_t> syms3;
+                static EmitObs mobs3;
+                memset(mobs3.visp, 0, sizeof mobs3.visp);
+                SymbolEmitter<SymPut> em3{0, SymPut{&syms3}};
+                const int np3 = emit_block<false>(st3, em3, w, h, orient, numbps, mobs3);
+                bool eq = np3 == np2 && em3.n == em.n && memcmp(syms3.data(), syms.data(), em.n) == 0 && memcmp(mobs3.visp, mobs.visp, sizeof mobs.visp) == 0;
+                if (!eq) {
+                    size_t k = 0; while (k < em.n && k < em3.n && syms[k] == syms3[k]) k++;
+                    printf("trial %d BIT-PARALLEL EMISSION differs at %zu of %u/%u (w %d h %d orient %d P %d): %02x vs %02x\n", t, k, em.n, em3.n, w, h, orient, numbps,
+                           k < em.n ? syms[k] : 0, k < em3.n ? syms3[k] : 0);
+                    bad++; continue;
+                }
+            }
             static MqCheckpoint ck2[120 * 16];
             CkView ckv2{ck2, nstr};
             int rates2[kMaxPasses];

@@ -115,7 +115,7 @@ struct J2kBuffers {
 // Code-blocks per wavefront in the tier-1 kernels.  The coders are serial and branchy: a wave executes the
 // union of its lanes' paths, and with 76 288 code-blocks a full 64-lane mapping leaves ~1 wave per SIMD, so
 // the SIMDs sit idle between dependent instructions.  Fewer code-blocks per wave = more waves in flight and
-// smaller unions.  Defaults measured on MI355X (profiles/): decision pass 32, MQ pass 64 (its lanes share one
+// smaller unions.  Defaults measured on MI355X (profiles/): decision pass 64 and MQ pass 64 (their lanes share one
 // instruction stream), probe restart 16, decode 8; EBCC_T1_LPW="<n>" or "<a>,<b>,<c>,<d>" overrides them.
 enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
 int t1_lanes_per_wave(int kernel);

@@ -32,7 +32,7 @@ int t1_lanes_per_wave(int kernel)
 {
     // EBCC_T1_LPW = "<n>" (all kernels) or "<decision pass>,<MQ pass>,<probe restart>,<decode>", each 8, 16, 32 or 64
     // (read at every launch: a tuning knob, results do not depend on it)
-    int t[4] = {32, 64, 16, 8};
+    int t[4] = {64, 64, 16, 8};
     if (const char *e = getenv("EBCC_T1_LPW")) {
         int v[4], n = sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
         for (int i = 0; i < 4; i++) {
@@ -839,7 +839,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     EBCC_HIP_CHECK(hipMemsetAsync(jb.SPS, 0, groups * 64 * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_encode", s);
     if (!jb.SYM) {
-        int lpw = t1_lanes_per_wave(T1_ENCODE);
+        int lpw = getenv("EBCC_T1_LPW") ? t1_lanes_per_wave(T1_ENCODE) : 32;    // (the single-kernel encoder is at its best with 32)
         unsigned t1_grid = (unsigned) ceil_div(total, lpw);
         hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
                            jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.VISP, jb.d_geom,

@@ -812,6 +812,34 @@ struct Passes {
             store(sp, y0);
         }
     }
+
+    T1_HD void refine_bits(int plane, int ystart = 0)
+    {
+        for (int y0 = ystart; y0 < h; y0 += 4) {
+            stripe_hook(y0);
+            Stripe sp;
+            load(sp, y0);
+            const u64 b[4] = {st.BP(plane, y0), st.BP(plane, y0 + 1), st.BP(plane, y0 + 2), st.BP(plane, y0 + 3)};
+            u64 m[4], ref[4], nb[4], pending = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                m[r] = sp.s[r + 1] & ~sp.vis[r];                          // significant before this plane
+                ref[r] = st.REF(y0 + r);
+                nb[r] = neighbours(sp.s[r], sp.s[r + 1], sp.s[r + 2]);
+                pending |= m[r];
+            }
+            while (pending) {
+                T1_STAT(1);
+                const int x = ctz64(pending);
+                pending &= pending - 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    mq.emit_if(bit_at(m[r], x) != 0, (uint32_t) CTX_MAG0 + (bit_at(ref[r], x) ? 2u : bit_at(nb[r], x)), bit_at(b[r], x));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) st.REF(y0 + r) = ref[r] | m[r];
+        }
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -981,7 +1009,7 @@ T1_HD int emit_block(Store &st, SymbolEmitter<Put> &em, int w, int h, int orient
         const long long t0_ = wall_clock64();
 #endif
         if (passtype == 0) { if constexpr (BITS) ps.sigprop_bits(bp); else ps.sigprop(bp); obs.sigprop_done(bp, st); }
-        else if (passtype == 1) ps.refine(bp);
+        else if (passtype == 1) { if constexpr (BITS) ps.refine_bits(bp); else ps.refine(bp); }
         else { if constexpr (BITS) ps.cleanup_bits(bp); else ps.cleanup(bp); }
 #ifdef EBCC_T1_PROFILE
         t1_profile[passtype] += wall_clock64() - t0_;

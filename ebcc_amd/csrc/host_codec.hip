@@ -727,6 +727,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     const J2kGeom &g = jb.geom;
     std::vector<int> table(n * (size_t) g.nblocks * 4, 0);
     std::vector<std::vector<uint8_t>> coeffs(n);
+    PhaseTimer pt;
     fetch_frame_states(ctx, n);
     bool any_resid = false;
     for (size_t f = 0; f < n; f++) {
@@ -758,6 +759,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
             }
         }
     }
+    pt.mark("decode: parse, zstd, uploads");
     push_frame_states(ctx, n);
     // The residual layer (SPIHT decode + synthesis: one wave per frame, latency-bound) does not depend on the
     // base layer until the final addition, so it runs on the engine's second stream beside the tier-1 decode.
@@ -803,6 +805,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
             EBCC_HIP_CHECK(hipStreamSynchronize(s));
         }
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    pt.mark("decode: kernels");
     return 0;
 }
 

@@ -206,6 +206,18 @@ def test_zarr_codec_class():
     assert np.array_equal(out, const)
 
 
+@pytest.mark.parametrize("switch", ["EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK",
+                                    "EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK_CONSISTENCY", "EBCC_DISABLE_MEAN_ADJUSTMENT"])
+def test_env_switches_match_oracle(switch, monkeypatch):
+    """src/ebcc_codec.c:634-649 (pinned against the reference build by tests/test_oracle_golden.py)."""
+    from tests.test_oracle_golden import env_switch_cases
+    monkeypatch.setenv(switch, "1")
+    monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", "0.1")        # loose base layer: the switches change the streams
+    L.oracle().orc_set_j2k_backend(0)
+    for frame, cfg in env_switch_cases():
+        assert api_encode(frame, cfg) == L.orc_encode(frame, cfg), switch
+
+
 def test_constant_and_zero_fields():
     for v in (3.25, 0.0):
         data = np.full((64, 64), v, np.float32)

@@ -157,3 +157,32 @@ def test_legacy_repack_is_what_the_reference_decodes():
             n = ref.ebcc_decode(b, len(leg), ctypes.byref(out))
             got = np.frombuffer(ctypes.string_at(out.value, 4 * n), np.float32)
             assert hashlib.sha256(got.tobytes()).hexdigest() == streams[name]["decoded_sha256"], name
+
+
+ENV_SWITCHES = ["EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", "EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK_CONSISTENCY",
+                "EBCC_DISABLE_MEAN_ADJUSTMENT"]
+
+
+def env_switch_cases():
+    """(frame, config) pairs that exercise both outcomes of the :838 selection (residual kept / pure base layer)."""
+    a = L.era5_like(64, 96, 21, 1.0, 0.8)
+    b = L.smooth_image(96, 64, 5) if hasattr(L, "smooth_image") else L.era5_like(96, 64, 22, 2.5, 0.2)
+    return [(a, L.make_config((1, 64, 96), base_cr=25.0, error=0.02, residual_type=L.MAX_ERROR)),
+            (a, L.make_config((1, 64, 96), base_cr=8.0, error=2e-3, residual_type=L.RELATIVE_ERROR)),
+            (np.ascontiguousarray(b, np.float32).reshape(96, 64), L.make_config((1, 96, 64), base_cr=40.0, error=0.05, residual_type=L.MAX_ERROR))]
+
+
+@pytest.mark.skipif(not os.path.exists(L.REF_SO), reason="reference build only exists in the dev container")
+@pytest.mark.parametrize("switch", ENV_SWITCHES)
+def test_oracle_env_switches_match_reference(switch, monkeypatch):
+    """The three EBCC_DISABLE_* switches of src/ebcc_codec.c:634-649: oracle == reference build, so that the GPU
+    test of the same switches (tests/test_codec_gpu.py) can use the oracle on a box without the reference."""
+    ref = ctypes.CDLL(L.REF_SO)
+    ref.ebcc_encode.restype = ctypes.c_size_t
+    ref.ebcc_encode.argtypes = [ctypes.c_void_p, ctypes.POINTER(L.CodecConfig), L.c_void_pp]
+    monkeypatch.setenv(switch, "1")
+    monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", "0.1")        # loose base layer: the switches change the streams
+    for frame, cfg in env_switch_cases():
+        out = ctypes.c_void_p()
+        n = ref.ebcc_encode(np.ascontiguousarray(frame, np.float32).ctypes.data, ctypes.byref(cfg), ctypes.byref(out))
+        assert ctypes.string_at(out.value, n) == L.orc_encode(frame, cfg), switch

@@ -108,9 +108,8 @@ class BatchCodec:
 def create_dataset(group, name, shape, base_cr, residual_opt=("none", None), **kw):
     """An EBCC-filtered float32 dataset of shape (..., H, W) with one frame per chunk."""
     h, w = shape[-2:]
-    chunks = (1,) * (len(shape) - 2) + (h, w)
-    return group.create_dataset(name, shape=shape, dtype="f4", chunks=chunks,
-                                **EBCC_Filter(base_cr=base_cr, height=h, width=w, residual_opt=residual_opt), **kw)
+    return group.create_dataset(name, shape=shape,
+                                **EBCC_Filter(base_cr=base_cr, height=h, width=w, residual_opt=residual_opt, data_dim=len(shape)), **kw)
 
 
 def write_frames(dset, data, base_cr, residual_opt=("none", None), batch=256, codec=None):

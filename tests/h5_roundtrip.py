@@ -17,11 +17,11 @@ y, x = np.mgrid[0:H, 0:W]
 data = np.stack([(280 + 10 * np.sin(x / (9.0 + k)) * np.cos(y / (7.0 + k)) + rng.normal(0, 0.4, (H, W))).astype(np.float32)
                  for k in range(N)])
 data[3] = 1.5                                                    # constant field
-opt = ("max_error", 0.1)
+opt = ("max_error_target", 0.1)
 
 # (1) through the HDF5 filter callback, one chunk per call
 with h5py.File(os.path.join(out, "cb.h5"), "w") as f:
-    f.create_dataset("t", data=data, chunks=(1, H, W), **EBCC_Filter(base_cr=20, height=H, width=W, residual_opt=opt))
+    f.create_dataset("t", data=data, **EBCC_Filter(base_cr=20, height=H, width=W, residual_opt=opt, data_dim=3))
 with h5py.File(os.path.join(out, "cb.h5"), "r") as f:
     back = f["t"][...]
     raw_cb = [f["t"].id.read_direct_chunk((k, 0, 0))[1] for k in range(N)]

@@ -78,3 +78,22 @@ def test_populate_config_matches_reference_packing():
     lib.populate_config(ctypes.byref(cfg), 5, cd, 2 * 721 * 1440 * 4)
     assert tuple(cfg.dims) == (2, 721, 1440) and cfg.base_cr == 30.0 and cfg.residual_compression_type == 1
     assert abs(cfg.error - 0.5) < 1e-7 and tuple(cfg.chunk_dims) == (0, 0, 0)
+
+
+def test_filter_wrapper_mirrors_reference_interface():
+    """ebcc_amd.EBCC_Filter against the contract of /root/reference/ebcc/filter_wrapper.py:16-68 (names of the
+    residual options, keyword set, attributes, cd_values packing); values cross-checked with the CDO string the
+    reference's README quotes for base_cr 30 / max error 0.5 on 721x1440."""
+    from ebcc_amd import EBCC_Filter
+    f = EBCC_Filter(base_cr=30, height=721, width=1440, residual_opt=("max_error_target", 0.5), data_dim=3)
+    assert dict(f) == {"dtype": "float32", "chunks": (1, 721, 1440), "compression": 308,
+                       "compression_opts": (721, 1440, 1106247680, 1, 1056964608)}
+    assert f.hdf_filter_opts == f["compression_opts"] and f.chunks == (1, 721, 1440) and EBCC_Filter.FILTER_ID == 308
+    assert (f.base_cr, f.height, f.width, f.data_dim, f.residual_opt) == (30.0, 721, 1440, 3, ("max_error_target", 0.5))
+    assert f.cdo_filter_string() == "308,721,1440,1106247680,1,1056964608"
+    assert EBCC_Filter(10, 64, 64, ("relative_error_target", 0.01)).hdf_filter_opts[3:] == (2, 1008981770)
+    assert EBCC_Filter(10, 64, 64, ("none", 0)).hdf_filter_opts == (64, 64, 1092616192, 0)
+    assert EBCC_Filter(10, 64, 64, None, data_dim=4).chunks == (1, 1, 64, 64)
+    assert hash(f) == hash(EBCC_Filter(30, 721, 1440, ("max_error", 0.5)))
+    with pytest.raises(ValueError):
+        EBCC_Filter(10, 64, 64, ("lossless", 0))

@@ -190,7 +190,9 @@ def test_zarr_codec_class():
     from ebcc_amd import EBCC_Filter
     from ebcc_amd.zarr_filter import EBCCZarrFilter
     data = L.era5_like(64, 96, 9)
-    opts = EBCC_Filter(base_cr=12, height=64, width=96, residual_opt=("max_error", 0.05))["compression_opts"]
+    flt = EBCC_Filter(base_cr=12, height=64, width=96, residual_opt=("max_error_target", 0.05))
+    opts = flt.hdf_filter_opts
+    assert opts == flt["compression_opts"] == EBCC_Filter(12, 64, 96, ("max_error", 0.05)).hdf_filter_opts
     codec = EBCCZarrFilter(opts)
     assert EBCCZarrFilter.from_config(codec.get_config()).get_config() == {"id": "ebcc_filter", "arglist": [int(v) for v in opts]}
     s = codec.encode(data)

@@ -191,6 +191,7 @@ size_t batch_capacity(size_t n_pix)
 struct EncodeEnv {
     double base_error_quantile = 1e-6;
     bool no_fallback = false, no_consistency = false, no_mean_adjust = false;
+    int zstd_level = 22;
     EncodeEnv()
     {
         // :634-649
@@ -198,6 +199,9 @@ struct EncodeEnv {
         no_fallback = getenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK") != nullptr;
         no_consistency = getenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK_CONSISTENCY") != nullptr;
         no_mean_adjust = getenv("EBCC_DISABLE_MEAN_ADJUSTMENT") != nullptr;
+        // Level of the residual's zstd stage (:816 uses 22).  Any level gives streams every EBCC decoder reads, but
+        // only 22 reproduces the reference's bytes, so this is an opt-in knob (SURVEY section 8(f) n3 study).
+        if (const char *e = getenv("EBCC_ZSTD_LEVEL")) { long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 22) zstd_level = (int) v; }
     }
 };
 
@@ -577,7 +581,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 Job &j = jobs[f];
                 if (j.coeffs_size == 0) continue;
                 j.zbytes.resize(zstd().bound(j.coeffs_size));
-                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_bytes[f].data(), j.coeffs_size, 22);
+                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_bytes[f].data(), j.coeffs_size, env.zstd_level);
                 j.zbytes.resize(z);
             }
         };

@@ -25,6 +25,8 @@
 
 namespace ebcc {
 bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table);
+bool j2k_peek_dims(const uint8_t *cs, size_t n, int *W, int *H, int *tile_w, int *tile_h);
+bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kGeom &g, int tiles, int *tables, size_t *part_off, size_t *part_len);
 }
 using namespace ebcc;
 
@@ -229,6 +231,8 @@ struct SliceGate {
     void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return open; }); }
 };
 
+constexpr int kJ2kMainHeaderBytes = 135;     // SOC, SIZ, COD, QCD, COM of every codestream the codec writes
+
 struct ProbeRec { float cr = -1; unsigned long long nbad = 0; int stream_bytes = 0; double err_sum = 0; };
 
 struct Job {                     // host-side state of one frame being encoded
@@ -264,49 +268,117 @@ hipStream_t second_stream(ebcc_hip_ctx *c)
     return c->stream2;
 }
 
+// The base layer of a batch of chunks.  A chunk is one frame, or `tiles` frames stacked along the row axis that
+// the reference codes as ONE JPEG 2000 image with one tile per frame (src/ebcc_codec.c:105-180, n_tiles > 1).
+// Every tile is a frame of the engine `ctx` (tile t of chunk c at index c * tiles + t); the arrays below are per
+// CHUNK - rate, target, error statistics, codestream size - and are expanded to / gathered from the tiles here:
+//   * all tiles of a chunk are probed at the same rate; a tile's byte budget subtracts its share of the main
+//     header only (opj_j2k_update_rates: 135 / tiles, J2kFrame::hdr_share);
+//   * nbad / err_sum add up; the codestream is main header (SIZ rewritten for the stacked image) + the tile-parts
+//     (SOT with the tile index) + EOC, byte-identical to OpenJPEG's opj_write_tile sequence.
+// The residual layer works on whole chunks in the engine `rc` (== ctx for one-frame chunks).
 struct Batch {
     ebcc_hip_ctx *ctx;
     J2kBuffers &jb;
     const float *d_frames;
-    size_t n;
-    std::vector<J2kFrame> jf;
-    std::vector<int> active;       // host copy of this probe set's active mask
-    std::vector<float> state_cr;   // rate of the decode this set holds for every frame (-1: none)
-    int *d_active;
+    size_t n, tiles, nt;           // chunks, tiles per chunk, n * tiles
+    std::vector<J2kFrame> jf;      // per chunk
+    std::vector<J2kFrame> tjf;     // per tile (device image)
+    std::vector<int> active;       // per chunk
+    std::vector<int> tactive;
+    std::vector<float> state_cr;   // rate of the decode the engine holds for every chunk (-1: none)
+    int *d_active;                 // per tile, on ctx
     hipStream_t s;
-    Batch(ebcc_hip_ctx *c, const float *d, size_t n_)
-        : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), jf(n_), active(n_, 0), state_cr(n_, -1.f),
-          d_active(c->d_active), s(c->stream) {}
+    ebcc_hip_ctx *rc;              // residual engine (chunk-sized frames)
+    hipStream_t rs;
+    Batch(ebcc_hip_ctx *c, const float *d, size_t n_, size_t tiles_ = 1, ebcc_hip_ctx *rc_ = nullptr)
+        : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), tiles(tiles_), nt(n_ * tiles_), jf(n_), tjf(n_ * tiles_),
+          active(n_, 0), tactive(n_ * tiles_, 0), state_cr(n_, -1.f), d_active(c->d_active), s(c->stream), rc(rc_ ? rc_ : c),
+          rs((rc_ ? rc_ : c)->stream) {}
     void fetch_jf()
     {
-        EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(tjf.data(), jb.jf, sizeof(J2kFrame) * nt, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t c = 0; c < n; c++) {
+            J2kFrame &o = jf[c];
+            o.nbad = 0; o.err_sum = 0; o.overflow = 0; o.body_bytes = 0;
+            for (size_t t = c * tiles; t < (c + 1) * tiles; t++) {
+                o.nbad += tjf[t].nbad; o.err_sum += tjf[t].err_sum; o.overflow |= tjf[t].overflow; o.body_bytes += tjf[t].body_bytes;
+            }
+            o.stream_bytes = kJ2kMainHeaderBytes + (int) tiles * 14 + o.body_bytes + 2;     // main header, SOT + SOD per tile, EOC
+        }
     }
-    void push_jf() { EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n, hipMemcpyHostToDevice, s)); }
-    void push_active() { EBCC_HIP_CHECK(hipMemcpyAsync(d_active, active.data(), sizeof(int) * n, hipMemcpyHostToDevice, s)); }
-    // one probe of the base layer for the active frames: rate allocation at jf[f].cr (+ decode and statistics)
+    void push_jf()
+    {
+        for (size_t c = 0; c < n; c++)
+            for (size_t t = c * tiles; t < (c + 1) * tiles; t++) {
+                tjf[t].cr = jf[c].cr; tjf[t].target = jf[c].target;
+                tjf[t].hdr_share = tiles > 1 ? (float) kJ2kMainHeaderBytes / (float) tiles : 0.0f;
+            }
+        EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, tjf.data(), sizeof(J2kFrame) * nt, hipMemcpyHostToDevice, s));
+    }
+    void push_active()
+    {
+        for (size_t c = 0; c < n; c++)
+            for (size_t t = c * tiles; t < (c + 1) * tiles; t++) tactive[t] = active[c];
+        EBCC_HIP_CHECK(hipMemcpyAsync(d_active, tactive.data(), sizeof(int) * nt, hipMemcpyHostToDevice, s));
+    }
+    // the chunk mask for the residual engine's kernels
+    void push_ractive() { EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_active, active.data(), sizeof(int) * n, hipMemcpyHostToDevice, rs)); }
+    // one probe of the base layer for the active chunks: rate allocation at jf[c].cr (+ decode and statistics)
     void launch_probe(bool decode)
     {
         push_jf();
         push_active();
-        launch_j2k_rate(jb, (int) n, d_active, s);
-        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) n, d_active, s);
+        launch_j2k_rate(jb, (int) nt, d_active, s);
+        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) nt, d_active, s);
     }
     void probe(bool decode) { launch_probe(decode); fetch_jf(); }
-    // codestream of the current layer assignment of the active frames -> jobs[f].tail
+    // codestream of the current layer assignment of the active chunks -> jobs[c].tail
     template <class Jobs>
     void collect_tails(Jobs &jobs)
     {
         push_active();
-        launch_j2k_write(jb, (int) n, d_active, s);
+        launch_j2k_write(jb, (int) nt, d_active, s);
         fetch_jf();
-        for (size_t f = 0; f < n; f++)
-            if (active[f]) {
-                jobs[f].tail.resize((size_t) jf[f].stream_bytes);
-                EBCC_HIP_CHECK(hipMemcpyAsync(jobs[f].tail.data(), jb.stream + f * jb.stream_cap, jobs[f].tail.size(),
-                                              hipMemcpyDeviceToHost, s));
+        if (tiles == 1) {
+            for (size_t f = 0; f < n; f++)
+                if (active[f]) {
+                    jobs[f].tail.resize((size_t) jf[f].stream_bytes);
+                    EBCC_HIP_CHECK(hipMemcpyAsync(jobs[f].tail.data(), jb.stream + f * jb.stream_cap, jobs[f].tail.size(),
+                                                  hipMemcpyDeviceToHost, s));
+                }
+            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+            return;
+        }
+        // every tile was written as a one-tile codestream into its slot: [main header 135][SOT 12][SOD 2][packets][EOC 2]
+        for (size_t c = 0; c < n; c++) {
+            if (!active[c]) continue;
+            std::vector<uint8_t> &o = jobs[c].tail;
+            o.resize((size_t) jf[c].stream_bytes);
+            size_t at = kJ2kMainHeaderBytes;
+            for (size_t k = 0; k < tiles; k++) {
+                const size_t t = c * tiles + k, part = 14 + (size_t) tjf[t].body_bytes;
+                const uint8_t *slot = jb.stream + t * jb.stream_cap;
+                if (k == 0) EBCC_HIP_CHECK(hipMemcpyAsync(o.data(), slot, kJ2kMainHeaderBytes, hipMemcpyDeviceToHost, s));
+                EBCC_HIP_CHECK(hipMemcpyAsync(o.data() + at, slot + kJ2kMainHeaderBytes, part, hipMemcpyDeviceToHost, s));
+                at += part;
             }
+        }
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        const unsigned H = (unsigned) jb.geom.H;
+        for (size_t c = 0; c < n; c++) {
+            if (!active[c]) continue;
+            std::vector<uint8_t> &o = jobs[c].tail;
+            auto put32 = [&](size_t at, unsigned v) { o[at] = (uint8_t) (v >> 24); o[at + 1] = (uint8_t) (v >> 16); o[at + 2] = (uint8_t) (v >> 8); o[at + 3] = (uint8_t) v; };
+            put32(12, H * (unsigned) tiles);                             // SIZ: Ysiz (tile size XTsiz/YTsiz stays W x H)
+            size_t at = kJ2kMainHeaderBytes;
+            for (size_t k = 0; k < tiles; k++) {
+                o[at + 4] = (uint8_t) (k >> 8); o[at + 5] = (uint8_t) k;  // SOT: Isot
+                at += 14 + (size_t) tjf[c * tiles + k].body_bytes;
+            }
+            o[at] = 0xFF; o[at + 1] = 0xD9;                               // EOC
+        }
     }
 };
 
@@ -381,40 +453,67 @@ void run_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
 // ------------------------------------------------------------------------------------------------
 // ebcc_encode for a batch of device-resident single-frame chunks.  Returns 0, 1 (error) or 2 (NaN/Inf).
 // ------------------------------------------------------------------------------------------------
+// `n` chunks of `tiles` frames each (tiles == 1: the frame-per-chunk case); `rctx`: residual engine for the stacked
+// chunk image when tiles > 1.
 int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
-                 SliceGate *next = nullptr)
+                 SliceGate *next = nullptr, size_t tiles = 1, ebcc_hip_ctx *rctx = nullptr)
 {
     struct Release { SliceGate *g; ~Release() { if (g) g->release(); } } release_on_exit{next};   // (error paths too)
     const EncodeEnv env;
     const double q_target = 1 - env.base_error_quantile;
     const int mode = (int) cfg->residual_compression_type;
     const bool searching = mode == MAX_ERROR || mode == RELATIVE_ERROR;
-    const size_t n_pix = ctx->n_pix;
-    Batch b(ctx, d_frames, n);
+    const size_t n_pix = ctx->n_pix * tiles;                           // pixels of a chunk
+    const size_t nt = n * tiles;
+    Batch b(ctx, d_frames, n, tiles, rctx);
     J2kBuffers &jb = b.jb;
     hipStream_t s = b.s;
+    ebcc_hip_ctx *rc = b.rc;                                           // residual engine and its stream (== ctx, s for one-frame chunks)
+    hipStream_t rs = b.rs;
     std::vector<Job> jobs(n);
     PhaseTimer pt;
 
     // ---- statistics, scaling, transform, tier-1: once per frame
-    launch_input_stats(d_frames, (int) n, n_pix, ctx->rb.fs, s);
-    launch_j2k_analysis(d_frames, jb, (int) n, s);
+    launch_input_stats(d_frames, (int) nt, ctx->n_pix, ctx->rb.fs, s);
+    if (tiles > 1) {
+        // the reference scales the whole chunk with one (min, max) (:686-689): combine the tiles' statistics before
+        // the transform reads them; a tile that happens to be constant inside a varying chunk is coded normally
+        fetch_frame_states(ctx, nt);
+        for (size_t c = 0; c < n; c++) {
+            FrameState *t0 = ctx->h_fs + c * tiles;
+            float mn = t0[0].minv, mx = t0[0].maxv;
+            int bad = 0;
+            for (size_t k = 0; k < tiles; k++) { mn = std::min(mn, t0[k].minv); mx = std::max(mx, t0[k].maxv); bad |= t0[k].has_nonfinite; }
+            for (size_t k = 0; k < tiles; k++) { t0[k].minv = mn; t0[k].maxv = mx; t0[k].has_nonfinite = bad; t0[k].const_field = mn == mx; }
+        }
+        push_frame_states(ctx, nt);
+    }
+    launch_j2k_analysis(d_frames, jb, (int) nt, s);
     if (next) {                                   // the next slice may start: this one's first stage is queued
         const char *e = getenv("EBCC_HIP_SLICE_GATE");
         if (e && atoi(e) == 1) { EBCC_HIP_CHECK(hipStreamSynchronize(s)); }
         next->release(); release_on_exit.g = nullptr;
     }
-    fetch_frame_states(ctx, n);
+    fetch_frame_states(ctx, nt);
     b.fetch_jf();
     for (size_t f = 0; f < n; f++) {
-        if (ctx->h_fs[f].has_nonfinite) { log_fatal("NaN or Inf found in data of frame %zu", f); return 2; }
+        const FrameState &t0 = ctx->h_fs[f * tiles];                   // (all tiles of a chunk carry the chunk's statistics)
+        if (t0.has_nonfinite) { log_fatal("NaN or Inf found in data of frame %zu", f); return 2; }
         if (b.jf[f].overflow) { log_fatal("code-block byte slot overflow in frame %zu", f); return 1; }
-        jobs[f].const_field = ctx->h_fs[f].const_field != 0;
-        jobs[f].minv = ctx->h_fs[f].minv;
-        jobs[f].maxv = ctx->h_fs[f].maxv;
+        jobs[f].const_field = t0.const_field != 0;
+        jobs[f].minv = t0.minv;
+        jobs[f].maxv = t0.maxv;
         b.jf[f].cr = cfg->base_cr;
         b.jf[f].target = 0;
         b.active[f] = jobs[f].const_field ? 0 : 1;
+    }
+    if (rc != ctx) {                                                   // chunk-level frame states of the residual engine
+        for (size_t f = 0; f < n; f++) {
+            FrameState &r = rc->h_fs[f];
+            r = FrameState{};
+            r.minv = jobs[f].minv; r.maxv = jobs[f].maxv; r.const_field = jobs[f].const_field;
+        }
+        push_frame_states(rc, n);
     }
     pt.mark("analysis (dwt, tier-1, ckpt)");
     const bool need_decode = mode != NONE;
@@ -439,9 +538,9 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             b.state_cr[f] = b.jf[f].cr;
         }
         // residual range of the first decode: only the header fields survive when no search runs (:716)
-        launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, ctx->rb.fs, s);
-        fetch_frame_states(ctx, n);
-        for (size_t f = 0; f < n; f++) { jobs[f].rmin = ctx->h_fs[f].rmin; jobs[f].rmax = ctx->h_fs[f].rmax; }
+        launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);
+        fetch_frame_states(rc, n);
+        for (size_t f = 0; f < n; f++) { jobs[f].rmin = rc->h_fs[f].rmin; jobs[f].rmax = rc->h_fs[f].rmax; }
         if (!searching) {                       // stale enum values fall through to a base-only stream (quirk Q2)
             for (size_t f = 0; f < n; f++) b.active[f] = jobs[f].const_field ? 0 : 1;
             b.collect_tails(jobs);
@@ -462,14 +561,14 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         }
         pt.mark("rate search 1");
         b.collect_tails(jobs);                                                                // base layer of search #1
-        launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, ctx->rb.fs, s);               // :730-733
-        fetch_frame_states(ctx, n);
+        launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
+        fetch_frame_states(rc, n);
         bool any_resid = false;
         for (size_t f = 0; f < n; f++) {
             Job &j = jobs[f];
             b.active[f] = 0;
             if (j.const_field) continue;
-            j.rmin = ctx->h_fs[f].rmin; j.rmax = ctx->h_fs[f].rmax;
+            j.rmin = rc->h_fs[f].rmin; j.rmax = rc->h_fs[f].rmax;
             float cur = fmaxf(fabsf(j.rmin), fabsf(j.rmax));                                  // :735
             j.skip = cur <= j.target;                                                         // :737
             if (!j.skip) { b.active[f] = 1; any_resid = true; }
@@ -478,45 +577,45 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
 
         if (any_resid) {
             // ---- residual layer: SPIHT with a budget of the base layer's size (:744-754)
-            b.push_active();
-            launch_pad_and_dc(d_frames, jb.DEC, ctx->rb, (int) n, b.d_active, s);
-            launch_analysis(ctx->rb, (int) n, b.d_active, s);
-            fetch_frame_states(ctx, n);
+            b.push_ractive();
+            launch_pad_and_dc(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+            launch_analysis(rc->rb, (int) n, rc->d_active, rs);
+            fetch_frame_states(rc, n);
             for (size_t f = 0; f < n; f++) {
                 unsigned long long bits0 = (unsigned long long) jobs[f].len1 * 8 + 128;       // trunc_bits + 128
-                ctx->h_u64a[f] = bits0;
-                ctx->h_fs[f].budget = bits0 - 128;
+                rc->h_u64a[f] = bits0;
+                rc->h_fs[f].budget = bits0 - 128;
             }
-            push_frame_states(ctx, n);
-            EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-            launch_spiht_encode(ctx->rb, (int) n, ctx->d_u64a, b.d_active, s);
-            fetch_frame_states(ctx, n);
+            push_frame_states(rc, n);
+            EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64a, rc->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
+            launch_spiht_encode(rc->rb, (int) n, rc->d_u64a, rc->d_active, rs);
+            fetch_frame_states(rc, n);
             for (size_t f = 0; f < n; f++) {
                 if (!b.active[f]) continue;
-                jobs[f].coeffs_orig = ctx->h_fs[f].stream_bytes;
+                jobs[f].coeffs_orig = rc->h_fs[f].stream_bytes;
                 jobs[f].coeffs_size = jobs[f].coeffs_orig;
-                ctx->h_u64b[f] = (unsigned long long) jobs[f].coeffs_orig * 8;                // full decode, :749
-                ctx->h_fs[f].dec_dc = (int) ctx->h_fs[f].dc;
+                rc->h_u64b[f] = (unsigned long long) jobs[f].coeffs_orig * 8;                // full decode, :749
+                rc->h_fs[f].dec_dc = (int) rc->h_fs[f].dc;
             }
             auto probe_residual = [&]() {
-                EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-                b.push_active();
-                launch_reconstruct(ctx->rb, (int) n, ctx->d_u64b, b.d_active, s);
-                launch_synthesis(ctx->rb, (int) n, b.d_active, s);
-                launch_probe_stats(d_frames, jb.DEC, ctx->rb, (int) n, b.d_active, s);
-                fetch_frame_states(ctx, n);
+                EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64b, rc->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
+                b.push_ractive();
+                launch_reconstruct(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
+                launch_synthesis(rc->rb, (int) n, rc->d_active, rs);
+                launch_probe_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+                fetch_frame_states(rc, n);
             };
             probe_residual();
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
                 if (!b.active[f]) continue;
-                float cur = u2f(ctx->h_fs[f].maxerr_bits);                                    // :754
+                float cur = u2f(rc->h_fs[f].maxerr_bits);                                    // :754
                 if (cur > j.target) {                                                         // :755-759
                     log_info("frame %zu: could not reach error target %f (%f instead); retry with pure base compression", f, j.target, cur);
                     j.skip = true; j.need_pure = true;
                 } else {
                     j.best_err = cur;
-                    j.mean_err = ctx->h_fs[f].err_sum / (double) n_pix;                       // :762
+                    j.mean_err = rc->h_fs[f].err_sum / (double) n_pix;                       // :762
                     j.t_hi = (double) j.coeffs_size * 8; j.t_lo = 112.0; j.t_best = j.t_hi;   // :766-776
                     j.trunc_active = true;
                 }
@@ -531,7 +630,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                     if (!j.trunc_active) continue;
                     if (((j.target - j.best_err) / j.target > eps) && (j.t_hi - j.t_lo > 8 * 4)) {
                         size_t tb = ((size_t) ceill((long double) ((j.t_hi + j.t_lo) / 2 / 8))) * 8;
-                        ctx->h_u64b[f] = tb;
+                        rc->h_u64b[f] = tb;
                         b.active[f] = 1;
                         any = true;
                     } else {
@@ -543,12 +642,12 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 for (size_t f = 0; f < n; f++) {
                     Job &j = jobs[f];
                     if (!b.active[f]) continue;
-                    const double tb = (double) ctx->h_u64b[f];
-                    float cur = u2f(ctx->h_fs[f].maxerr_bits);
+                    const double tb = (double) rc->h_u64b[f];
+                    float cur = u2f(rc->h_fs[f].maxerr_bits);
                     if (cur > j.target) j.t_lo = tb;
                     else {
                         j.t_hi = tb;
-                        if (cur >= j.best_err) { j.best_err = cur; j.t_best = tb; j.mean_err = ctx->h_fs[f].err_sum / (double) n_pix; }
+                        if (cur >= j.best_err) { j.best_err = cur; j.t_best = tb; j.mean_err = rc->h_fs[f].err_sum / (double) n_pix; }
                     }
                     log_trace("frame %zu: trunc_lo %.1f trunc_hi %.1f max error %f", f, j.t_lo, j.t_hi, cur);
                 }
@@ -570,11 +669,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             if (j.coeffs_size <= 16) j.coeffs_size = 0;
             if (j.coeffs_size > 0) {
                 coeff_bytes[f].resize(j.coeffs_size);
-                EBCC_HIP_CHECK(hipMemcpyAsync(coeff_bytes[f].data(), ctx->rb.stream + f * ctx->rb.stream_words, j.coeffs_size,
-                                              hipMemcpyDeviceToHost, s));
+                EBCC_HIP_CHECK(hipMemcpyAsync(coeff_bytes[f].data(), rc->rb.stream + f * rc->rb.stream_words, j.coeffs_size,
+                                              hipMemcpyDeviceToHost, rs));
             }
         }
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(rs));
         std::atomic<size_t> next_frame{0};
         auto zworker = [&]() {
             for (size_t f = next_frame++; f < n; f = next_frame++) {
@@ -625,7 +724,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 // the layer assignment of that rate again (allocation only, no decode), then its codestream
                 b.push_jf();
                 b.push_active();
-                launch_j2k_rate(jb, (int) n, b.d_active, s);
+                launch_j2k_rate(jb, (int) nt, b.d_active, s);
                 b.collect_tails(jobs);
             }
         }
@@ -813,23 +912,125 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     return 0;
 }
 
+// Chunks of several frames: the tail is one codestream with a tile per frame (reference :121-125); the tiles are
+// decoded as frames of `ctx`, the residual of the whole chunk image in `rc`.  Tile heights for which every tile has
+// the geometry of a tile at the origin only (see tile_height_supported).
+bool tile_height_supported(size_t h) { return h >= 32 && h <= 1024 && (h & (h - 1)) == 0; }
+
+int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *streams, const size_t *sizes, size_t n, size_t tiles,
+                 float *d_out)
+{
+    J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
+    hipStream_t s = ctx->stream, rs = rc->stream;
+    const J2kGeom &g = jb.geom;
+    const size_t tile_pix = ctx->n_pix, n_pix = tile_pix * tiles, nt = n * tiles;
+    std::vector<int> table(nt * (size_t) g.nblocks * 4, 0);
+    std::vector<std::vector<uint8_t>> coeffs(n);
+    std::vector<size_t> off(tiles), len(tiles);
+    bool any_resid = false;
+    for (size_t c = 0; c < n; c++) {
+        ParsedFrame hd;
+        if (!parse_frame(streams[c], sizes[c], hd)) return 1;
+        rc->h_active[c] = 0;
+        FrameState &r = rc->h_fs[c];
+        r = FrameState{};
+        r.minv = hd.minv; r.maxv = hd.maxv; r.rmin = hd.rmin; r.rmax = hd.rmax; r.const_field = hd.const_field ? 1 : 0;
+        for (size_t k = 0; k < tiles; k++) {
+            FrameState &t = ctx->h_fs[c * tiles + k];
+            t = FrameState{};
+            t.minv = hd.minv; t.maxv = hd.maxv; t.const_field = r.const_field;
+        }
+        if (hd.const_field) {
+            uint64_t cnt = 0;
+            memcpy(&cnt, hd.tail, 8);
+            if (cnt != n_pix) { log_fatal("const-field length %llu does not match the chunk", (unsigned long long) cnt); return 1; }
+            continue;
+        }
+        if (!j2k_parse_tiled(hd.tail, hd.tail_size, g, (int) tiles, table.data() + c * tiles * g.nblocks * 4, off.data(), len.data())) {
+            log_fatal("Invalid encoded data: %s", ebcc_hip_last_error());
+            return 1;
+        }
+        for (size_t k = 0; k < tiles; k++) {
+            if (len[k] > jb.stream_cap) { log_fatal("tile-part larger than the device slot"); return 1; }
+            EBCC_HIP_CHECK(hipMemcpyAsync(jb.stream + (c * tiles + k) * jb.stream_cap, hd.tail + off[k], len[k], hipMemcpyHostToDevice, s));
+        }
+        if (hd.compressed_size > 0 && hd.coeffs_size > 0) {
+            if (hd.coeffs_size > rc->rb.stream_words * 4 - 64) { log_fatal("residual stream larger than the device slot"); return 1; }
+            coeffs[c].assign(hd.coeffs_size, 0);
+            zstd().decompress(coeffs[c].data(), hd.coeffs_size, hd.z, hd.compressed_size);
+            rc->h_active[c] = 1;
+            any_resid = true;
+        }
+    }
+    push_frame_states(ctx, nt);
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_j2k_decode(jb, (int) nt, s);
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    if (any_resid) {
+        push_frame_states(rc, n);
+        const size_t slot = rc->rb.stream_words * 4;
+        for (size_t c = 0; c < n; c++) {
+            rc->h_u64a[c] = coeffs[c].size();
+            rc->h_u64b[c] = coeffs[c].size() * 8;
+            if (rc->h_active[c])
+                EBCC_HIP_CHECK(hipMemcpyAsync((uint8_t *) rc->rb.stream + c * slot, coeffs[c].data(), coeffs[c].size(), hipMemcpyHostToDevice, rs));
+        }
+        EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64a, rc->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
+        EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64b, rc->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
+        EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_active, rc->h_active, n * sizeof(int), hipMemcpyHostToDevice, rs));
+        launch_spiht_decode((const uint8_t *) rc->rb.stream, slot, rc->d_u64a, rc->d_u64b, rc->rb, (int) n, rc->d_active, rs);
+        launch_synthesis(rc->rb, (int) n, rc->d_active, rs);
+        launch_add_residual(jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+        EBCC_HIP_CHECK(hipStreamSynchronize(rs));
+    }
+    EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (size_t c = 0; c < n; c++)
+        if (rc->h_fs[c].const_field) {
+            std::vector<float> v(n_pix, rc->h_fs[c].minv);
+            EBCC_HIP_CHECK(hipMemcpyAsync(d_out + c * n_pix, v.data(), n_pix * sizeof(float), hipMemcpyHostToDevice, s));
+            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// the engine of the tiles and, for chunks of several frames, the engine of the stacked chunk image
+bool chunk_engines(int H, int W, size_t chunks, size_t tiles, ebcc_hip_ctx **ctx, ebcc_hip_ctx **rc)
+{
+    *rc = nullptr;
+    if (tiles > 1) {
+        *rc = get_context((int) (tiles * (size_t) H), W, chunks);
+        if (!*rc) return false;
+    }
+    *ctx = get_context(H, W, chunks * tiles);
+    if (!*ctx) return false;
+    if (tiles > 1) {                                             // (creating the second engine may have evicted the first)
+        *rc = get_context((int) (tiles * (size_t) H), W, chunks);
+        if (!*rc) return false;
+        if (g_ctx.find(std::make_pair(H, W)) == g_ctx.end()) return false;
+    }
+    return true;
+}
+
 // host-pointer convenience used by the reference-compatible entry points
-size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
+// n chunks of `tiles` frames of H x W each, contiguous in host memory
+size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
+                          size_t tiles = 1)
 {
     std::lock_guard<std::mutex> lock(g_mutex);
-    const size_t cap = std::min(n, batch_capacity((size_t) H * W));
-    ebcc_hip_ctx *ctx = get_context(H, W, cap);
-    if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
-    const size_t n_pix = (size_t) H * W;
+    const size_t n_pix = (size_t) H * W * tiles;
+    const size_t cap = std::min(n, batch_capacity(n_pix));
+    ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+    if (!chunk_engines(H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
     float *d = nullptr;
     EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * n_pix * sizeof(float)));
     size_t done = 0;
     while (done < n) {
         size_t k = std::min(cap, n - done);
         EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
-        int rc = encode_batch(ctx, d, k, cfg, outs + done, sizes + done);
-        if (rc == 2) { hipFree(d); exit(1); }                                                  // check_nan_inf, :598-605
-        if (rc) { hipFree(d); return 0; }
+        int rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
+        if (rcode == 2) { hipFree(d); exit(1); }                                               // check_nan_inf, :598-605
+        if (rcode) { hipFree(d); return 0; }
         done += k;
     }
     hipFree(d);
@@ -838,9 +1039,6 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
 
 }  // namespace
 
-// ================================================================================================
-// C API
-// ================================================================================================
 // Slices of a batch: EBCC_HIP_SLICES (encode, default 2, 1 = off) / EBCC_HIP_DECODE_SLICES (default 1) engines of max_frames / slices frames each, created on
 // first use.  Small batches stay on the context's own engine.  More than two slices only pay when the HIP
 // runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the application's streams):
@@ -951,27 +1149,18 @@ size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
         return 0;
     }
     print_config(config);
-    if (config->dims[0] != 1) {
-        // the reference codes such a chunk as one tiled JPEG 2000 image (src/ebcc_codec.c:121-125,167-171)
-        log_fatal("chunks holding %lu frames (tiled JPEG 2000) are not supported by the MI355X build yet; use one frame per chunk",
-                  config->dims[0]);
+    if (config->dims[0] != 1 && !tile_height_supported(config->dims[1])) {
+        // the reference codes such a chunk as one tiled JPEG 2000 image (src/ebcc_codec.c:121-125,167-171); a tile away
+        // from the origin has its own sub-band and code-block geometry unless the tile height is a power of two
+        log_fatal("chunks holding %lu frames of %lu rows are not supported by the MI355X build yet (multi-frame chunks need a "
+                  "power-of-two frame height between 32 and 1024); use one frame per chunk", config->dims[0], config->dims[1]);
         return 0;
     }
     size_t size = 0;
     uint8_t *o = nullptr;
-    if (encode_host_frames(data, 1, (int) config->dims[1], (int) config->dims[2], config, &o, &size) != 1) return 0;
+    if (encode_host_frames(data, 1, (int) config->dims[1], (int) config->dims[2], config, &o, &size, config->dims[0]) != 1) return 0;
     *out_buffer = o;
     return size;
-}
-
-static int peek_j2k_dims(const uint8_t *d, size_t n, int *H, int *W)
-{
-    // SIZ follows SOC immediately in every stream the codec writes (T.800 A.5.1)
-    if (n < 2 + 4 + 38 || d[0] != 0xFF || d[1] != 0x4F || d[2] != 0xFF || d[3] != 0x51) return 0;
-    auto be32 = [](const uint8_t *p) { return ((unsigned) p[0] << 24) | ((unsigned) p[1] << 16) | ((unsigned) p[2] << 8) | p[3]; };
-    *W = (int) (be32(d + 8) - be32(d + 16));
-    *H = (int) (be32(d + 12) - be32(d + 20));
-    return 1;
 }
 
 size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
@@ -988,20 +1177,25 @@ size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
         *out_buffer = o;
         return (size_t) cnt;
     }
-    int H = 0, W = 0;
-    if (!peek_j2k_dims(tail, hd.tail_size, &H, &W) || H < 1 || W < 1 || H > 2047 || W > 2047) {
-        log_fatal("Invalid encoded data: no JPEG 2000 codestream in the tail");
+    int H = 0, W = 0, tw = 0, th = 0;
+    if (!j2k_peek_dims(tail, hd.tail_size, &W, &H, &tw, &th) || H < 1 || W < 1 || H > 2047 || W > 2047 || th < 1 || tw != W || H % th != 0) {
+        log_fatal("Invalid encoded data: no usable JPEG 2000 codestream in the tail");
+        return 0;
+    }
+    const size_t tiles = (size_t) (H / th);
+    if (tiles > 1 && !tile_height_supported((size_t) th)) {
+        log_fatal("streams with %zu tiles of %d rows are not supported by the MI355X build yet", tiles, th);
         return 0;
     }
     std::lock_guard<std::mutex> lock(g_mutex);
-    ebcc_hip_ctx *ctx = get_context(H, W, 1);
-    if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+    ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+    if (!chunk_engines(th, W, 1, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
     const size_t n_pix = (size_t) H * W;
     float *d = nullptr;
     EBCC_HIP_CHECK(hipMalloc((void **) &d, n_pix * sizeof(float)));
     const uint8_t *sp = data;
-    int rc = decode_batch(ctx, &sp, &data_size, 1, d);
-    if (rc) { hipFree(d); return 0; }
+    int rcode = tiles > 1 ? decode_tiled(ctx, rc, &sp, &data_size, 1, tiles, d) : decode_batch(ctx, &sp, &data_size, 1, d);
+    if (rcode) { hipFree(d); return 0; }
     // :1126-1128: honour a caller-provided buffer
     float *o = *out_buffer ? *out_buffer : (float *) malloc(n_pix * sizeof(float));
     EBCC_HIP_CHECK(hipMemcpy(o, d, n_pix * sizeof(float), hipMemcpyDeviceToHost));
@@ -1030,8 +1224,9 @@ size_t ebcc_encode_chunking(float *data, codec_config_t *config, uint8_t **out_b
         if (config->dims[i] == 0 || cd[i] == 0) { log_fatal("Invalid chunking dimensions: dims and chunk_dims must be non-zero"); return 0; }
         cnt[i] = cdiv(config->dims[i], cd[i]);
     }
-    if (cd[0] != 1) {
-        log_fatal("chunks holding %lu frames (tiled JPEG 2000) are not supported by the MI355X build yet; use chunk_dims[0] = 1", cd[0]);
+    if (cd[0] != 1 && !tile_height_supported(cd[1])) {
+        log_fatal("chunks holding %lu frames of %lu rows are not supported by the MI355X build yet (multi-frame chunks need a "
+                  "power-of-two frame height between 32 and 1024); use chunk_dims[0] = 1", cd[0], cd[1]);
         return 0;
     }
     const size_t csize = cd[0] * cd[1] * cd[2], nchunks = cnt[0] * cnt[1] * cnt[2];
@@ -1060,7 +1255,7 @@ size_t ebcc_encode_chunking(float *data, codec_config_t *config, uint8_t **out_b
     for (int i = 0; i < 3; i++) { cc.dims[i] = cd[i]; cc.chunk_dims[i] = 0; }
     std::vector<uint8_t *> outs(nchunks, nullptr);
     std::vector<size_t> sizes(nchunks, 0);
-    if (encode_host_frames(gathered.data(), nchunks, (int) cd[1], (int) cd[2], &cc, outs.data(), sizes.data()) != nchunks) {
+    if (encode_host_frames(gathered.data(), nchunks, (int) cd[1], (int) cd[2], &cc, outs.data(), sizes.data(), cd[0]) != nchunks) {
         for (auto p : outs) free(p);
         return 0;
     }
@@ -1128,7 +1323,10 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     }
     const size_t csize = cd[0] * cd[1] * cd[2], nchunks = cnt[0] * cnt[1] * cnt[2], total = dims[0] * dims[1] * dims[2];
     if (hd.chunk_size != csize || hd.num_chunks != nchunks) { log_fatal("Invalid chunked EBCC data: inconsistent chunk metadata"); return 0; }
-    if (cd[0] != 1) { log_fatal("chunks holding %lu frames are not supported by the MI355X build yet", cd[0]); return 0; }
+    if (cd[0] != 1 && !tile_height_supported(cd[1])) {
+        log_fatal("chunks holding %lu frames of %lu rows are not supported by the MI355X build yet", cd[0], cd[1]);
+        return 0;
+    }
     std::vector<const uint8_t *> ptrs(nchunks);
     std::vector<size_t> lens(nchunks);
     const uint8_t *p = data + sizeof hd, *end = data + data_size;
@@ -1144,14 +1342,17 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     std::vector<float> chunks(nchunks * csize);
     {
         std::lock_guard<std::mutex> lock(g_mutex);
-        const size_t cap = std::min(nchunks, batch_capacity((size_t) H * W));
-        ebcc_hip_ctx *ctx = get_context(H, W, cap);
-        if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+        const size_t tiles = cd[0];
+        const size_t cap = std::min(nchunks, batch_capacity(csize));
+        ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+        if (!chunk_engines(H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
         float *d = nullptr;
         EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * csize * sizeof(float)));
         for (size_t done = 0; done < nchunks;) {
             size_t k = std::min(cap, nchunks - done);
-            if (decode_batch(ctx, ptrs.data() + done, lens.data() + done, k, d)) { hipFree(d); return 0; }
+            const int rcode = tiles > 1 ? decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d)
+                                        : decode_batch(ctx, ptrs.data() + done, lens.data() + done, k, d);
+            if (rcode) { hipFree(d); return 0; }
             EBCC_HIP_CHECK(hipMemcpy(chunks.data() + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
             done += k;
         }

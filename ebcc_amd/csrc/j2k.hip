@@ -138,43 +138,64 @@ int flog2(int a) { int l = 0; while (a > 1) { a >>= 1; l++; } return l; }
 }  // namespace
 
 // returns false on a malformed / unsupported codestream
-bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table /* [nblocks][4] */)
+namespace {
+
+struct MainHeader {
+    int W = 0, H = 0, tile_w = 0, tile_h = 0, nres = 0, qsty = -1, guard = 0;
+    int expn[kJ2kBands] = {0}, mant[kJ2kBands] = {0};
+    size_t first_sot = 0;          // position of the first SOT marker
+};
+
+// main header up to the first tile-part (A.5, A.6)
+bool parse_main_header(const uint8_t *cs, size_t n, MainHeader &h)
 {
     if (n < 4 || be16(cs) != 0xFF4F) { set_error("J2K: missing SOC"); return false; }
     size_t pos = 2;
-    int W = 0, H = 0, nres = 0, qsty = -1, guard = 0;
-    int expn[kJ2kBands] = {0}, mant[kJ2kBands] = {0};
-    const uint8_t *tile_data = nullptr, *tile_end = nullptr;
     while (pos + 4 <= n) {
-        unsigned mk = be16(cs + pos), len = be16(cs + pos + 2);
+        const unsigned mk = be16(cs + pos), len = be16(cs + pos + 2);
         const uint8_t *p = cs + pos + 4;
+        if (mk == 0xFF90) { h.first_sot = pos; return true; }
         if (pos + 2 + len > n) { set_error("J2K: truncated marker segment"); return false; }
-        if (mk == 0xFF51) { W = (int) (be32(p + 2) - be32(p + 10)); H = (int) (be32(p + 6) - be32(p + 14)); }
-        else if (mk == 0xFF52) nres = p[5] + 1;
+        if (mk == 0xFF51) {
+            h.W = (int) (be32(p + 2) - be32(p + 10)); h.H = (int) (be32(p + 6) - be32(p + 14));
+            h.tile_w = (int) be32(p + 18); h.tile_h = (int) be32(p + 22);
+        } else if (mk == 0xFF52) h.nres = p[5] + 1;
         else if (mk == 0xFF5C) {
-            qsty = p[0] & 0x1F; guard = p[0] >> 5;
-            int nb = (int) (len - 3) / 2;
-            for (int i = 0; i < nb && i < kJ2kBands; i++) { unsigned v = be16(p + 1 + 2 * i); expn[i] = (int) (v >> 11); mant[i] = (int) (v & 0x7FF); }
-        } else if (mk == 0xFF90) {
-            unsigned psot = be32(p + 2);
-            const uint8_t *sot = cs + pos;
-            pos += 2 + len;
-            if (pos + 2 > n || be16(cs + pos) != 0xFF93) { set_error("J2K: missing SOD"); return false; }
-            tile_data = cs + pos + 2;
-            tile_end = psot ? sot + psot : cs + n - 2;
-            if (tile_end > cs + n) { set_error("J2K: tile-part overruns the stream"); return false; }
-            break;
+            h.qsty = p[0] & 0x1F; h.guard = p[0] >> 5;
+            const int nb = (int) (len - 3) / 2;
+            for (int i = 0; i < nb && i < kJ2kBands; i++) { unsigned v = be16(p + 1 + 2 * i); h.expn[i] = (int) (v >> 11); h.mant[i] = (int) (v & 0x7FF); }
         }
         pos += 2 + len;
     }
-    if (!tile_data || W != g.W || H != g.H || nres != kJ2kRes || qsty != 2 || guard != 2) {
-        set_error("J2K: codestream (%dx%d, %d resolutions, qsty %d) does not match the context (%dx%d)", W, H, nres, qsty, g.W, g.H);
-        return false;
-    }
+    set_error("J2K: no tile-part");
+    return false;
+}
+
+bool header_matches(const MainHeader &h, const J2kGeom &g)
+{
+    if (h.nres != kJ2kRes || h.qsty != 2 || h.guard != 2) return false;
     for (int b = 0; b < g.nbands; b++)
-        if (expn[b] != g.bands[b].expn || mant[b] != g.bands[b].mant) { set_error("J2K: unexpected quantisation table"); return false; }
+        if (h.expn[b] != g.bands[b].expn || h.mant[b] != g.bands[b].mant) return false;
+    return true;
+}
+
+// One tile-part starting at the SOT marker at cs + sot: packet headers -> table [nblocks][4] = {offset of the
+// code-block's bytes relative to `origin`, length, numbps, passes}.  Returns the position after the tile-part.
+bool parse_tile_part(const uint8_t *cs, size_t n, size_t sot, const uint8_t *origin, const J2kGeom &g, int *table, int *isot,
+                     size_t *next)
+{
+    if (sot + 12 + 2 > n || be16(cs + sot) != 0xFF90) { set_error("J2K: missing SOT"); return false; }
+    const uint8_t *p = cs + sot + 4;
+    *isot = (int) be16(p);
+    const unsigned psot = be32(p + 2);
+    if (p[6] != 0) { set_error("J2K: tiles split into several tile-parts are not supported"); return false; }
+    size_t pos = sot + 2 + be16(cs + sot + 2);
+    if (pos + 2 > n || be16(cs + pos) != 0xFF93) { set_error("J2K: missing SOD"); return false; }
+    const uint8_t *tile_data = cs + pos + 2;
+    const uint8_t *tile_end = psot ? cs + sot + psot : cs + n - 2;
+    if (tile_end > cs + n || tile_end < tile_data) { set_error("J2K: tile-part overruns the stream"); return false; }
     std::memset(table, 0, sizeof(int) * 4 * (size_t) g.nblocks);
-    const uint8_t *p = tile_data;
+    p = tile_data;
     for (int r = 0; r < kJ2kRes; r++) {
         BitReader br{p, tile_end};
         std::vector<int> included;
@@ -207,9 +228,63 @@ bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *ta
         p = br.p;
         for (int blk : included) {
             if (p + table[4 * blk + 1] > tile_end) { set_error("J2K: packet body overruns the tile-part"); return false; }
-            table[4 * blk + 0] = (int) (p - cs);
+            table[4 * blk + 0] = (int) (p - origin);
             p += table[4 * blk + 1];
         }
+    }
+    *next = (size_t) (tile_end - cs);
+    return true;
+}
+
+}  // namespace
+
+bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table /* [nblocks][4] */)
+{
+    MainHeader h;
+    if (!parse_main_header(cs, n, h)) return false;
+    if (h.W != g.W || h.H != g.H || !header_matches(h, g)) {
+        set_error("J2K: codestream (%dx%d, %d resolutions, qsty %d) does not match the context (%dx%d)", h.W, h.H, h.nres, h.qsty, g.W, g.H);
+        return false;
+    }
+    int isot;
+    size_t next;
+    return parse_tile_part(cs, n, h.first_sot, cs, g, table, &isot, &next);      // offsets relative to the whole stream
+}
+
+// Image / tile extents of a codestream (A.5.1): false if it has no usable main header
+bool j2k_peek_dims(const uint8_t *cs, size_t n, int *W, int *H, int *tile_w, int *tile_h)
+{
+    MainHeader h;
+    if (!parse_main_header(cs, n, h)) return false;
+    *W = h.W; *H = h.H; *tile_w = h.tile_w; *tile_h = h.tile_h;
+    return true;
+}
+
+// A codestream of `tiles` tiles of the context's geometry stacked along y (what the reference writes for a
+// chunk of several frames): tables[t] as above with offsets relative to the tile-part's SOT, and the extent of
+// every tile-part inside cs.
+bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kGeom &g, int tiles, int *tables /* [tiles][nblocks][4] */,
+                     size_t *part_off, size_t *part_len)
+{
+    MainHeader h;
+    if (!parse_main_header(cs, n, h)) return false;
+    if (h.W != g.W || h.H != g.H * tiles || h.tile_w != g.W || h.tile_h != g.H || !header_matches(h, g)) {
+        set_error("J2K: codestream (%dx%d in tiles of %dx%d) does not match %d tiles of %dx%d", h.W, h.H, h.tile_w, h.tile_h, tiles, g.W, g.H);
+        return false;
+    }
+    std::vector<char> seen((size_t) tiles, 0);
+    size_t pos = h.first_sot;
+    for (int k = 0; k < tiles; k++) {
+        int isot;
+        size_t next;
+        if (pos + 12 > n || be16(cs + pos) != 0xFF90) { set_error("J2K: fewer tile-parts than tiles"); return false; }
+        const int peek = (int) be16(cs + pos + 4);
+        if (peek < 0 || peek >= tiles || seen[(size_t) peek]) { set_error("J2K: bad tile index %d", peek); return false; }
+        if (!parse_tile_part(cs, n, pos, cs + pos, g, tables + (size_t) peek * g.nblocks * 4, &isot, &next)) return false;
+        seen[(size_t) peek] = 1;
+        part_off[peek] = pos;
+        part_len[peek] = next - pos;
+        pos = next;
     }
     return true;
 }

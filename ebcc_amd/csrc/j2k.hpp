@@ -73,6 +73,8 @@ struct J2kFrame {                 // per-frame scalars (device)
     unsigned long long nbad;      // count(|x - d| > target) of the last decode
     double err_sum;               // sum(x - d)
     int overflow;                 // a code-block outgrew its byte slot
+    float hdr_share;              // this tile's share of the main header in the byte budget (opj_j2k_update_rates:
+                                  // main header bytes / number of tiles); 0 = a single tile = all 135 bytes
 };
 
 struct J2kBuffers {

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     if (rate <= 1.0f) rate = 0.0f;                                   // "force lossless"
     if (rate > 0.0f) {
         rate = (float) (((double) 16 * (double) g.W * (double) g.H) / ((double) rate * (double) 8)) - 0.0f;
-        rate -= (float) kMainHeaderBytes / 1.0f;
+        rate -= jf[frame].hdr_share > 0.0f ? jf[frame].hdr_share : (float) kMainHeaderBytes / 1.0f;
         if (rate < 30.0f) rate = 30.0f;
     }
 

@@ -150,5 +150,59 @@ def main():
     print("golden fixtures written to", OUT)
 
 
+def tiled():
+    """Chunks holding several frames (reference src/ebcc_codec.c:105-180: one multi-tile JPEG 2000 image per chunk)
+    -> tests/golden/tiled.json + tiled_inputs.npz.  `python oracle/make_golden.py tiled`"""
+    rng = np.random.default_rng(77)
+    idx = lambda shape: np.indices(shape, dtype=np.float32)
+    inputs = {
+        "ramp_2x32x32": np.ascontiguousarray(idx((2, 32, 32))[0] * 100.0 + idx((2, 32, 32))[1] * 1.5 + idx((2, 32, 32))[2] * 0.25, np.float32),
+        "noise_4x32x64": (270 + 5 * np.cumsum(rng.standard_normal((4, 32, 64)), axis=2) / 8 + rng.standard_normal((4, 32, 64))).astype(np.float32),
+        "waves_2x64x96": np.stack([(10 * np.sin(np.arange(96)[None, :] / (7.0 + k)) * np.cos(np.arange(64)[:, None] / (5.0 + k))
+                                    + 0.3 * rng.standard_normal((64, 96))) for k in range(2)]).astype(np.float32),
+        "mixed_3x128x160": np.stack([L.era5_like(128, 160, 40 + k, 1.3, 1.5) for k in range(3)]).astype(np.float32),
+        "const_2x32x32": np.full((2, 32, 32), 4.5, np.float32),
+    }
+    np.savez_compressed(os.path.join(OUT, "tiled_inputs.npz"), **inputs)
+    cases = {}
+    for name, base_cr, mode, err, quant in [("ramp_2x32x32", 2.0, 0, 0.0, None), ("ramp_2x32x32", 2.0, 1, 0.01, None),
+                                            ("ramp_2x32x32", 2.0, 2, 0.01, None), ("noise_4x32x64", 10.0, 1, 0.05, None),
+                                            ("noise_4x32x64", 10.0, 2, 1e-3, None), ("noise_4x32x64", 40.0, 0, 0.0, None),
+                                            ("waves_2x64x96", 20.0, 1, 0.02, "0.1"), ("waves_2x64x96", 20.0, 1, 0.02, None),
+                                            ("waves_2x64x96", 6.0, 2, 5e-4, "0.02"), ("mixed_3x128x160", 30.0, 1, 0.1, None),
+                                            ("mixed_3x128x160", 30.0, 1, 0.1, "0.1"), ("const_2x32x32", 5.0, 1, 0.1, None),
+                                            # residual layer kept (the pure-base fallback switched off): SPIHT over the whole chunk
+                                            ("waves_2x64x96", 20.0, 1, 0.02, "0.1+nofallback"), ("mixed_3x128x160", 30.0, 1, 0.1, "0.1+nofallback"),
+                                            ("noise_4x32x64", 10.0, 2, 1e-3, "0.02+nofallback")]:
+        os.environ.pop("EBCC_INIT_BASE_ERROR_QUANTILE", None)
+        os.environ.pop("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", None)
+        if quant:
+            os.environ["EBCC_INIT_BASE_ERROR_QUANTILE"] = quant.split("+")[0]
+            if quant.endswith("+nofallback"):
+                os.environ["EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK"] = "1"
+        x = inputs[name]
+        cfg = L.make_config(x.shape, base_cr=base_cr, error=err, residual_type=mode)
+        s = ref_encode(x, cfg)
+        d = ref_decode(s)
+        import struct
+        coeffs = struct.unpack("<Q", s[16:24])[0]
+        cases[f"{name}_cr{base_cr:g}_m{mode}_q{quant}"] = {"input": name, "base_cr": base_cr, "mode": mode, "error": err, "quantile": quant,
+                                                          "stream_hex": s.hex(), "decoded_sha256": sha(d.tobytes()), "coeffs_size": coeffs}
+        print(name, mode, quant, len(s), "coeffs", coeffs, "max err", float(np.abs(d - x.ravel()).max()))
+    os.environ.pop("EBCC_INIT_BASE_ERROR_QUANTILE", None)
+    os.environ.pop("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", None)
+    make_data = lambda shape: np.ascontiguousarray(idx(shape)[0] * 100.0 + idx(shape)[1] * 1.5 + idx(shape)[2] * 0.25, np.float32)
+    ebck = {}
+    for shape, chunk in [((3, 33, 35), (2, 32, 32)), ((2, 32, 32), (4, 32, 32)), ((2, 32, 32), (0, 0, 0)), ((5, 64, 64), (2, 64, 32))]:
+        for mode, err in ((1, 0.01), (0, 0.0)):
+            cfg = L.make_config(shape, chunk if any(chunk) else None, base_cr=2.0, error=err, residual_type=mode)
+            s = ref_encode(make_data(shape), cfg, "ebcc_encode_chunking")
+            d = ref_decode(s, "ebcc_decode_chunking")
+            ebck[f"{shape}_{chunk}_m{mode}"] = {"shape": shape, "chunk": chunk, "mode": mode, "error": err, "n": len(s),
+                                                "stream_sha256": sha(s), "decoded_sha256": sha(d.tobytes())}
+    json.dump({"frames": cases, "ebck": ebck}, open(os.path.join(OUT, "tiled.json"), "w"), indent=0)
+    print("tiled fixtures written")
+
+
 if __name__ == "__main__":
-    main()
+    tiled() if sys.argv[1:] == ["tiled"] else main()

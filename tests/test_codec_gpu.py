@@ -81,6 +81,45 @@ def test_ebck_containers_bit_exact(name):
         assert np.allclose(d.reshape(shape), data, atol=0.02)
 
 
+_tiled = json.load(open(os.path.join(L.GOLDEN, "tiled.json")))
+_tiled_inputs = np.load(os.path.join(L.GOLDEN, "tiled_inputs.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(_tiled["frames"]), ids=str)
+def test_multi_frame_chunks_bit_exact(name, monkeypatch):
+    """Chunks of several frames = one multi-tile JPEG 2000 image + SPIHT over the stacked image (reference
+    src/ebcc_codec.c:105-180); golden streams from the reference build (oracle/make_golden.py tiled)."""
+    c = _tiled["frames"][name]
+    for k in ("EBCC_INIT_BASE_ERROR_QUANTILE", "EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK"):
+        monkeypatch.delenv(k, raising=False)
+    if c["quantile"]:
+        monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", c["quantile"].split("+")[0])
+        if c["quantile"].endswith("+nofallback"):
+            monkeypatch.setenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", "1")
+    x = _tiled_inputs[c["input"]]
+    cfg = L.make_config(x.shape, base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+    want = bytes.fromhex(c["stream_hex"])
+    got = api_encode(x, cfg)
+    assert len(got) == len(want) and got == want
+    assert sha(api_decode(want).tobytes()) == c["decoded_sha256"]
+
+
+@pytest.mark.parametrize("name", sorted(_tiled["ebck"]), ids=str)
+def test_multi_frame_chunk_containers_bit_exact(name):
+    """The chunk shapes of the reference's tests/test_c_api.py:194-258 (several frames per chunk, padded edges,
+    chunk larger than the data, default full-array chunk)."""
+    c = _tiled["ebck"][name]
+    shape, chunk = tuple(c["shape"]), tuple(c["chunk"])
+    cfg = L.make_config(shape, chunk if any(chunk) else None, base_cr=2.0, error=c["error"], residual_type=c["mode"])
+    data = _make_data(shape)
+    s = api_encode(data, cfg, "ebcc_encode_chunking")
+    assert len(s) == c["n"] and sha(s) == c["stream_sha256"]
+    d = api_decode(s, "ebcc_decode_chunking")
+    assert sha(d.tobytes()) == c["decoded_sha256"]
+    if c["mode"] == 1:
+        assert np.allclose(d.reshape(shape), data, atol=0.02)
+
+
 def test_full_size_formula_frames_bit_exact():
     big = json.load(open(os.path.join(L.GOLDEN, "codec_big.json")))
     y, x = np.mgrid[0:721, 0:1440]

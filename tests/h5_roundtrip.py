@@ -40,5 +40,19 @@ assert raw_dc == raw_cb, [len(a) - len(b) for a, b in zip(raw_dc, raw_cb)]
 print("OK direct-chunk bytes == callback bytes", sum(len(r) for r in raw_dc))
 assert np.array_equal(via_callback, back) and np.array_equal(via_batch, back)
 print("OK batch read == callback read")
+# (3) chunks of two frames: the filter callback receives both frames at once (one multi-tile codestream per chunk)
+h2, w2 = 32, 64
+multi = np.stack([(260 + 8 * np.sin(x[:h2, :w2] / (5.0 + k)) + rng.normal(0, 0.2, (h2, w2))).astype(np.float32) for k in range(4)])
+kw = dict(EBCC_Filter(base_cr=10, height=h2, width=w2, residual_opt=("max_error_target", 0.05), data_dim=3))
+kw["chunks"] = (2, h2, w2)
+with h5py.File(os.path.join(out, "mf.h5"), "w") as f:
+    f.create_dataset("t", data=multi, **kw)
+with h5py.File(os.path.join(out, "mf.h5"), "r") as f:
+    back2 = f["t"][...]
+    raw2 = [f["t"].id.read_direct_chunk((k, 0, 0))[1] for k in (0, 2)]
+assert np.abs(back2 - multi).max() <= 0.05 * 1.01 + 1e-4, np.abs(back2 - multi).max()
+print("OK two-frame chunks round trip, max error", float(np.abs(back2 - multi).max()))
+np.save(os.path.join(out, "chunks2.npy"), np.array([np.frombuffer(r, np.uint8) for r in raw2], dtype=object), allow_pickle=True)
+np.save(os.path.join(out, "data2.npy"), multi)
 np.save(os.path.join(out, "chunks.npy"), np.array([np.frombuffer(r, np.uint8) for r in raw_cb], dtype=object), allow_pickle=True)
 np.save(os.path.join(out, "data.npy"), data)

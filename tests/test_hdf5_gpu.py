@@ -23,7 +23,7 @@ def test_hdf5_filter_and_direct_chunk_batch(tmp_path):
     r = subprocess.run([CONDA_PY, os.path.join(L.ROOT, "tests", "h5_roundtrip.py"), str(tmp_path)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("OK") == 3, r.stdout
+    assert r.stdout.count("OK") == 4, r.stdout
     # what HDF5 stored == the oracle's frame streams for the same frames
     chunks = np.load(tmp_path / "chunks.npy", allow_pickle=True)
     data = np.load(tmp_path / "data.npy")
@@ -31,3 +31,10 @@ def test_hdf5_filter_and_direct_chunk_batch(tmp_path):
     L.oracle().orc_set_j2k_backend(0)
     for k in (0, 3, 5):
         assert bytes(chunks[k].tobytes()) == L.orc_encode(data[k], cfg), k
+    # two-frame chunks: what HDF5 stored == ebcc_encode of the same two frames through the C API
+    from tests.test_codec_gpu import api_encode
+    chunks2 = np.load(tmp_path / "chunks2.npy", allow_pickle=True)
+    data2 = np.load(tmp_path / "data2.npy")
+    cfg2 = L.make_config((2,) + data2.shape[1:], base_cr=10, error=0.05, residual_type=L.MAX_ERROR)
+    for i, k in enumerate((0, 2)):
+        assert bytes(chunks2[i].tobytes()) == api_encode(data2[k:k + 2], cfg2), k

@@ -51,17 +51,18 @@ static int zstd_load(void)
 
 /* ------------------------------------------------------------------ J2K back-ends */
 #ifdef ORC_HAVE_OPENJPEG
-size_t orc_opj_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out);
+size_t orc_opj_encode_tiled(const uint16_t *img, size_t tiles, size_t height, size_t width, float base_cr, uint8_t **out);
 size_t orc_opj_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *h, size_t *w);
 #endif
 
-static size_t j2k_enc(const uint16_t *img, size_t h, size_t w, float cr, uint8_t **out)
+/* j2k_encode_internal, ebcc_codec.c:105-180: a chunk of several frames is one image with one tile per frame */
+static size_t j2k_enc(const uint16_t *img, size_t tiles, size_t frame_h, size_t w, float cr, uint8_t **out)
 {
     g_trace.n_j2k_encodes++;
 #ifdef ORC_HAVE_OPENJPEG
-    if (g_backend == 1) return orc_opj_encode(img, h, w, cr, out);
+    if (g_backend == 1) return orc_opj_encode_tiled(img, tiles, frame_h, w, cr, out);
 #endif
-    return orc_j2k_encode(img, h, w, cr, out);
+    return orc_j2k_encode_tiled(img, tiles, frame_h, w, cr, out);
 }
 
 /* j2k_decode_internal, ebcc_codec.c:1092-1136: samples -> (s/65535)*(max-min)+min */
@@ -128,7 +129,7 @@ static float data_range(const float *a, size_t n)
 
 /* ------------------------------------------------------------------ rate search, :535-596 */
 typedef struct {
-    const uint16_t *scaled; size_t h, w, n;
+    const uint16_t *scaled; size_t tiles, frame_h, h, w, n;
     const float *data; float minv, maxv, target;
     uint8_t *cs; size_t cs_len;          /* last codestream produced */
     float *decoded;
@@ -137,7 +138,7 @@ typedef struct {
 static double probe(search_t *s, float cr)
 {
     free(s->cs); s->cs = NULL;
-    s->cs_len = j2k_enc(s->scaled, s->h, s->w, cr, &s->cs);
+    s->cs_len = j2k_enc(s->scaled, s->tiles, s->frame_h, s->w, cr, &s->cs);
     j2k_dec(s->cs, s->cs_len, s->minv, s->maxv, &s->decoded, NULL, NULL);
     return feasible_fraction(s->data, s->decoded, s->n, s->target);
 }
@@ -226,8 +227,8 @@ size_t orc_ebcc_encode(const float *data, const orc_config_t *cfg, uint8_t **out
         scaled = (uint16_t *) malloc(n * sizeof(uint16_t));
         for (size_t i = 0; i < n; i++)
             scaled[i] = ((data[i] - minv) / (maxv - minv)) * (uint16_t) -1;    /* :688 */
-        S.scaled = scaled; S.h = H; S.w = W; S.n = n; S.data = data; S.minv = minv; S.maxv = maxv;
-        S.cs_len = j2k_enc(scaled, H, W, cfg->base_cr, &S.cs);                 /* :693 */
+        S.scaled = scaled; S.tiles = H / frame_h; S.frame_h = frame_h; S.h = H; S.w = W; S.n = n; S.data = data; S.minv = minv; S.maxv = maxv;
+        S.cs_len = j2k_enc(scaled, S.tiles, frame_h, W, cfg->base_cr, &S.cs);                 /* :693 */
         if (mode == ORC_NONE) { tail = S.cs; tail_len = S.cs_len; S.cs = NULL; }
     }
 
@@ -305,7 +306,7 @@ after_search:
         if (!pure_done && !no_fallback && (mode == ORC_MAX_ERROR || mode == ORC_RELATIVE_ERROR)) {
             if (!no_consistency) {
                 free(S.cs); S.cs = NULL;
-                S.cs_len = j2k_enc(scaled, H, W, cfg->base_cr, &S.cs);         /* :830 */
+                S.cs_len = j2k_enc(scaled, S.tiles, frame_h, W, cfg->base_cr, &S.cs);         /* :830 */
                 j2k_dec(S.cs, S.cs_len, minv, maxv, &S.decoded, NULL, NULL);
                 cr = cfg->base_cr;
             }

@@ -59,39 +59,44 @@ typedef struct {
 
 typedef struct {
     int W, H;
+    int ty0;                      /* row of the tile's first line in the image (tiles are stacked along y) */
     res_t res[J2K_NRES];
 } tile_t;
 
 static int ceildivpow2(int a, int b) { return (int) (((int64_t) a + ((int64_t) 1 << b) - 1) >> b); }
 static int floorlog2(int a) { int l = 0; while (a > 1) { a >>= 1; l++; } return l; }
 
-static void tile_init(tile_t *t, int W, int H)
+/* resolutions / bands / code-blocks of the tile whose rows are [ty0, ty0 + H) of the image (T.800 B.5-B.7): a tile
+ * away from the origin has its own sub-band extents, low/high parity and code-block partition (the partition is
+ * anchored at multiples of 64 of the band coordinates) */
+static void tile_init_at(tile_t *t, int W, int H, int ty0)
 {
     memset(t, 0, sizeof *t);
-    t->W = W; t->H = H;
+    t->W = W; t->H = H; t->ty0 = ty0;
+    const int ty1 = ty0 + H;
     for (int r = 0; r < J2K_NRES; r++) {
         int lv = J2K_NRES - 1 - r;
         res_t *rs = &t->res[r];
-        rs->x0 = 0; rs->y0 = 0;
-        rs->x1 = ceildivpow2(W, lv); rs->y1 = ceildivpow2(H, lv);
+        rs->x0 = 0; rs->y0 = ceildivpow2(ty0, lv);
+        rs->x1 = ceildivpow2(W, lv); rs->y1 = ceildivpow2(ty1, lv);
         rs->nbands = r == 0 ? 1 : 3;
         for (int b = 0; b < rs->nbands; b++) {
             band_t *bd = &rs->bands[b];
             bd->level = lv;
             if (r == 0) {
                 bd->orient = 0;
-                bd->x0 = 0; bd->y0 = 0; bd->x1 = rs->x1; bd->y1 = rs->y1;
+                bd->x0 = 0; bd->y0 = rs->y0; bd->x1 = rs->x1; bd->y1 = rs->y1;
                 bd->offx = 0; bd->offy = 0;
             } else {
                 bd->orient = b + 1;
                 int xb = bd->orient & 1, yb = bd->orient >> 1;
                 /* T.800 B-15: band bounds from the tile-component bounds */
                 bd->x0 = ceildivpow2(0 - (xb << lv), lv + 1) < 0 ? 0 : ceildivpow2(0 - (xb << lv), lv + 1);
-                bd->y0 = ceildivpow2(0 - (yb << lv), lv + 1) < 0 ? 0 : ceildivpow2(0 - (yb << lv), lv + 1);
+                bd->y0 = ceildivpow2(ty0 - (yb << lv), lv + 1) < 0 ? 0 : ceildivpow2(ty0 - (yb << lv), lv + 1);
                 bd->x1 = ceildivpow2(W - (xb << lv), lv + 1);
-                bd->y1 = ceildivpow2(H - (yb << lv), lv + 1);
+                bd->y1 = ceildivpow2(ty1 - (yb << lv), lv + 1);
                 bd->offx = xb ? t->res[r - 1].x1 : 0;
-                bd->offy = yb ? t->res[r - 1].y1 : 0;
+                bd->offy = yb ? t->res[r - 1].y1 - t->res[r - 1].y0 : 0;
             }
             int bw = bd->x1 - bd->x0, bh = bd->y1 - bd->y0;
             if (bw <= 0 || bh <= 0) { bd->ncw = bd->nch = 0; continue; }
@@ -110,6 +115,7 @@ static void tile_init(tile_t *t, int W, int H)
         }
     }
 }
+
 
 static void tile_free(tile_t *t)
 {
@@ -505,46 +511,34 @@ static int tgt_decode(bior_t *b, tgt_t *t, int leaf, int threshold)
 static const float DWT_ALPHA = -1.586134342f, DWT_BETA = -0.052980118f, DWT_GAMMA = 0.882911075f,
                    DWT_DELTA = 0.443506852f, DWT_K = 1.230174105f, DWT_TWO_INVK = 1.625732422f;
 
-/* x: interleaved samples (even = low); sn lows, dn highs (cas 0: the first sample is a low) */
-static void idwt97_line(float *x, int sn, int dn)
+/* One synthesis lifting step on an interleaved line (opj_v8dwt_decode_step2 / opj_dwt_decode_1_real): the `cnt`
+ * samples at x[pa], x[pa + 2], ... are updated from their neighbours of the other parity x[pb + 2i - 1 ...];
+ * m = number of samples that have both neighbours. */
+static void idwt_step(float *x, int pa, int cnt, int m, float c)
 {
-    int n = sn + dn;
-    if (!(dn > 0 || sn > 1)) return;
-    for (int i = 0; i < sn; i++) x[2 * i] = x[2 * i] * DWT_K;
-    for (int i = 0; i < dn; i++) x[2 * i + 1] = x[2 * i + 1] * DWT_TWO_INVK;
-    (void) n;
-    /* l[i] += c*(h[i-1] + h[i]) with symmetric extension; c = -delta */
-    {
-        float c = -DWT_DELTA;
-        int m = sn < dn ? sn : dn;                       /* min(sn, dn - a), a = 0 */
-        for (int i = 0; i < m; i++) {
-            float hl = i == 0 ? x[1] : x[2 * i - 1];
-            x[2 * i] = x[2 * i] + ((hl + x[2 * i + 1]) * c);
-        }
-        if (m < sn) { float c2 = c + c; x[2 * m] = x[2 * m] + x[2 * m - 1] * c2; }
+    /* sample i sits at x[pa + 2 i]; its neighbours are x[pa + 2 i - 1] and x[pa + 2 i + 1]; at the left edge the
+     * missing neighbour is mirrored (x[pa + 1]), at the right edge the last sample sees its left neighbour twice */
+    int lim = cnt < m ? cnt : m;
+    for (int i = 0; i < lim; i++) {
+        float left = (pa + 2 * i - 1) >= 0 ? x[pa + 2 * i - 1] : x[pa + 2 * i + 1];
+        x[pa + 2 * i] = x[pa + 2 * i] + ((left + x[pa + 2 * i + 1]) * c);
     }
-    /* h[i] += c*(l[i] + l[i+1]); c = -gamma */
-    {
-        float c = -DWT_GAMMA;
-        int m = dn < sn - 1 ? dn : sn - 1;               /* min(dn, sn - b), b = 1 */
-        for (int i = 0; i < m; i++) x[2 * i + 1] = x[2 * i + 1] + ((x[2 * i] + x[2 * i + 2]) * c);
-        if (m < dn) { float c2 = c + c; x[2 * m + 1] = x[2 * m + 1] + x[2 * m] * c2; }
-    }
-    {
-        float c = -DWT_BETA;
-        int m = sn < dn ? sn : dn;
-        for (int i = 0; i < m; i++) {
-            float hl = i == 0 ? x[1] : x[2 * i - 1];
-            x[2 * i] = x[2 * i] + ((hl + x[2 * i + 1]) * c);
-        }
-        if (m < sn) { float c2 = c + c; x[2 * m] = x[2 * m] + x[2 * m - 1] * c2; }
-    }
-    {
-        float c = -DWT_ALPHA;
-        int m = dn < sn - 1 ? dn : sn - 1;
-        for (int i = 0; i < m; i++) x[2 * i + 1] = x[2 * i + 1] + ((x[2 * i] + x[2 * i + 2]) * c);
-        if (m < dn) { float c2 = c + c; x[2 * m + 1] = x[2 * m + 1] + x[2 * m] * c2; }
-    }
+    if (m < cnt) { float c2 = c + c; x[pa + 2 * m] = x[pa + 2 * m] + x[pa + 2 * m - 1] * c2; }
+}
+
+/* x: interleaved samples; sn lows, dn highs; cas = parity of the first sample's coordinate (0: it is a low) */
+static void idwt97_line(float *x, int sn, int dn, int cas)
+{
+    int a, b;
+    if (cas == 0) { if (!(dn > 0 || sn > 1)) return; a = 0; b = 1; }
+    else { if (!(sn > 0 || dn > 1)) return; a = 1; b = 0; }
+    /* lows live at x[a + 2i], highs at x[b + 2i] */
+    for (int i = 0; i < sn; i++) x[a + 2 * i] = x[a + 2 * i] * DWT_K;
+    for (int i = 0; i < dn; i++) x[b + 2 * i] = x[b + 2 * i] * DWT_TWO_INVK;
+    idwt_step(x, a, sn, sn < dn - a ? sn : dn - a, -DWT_DELTA);
+    idwt_step(x, b, dn, dn < sn - b ? dn : sn - b, -DWT_GAMMA);
+    idwt_step(x, a, sn, sn < dn - a ? sn : dn - a, -DWT_BETA);
+    idwt_step(x, b, dn, dn < sn - b ? dn : sn - b, -DWT_ALPHA);
 }
 
 static void idwt97_tile(float *buf, const tile_t *t)
@@ -552,21 +546,21 @@ static void idwt97_tile(float *buf, const tile_t *t)
     int W = t->W;
     float *line = (float *) malloc((size_t) (t->W > t->H ? t->W : t->H) * sizeof(float) + 64);
     for (int r = 1; r < J2K_NRES; r++) {
-        int rw = t->res[r].x1, rh = t->res[r].y1;
-        int sn = t->res[r - 1].x1, dn = rw - sn;
+        int rw = t->res[r].x1 - t->res[r].x0, rh = t->res[r].y1 - t->res[r].y0;
+        int sn = t->res[r - 1].x1 - t->res[r - 1].x0, dn = rw - sn, cas = t->res[r].x0 & 1;
         /* horizontal pass first (opj_dwt_decode_tile_97) */
         for (int y = 0; y < rh; y++) {
             float *row = buf + (size_t) y * W;
-            for (int i = 0; i < sn; i++) line[2 * i] = row[i];
-            for (int i = 0; i < dn; i++) line[2 * i + 1] = row[sn + i];
-            idwt97_line(line, sn, dn);
+            for (int i = 0; i < sn; i++) line[cas + 2 * i] = row[i];
+            for (int i = 0; i < dn; i++) line[1 - cas + 2 * i] = row[sn + i];
+            idwt97_line(line, sn, dn, cas);
             memcpy(row, line, (size_t) rw * sizeof(float));
         }
-        sn = t->res[r - 1].y1; dn = rh - sn;
+        sn = t->res[r - 1].y1 - t->res[r - 1].y0; dn = rh - sn; cas = t->res[r].y0 & 1;
         for (int x = 0; x < rw; x++) {
-            for (int i = 0; i < sn; i++) line[2 * i] = buf[(size_t) i * W + x];
-            for (int i = 0; i < dn; i++) line[2 * i + 1] = buf[(size_t) (sn + i) * W + x];
-            idwt97_line(line, sn, dn);
+            for (int i = 0; i < sn; i++) line[cas + 2 * i] = buf[(size_t) i * W + x];
+            for (int i = 0; i < dn; i++) line[1 - cas + 2 * i] = buf[(size_t) (sn + i) * W + x];
+            idwt97_line(line, sn, dn, cas);
             for (int i = 0; i < rh; i++) buf[(size_t) i * W + x] = line[i];
         }
     }
@@ -579,45 +573,12 @@ static void idwt97_tile(float *buf, const tile_t *t)
 static uint32_t be16(const uint8_t *p) { return ((uint32_t) p[0] << 8) | p[1]; }
 static uint32_t be32(const uint8_t *p) { return ((uint32_t) p[0] << 24) | ((uint32_t) p[1] << 16) | ((uint32_t) p[2] << 8) | p[3]; }
 
-size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *height, size_t *width)
+/* decodes one tile-part (packets at p .. tile_end) of the tile whose rows are [ty0, ty0 + H) into out[H * W] */
+static void decode_tile(const uint8_t *p, const uint8_t *tile_end, int W, int H, int ty0, const int *expn, const int *mant,
+                        int prec, int guard, int32_t *out)
 {
-    if (n < 4 || be16(cs) != 0xFF4F) return 0;
-    size_t pos = 2;
-    int W = 0, H = 0, prec = 16, guard = 2, nres = 0, qsty = 0;
-    int expn[3 * J2K_NRES], mant[3 * J2K_NRES];
-    memset(expn, 0, sizeof expn); memset(mant, 0, sizeof mant);
-    const uint8_t *tile_data = NULL, *tile_end = NULL;
-    while (pos + 4 <= n) {
-        uint32_t mk = be16(cs + pos), len = be16(cs + pos + 2);
-        const uint8_t *p = cs + pos + 4;
-        if (mk == 0xFF51) {                         /* SIZ, A.5.1 */
-            W = (int) (be32(p + 2) - be32(p + 10));
-            H = (int) (be32(p + 6) - be32(p + 14));
-            prec = (p[36] & 0x7F) + 1;
-        } else if (mk == 0xFF52) {                  /* COD, A.6.1 */
-            nres = p[5] + 1;
-        } else if (mk == 0xFF5C) {                  /* QCD, A.6.4 */
-            qsty = p[0] & 0x1F; guard = p[0] >> 5;
-            int nb = (int) (len - 3) / 2;
-            for (int i = 0; i < nb && i < 3 * J2K_NRES; i++) {
-                uint32_t v = be16(p + 1 + 2 * i);
-                expn[i] = (int) (v >> 11); mant[i] = (int) (v & 0x7FF);
-            }
-        } else if (mk == 0xFF90) {                  /* SOT, A.4.2 */
-            uint32_t psot = be32(p + 2);
-            const uint8_t *sot = cs + pos;
-            pos += 2 + len;
-            if (be16(cs + pos) != 0xFF93) return 0; /* SOD */
-            tile_data = cs + pos + 2;
-            tile_end = psot ? sot + psot : cs + n - 2;
-            break;
-        }
-        pos += 2 + len;
-    }
-    if (!tile_data || nres != J2K_NRES || qsty != 2 || W <= 0 || H <= 0) return 0;
-
     tile_t t;
-    tile_init(&t, W, H);
+    tile_init_at(&t, W, H, ty0);
     for (int r = 0; r < J2K_NRES; r++)
         for (int b = 0; b < t.res[r].nbands; b++) {
             int bi = r == 0 ? 0 : 3 * (r - 1) + b + 1;
@@ -625,7 +586,6 @@ size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *he
         }
 
     float *buf = (float *) calloc((size_t) W * H, sizeof(float));
-    const uint8_t *p = tile_data;
     /* LRCP, one layer, one component, one precinct per resolution: packets in resolution order (B.12.1.1) */
     for (int r = 0; r < J2K_NRES; r++) {
         res_t *rs = &t.res[r];
@@ -693,7 +653,6 @@ size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *he
     idwt97_tile(buf, &t);
 
     /* DC level shift + rounding + clamp (unsigned prec bits) */
-    int32_t *out = (int32_t *) malloc((size_t) W * H * sizeof(int32_t));
     const int64_t shift = (int64_t) 1 << (prec - 1), vmax = ((int64_t) 1 << prec) - 1;
     for (size_t i = 0; i < (size_t) W * H; i++) {
         int64_t v = (int64_t) lrintf(buf[i]) + shift;
@@ -701,6 +660,54 @@ size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *he
     }
     free(buf);
     tile_free(&t);
+}
+
+
+size_t orc_j2k_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *height, size_t *width)
+{
+    if (n < 4 || be16(cs) != 0xFF4F) return 0;
+    size_t pos = 2;
+    int W = 0, H = 0, TW = 0, TH = 0, prec = 16, guard = 2, nres = 0, qsty = 0;
+    int expn[3 * J2K_NRES], mant[3 * J2K_NRES];
+    memset(expn, 0, sizeof expn); memset(mant, 0, sizeof mant);
+    int32_t *out = NULL;
+    int tiles_seen = 0;
+    while (pos + 4 <= n) {
+        uint32_t mk = be16(cs + pos), len = be16(cs + pos + 2);
+        const uint8_t *p = cs + pos + 4;
+        if (mk == 0xFFD9) break;                    /* EOC */
+        if (mk == 0xFF51) {                         /* SIZ, A.5.1 */
+            W = (int) (be32(p + 2) - be32(p + 10));
+            H = (int) (be32(p + 6) - be32(p + 14));
+            TW = (int) be32(p + 18); TH = (int) be32(p + 22);
+            prec = (p[36] & 0x7F) + 1;
+        } else if (mk == 0xFF52) {                  /* COD, A.6.1 */
+            nres = p[5] + 1;
+        } else if (mk == 0xFF5C) {                  /* QCD, A.6.4 */
+            qsty = p[0] & 0x1F; guard = p[0] >> 5;
+            int nb = (int) (len - 3) / 2;
+            for (int i = 0; i < nb && i < 3 * J2K_NRES; i++) {
+                uint32_t v = be16(p + 1 + 2 * i);
+                expn[i] = (int) (v >> 11); mant[i] = (int) (v & 0x7FF);
+            }
+        } else if (mk == 0xFF90) {                  /* SOT, A.4.2: one tile-part per tile, tiles stacked along y */
+            if (nres != J2K_NRES || qsty != 2 || W <= 0 || H <= 0 || TW < W || TH <= 0) { free(out); return 0; }
+            if (!out) out = (int32_t *) calloc((size_t) W * H, sizeof(int32_t));
+            uint32_t isot = be16(p), psot = be32(p + 2);
+            const uint8_t *sot = cs + pos;
+            pos += 2 + len;
+            if (pos + 2 > n || be16(cs + pos) != 0xFF93) { free(out); return 0; }   /* SOD */
+            const uint8_t *tile_end = psot ? sot + psot : cs + n - 2;
+            int ty0 = (int) isot * TH, th = ty0 + TH <= H ? TH : H - ty0;
+            if (ty0 >= H || tile_end > cs + n) { free(out); return 0; }
+            decode_tile(cs + pos + 2, tile_end, W, th, ty0, expn, mant, prec, guard, out + (size_t) ty0 * W);
+            tiles_seen++;
+            pos = (size_t) (tile_end - cs);
+            continue;
+        }
+        pos += 2 + len;
+    }
+    if (!tiles_seen) { free(out); return 0; }
     *samples = out;
     if (height) *height = (size_t) H;
     if (width) *width = (size_t) W;
@@ -759,16 +766,18 @@ static void fdwt_step(float *w, int a, int b, int end, int m, float c)
     }
     if (m < end) fw[-1] += (2 * fw[-2]) * c;
 }
-static void fdwt97_line(float *w, int sn, int dn)
+static void fdwt97_line(float *w, int sn, int dn, int cas)
 {
     const float invK = (float) (1.0 / 1.230174105);
-    if (sn + dn <= 1) return;
-    fdwt_step(w, 0, 1, dn, dn < sn - 1 ? dn : sn - 1, DWT_ALPHA);
-    fdwt_step(w, 1, 0, sn, sn < dn ? sn : dn, DWT_BETA);
-    fdwt_step(w, 0, 1, dn, dn < sn - 1 ? dn : sn - 1, DWT_GAMMA);
-    fdwt_step(w, 1, 0, sn, sn < dn ? sn : dn, DWT_DELTA);
-    for (int i = 0; i < sn; i++) w[2 * i] *= invK;
-    for (int i = 0; i < dn; i++) w[2 * i + 1] *= DWT_K;
+    int a, b;
+    if (cas == 0) { if (sn + dn <= 1) return; a = 0; b = 1; }
+    else { if (!(sn > 0 || dn > 1)) return; a = 1; b = 0; }         /* a lone high-pass sample: see fdwt97_tile */
+    fdwt_step(w, a, b, dn, dn < sn - b ? dn : sn - b, DWT_ALPHA);
+    fdwt_step(w, b, a, sn, sn < dn - a ? sn : dn - a, DWT_BETA);
+    fdwt_step(w, a, b, dn, dn < sn - b ? dn : sn - b, DWT_GAMMA);
+    fdwt_step(w, b, a, sn, sn < dn - a ? sn : dn - a, DWT_DELTA);
+    for (int i = 0; i < sn; i++) w[a + 2 * i] *= invK;
+    for (int i = 0; i < dn; i++) w[b + 2 * i] *= DWT_K;
 }
 
 static void fdwt97_tile(float *buf, const tile_t *t)
@@ -776,24 +785,24 @@ static void fdwt97_tile(float *buf, const tile_t *t)
     int W = t->W;
     float *line = (float *) malloc((size_t) (t->W > t->H ? t->W : t->H) * sizeof(float) + 64);
     for (int r = J2K_NRES - 1; r >= 1; r--) {
-        int rw = t->res[r].x1, rh = t->res[r].y1;
-        int sn = t->res[r - 1].y1, dn = rh - sn;
+        int rw = t->res[r].x1 - t->res[r].x0, rh = t->res[r].y1 - t->res[r].y0;
+        int sn = t->res[r - 1].y1 - t->res[r - 1].y0, dn = rh - sn, cas = t->res[r].y0 & 1;
         /* vertical pass first (opj_dwt_encode_procedure) */
         for (int x = 0; x < rw; x++) {
             if (rh == 1) break;
             for (int i = 0; i < rh; i++) line[i] = buf[(size_t) i * W + x];
-            fdwt97_line(line, sn, dn);
-            for (int i = 0; i < sn; i++) buf[(size_t) i * W + x] = line[2 * i];
-            for (int i = 0; i < dn; i++) buf[(size_t) (sn + i) * W + x] = line[2 * i + 1];
+            fdwt97_line(line, sn, dn, cas);
+            for (int i = 0; i < sn; i++) buf[(size_t) i * W + x] = line[cas + 2 * i];
+            for (int i = 0; i < dn; i++) buf[(size_t) (sn + i) * W + x] = line[1 - cas + 2 * i];
         }
-        sn = t->res[r - 1].x1; dn = rw - sn;
+        sn = t->res[r - 1].x1 - t->res[r - 1].x0; dn = rw - sn; cas = t->res[r].x0 & 1;
         for (int y = 0; y < rh; y++) {
             if (rw == 1) break;
             float *row = buf + (size_t) y * W;
             memcpy(line, row, (size_t) rw * sizeof(float));
-            fdwt97_line(line, sn, dn);
-            for (int i = 0; i < sn; i++) row[i] = line[2 * i];
-            for (int i = 0; i < dn; i++) row[sn + i] = line[2 * i + 1];
+            fdwt97_line(line, sn, dn, cas);
+            for (int i = 0; i < sn; i++) row[i] = line[cas + 2 * i];
+            for (int i = 0; i < dn; i++) row[sn + i] = line[1 - cas + 2 * i];
         }
     }
     free(line);
@@ -1080,11 +1089,11 @@ static void (*g_block_sink)(const int32_t *q, int w, int h, int orient, void *us
 static void *g_block_sink_user = NULL;
 void orc_j2k_set_block_sink(void (*fn)(const int32_t *, int, int, int, void *), void *user) { g_block_sink = fn; g_block_sink_user = user; }
 
-static void j2k_analyse(const uint16_t *img, int H, int W, tile_t *tp, int *expn, int *mant)
+static void j2k_analyse_at(const uint16_t *img, int H, int W, int ty0, tile_t *tp, int *expn, int *mant)
 {
     init_luts();
     const int prec = 16, guard = 2;
-    tile_init(tp, W, H);
+    tile_init_at(tp, W, H, ty0);
 
     /* QCD step sizes: opj_dwt_calc_explicit_stepsizes + encode_stepsize */
     for (int bi = 0; bi < 3 * J2K_NRES - 2; bi++) {
@@ -1138,43 +1147,46 @@ static void j2k_analyse(const uint16_t *img, int H, int W, tile_t *tp, int *expn
 
 }
 
-size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
-{
-    const int W = (int) width, H = (int) height, prec = 16, guard = 2;
-    tile_t t;
-    int expn[3 * J2K_NRES - 2], mant[3 * J2K_NRES - 2];
-    j2k_analyse(img, H, W, &t, expn, mant);
+static void j2k_analyse(const uint16_t *img, int H, int W, tile_t *tp, int *expn, int *mant) { j2k_analyse_at(img, H, W, 0, tp, expn, mant); }
 
-    /* main header (A.5.1, A.6.1, A.6.4, A.9.2) */
-    static const char comment[] = "Created by OpenJPEG version 2.4.0";
-    size_t cap = 1024 + (size_t) W * H * 4;
-    uint8_t *o = (uint8_t *) calloc(cap, 1), *p = o;
 #define PUT16(v) do { *p++ = (uint8_t) ((v) >> 8); *p++ = (uint8_t) (v); } while (0)
 #define PUT32(v) do { PUT16((uint32_t) (v) >> 16); PUT16((uint32_t) (v) & 0xFFFF); } while (0)
+
+/* main header (A.5.1, A.6.1, A.6.4, A.9.2) of an image of `tiles` tiles of H rows stacked along y */
+static uint8_t *write_main_header(uint8_t *p, int W, int H, int tiles, const int *expn, const int *mant)
+{
+    static const char comment[] = "Created by OpenJPEG version 2.4.0";
+    const int prec = 16, guard = 2;
     PUT16(0xFF4F);
-    PUT16(0xFF51); PUT16(41); PUT16(0); PUT32(W); PUT32(H); PUT32(0); PUT32(0); PUT32(W); PUT32(H); PUT32(0); PUT32(0);
+    PUT16(0xFF51); PUT16(41); PUT16(0); PUT32(W); PUT32(H * tiles); PUT32(0); PUT32(0); PUT32(W); PUT32(H); PUT32(0); PUT32(0);
     PUT16(1); *p++ = (uint8_t) (prec - 1); *p++ = 1; *p++ = 1;
     PUT16(0xFF52); PUT16(12); *p++ = 0; *p++ = 0; PUT16(1); *p++ = 0; *p++ = J2K_NRES - 1; *p++ = 4; *p++ = 4; *p++ = 0; *p++ = 0;
     PUT16(0xFF5C); PUT16(3 + 2 * (3 * J2K_NRES - 2)); *p++ = (uint8_t) (2 + (guard << 5));
     for (int bi = 0; bi < 3 * J2K_NRES - 2; bi++) PUT16((uint32_t) ((expn[bi] << 11) | mant[bi]));
     PUT16(0xFF64); PUT16(4 + (int) strlen(comment)); PUT16(1);
     memcpy(p, comment, strlen(comment)); p += strlen(comment);
-    size_t main_hdr = (size_t) (p - o);
+    return p;
+}
 
-    /* rate target: opj_j2k_setup_encoder + opj_j2k_update_rates (single tile, single layer) */
+/* one tile-part (SOT, SOD, packets) of an analysed tile at `p`; returns its end, or NULL when the layer does not fit.
+ * The byte budget is opj_j2k_setup_encoder + opj_j2k_update_rates for one layer: every tile carries an equal share of
+ * the main header. */
+static uint8_t *write_tile_part(tile_t *t, uint8_t *p, uint8_t *end, float base_cr, size_t main_hdr, int tiles, int isot)
+{
+    const int prec = 16, W = t->W, H = t->H;
     float rate = base_cr / 2;
     if (rate <= 1.0f) rate = 0.0f;                               /* lossless: keep every pass */
     if (rate > 0.0f) {
         rate = (float) (((double) prec * (double) W * (double) H) / ((double) rate * 8.0)) - 0.0f;
-        rate -= (float) main_hdr / 1.0f;
+        rate -= (float) main_hdr / (float) tiles;
         if (rate < 30.0f) rate = 30.0f;
     }
 
     /* PCRD: opj_tcd_rateallocate */
     double smin = DBL_MAX, smax = 0;
     for (int r = 0; r < J2K_NRES; r++)
-        for (int b = 0; b < t.res[r].nbands; b++) {
-            band_t *bd = &t.res[r].bands[b];
+        for (int b = 0; b < t->res[r].nbands; b++) {
+            band_t *bd = &t->res[r].bands[b];
             for (int ci = 0; ci < bd->ncw * bd->nch; ci++) {
                 cblk_t *cb = &bd->cblks[ci];
                 for (int ps = 0; ps < cb->totalpasses; ps++) {
@@ -1190,7 +1202,7 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
         }
     uint8_t *sot = p;
     p += 12 + 2;
-    size_t room = cap - (size_t) (p - o) - 2;
+    size_t room = (size_t) (end - p) - 2;
     double good = -1;                                            /* rate 0: every pass */
     if (rate > 0.0f) {
         size_t maxlen = (size_t) ceil(rate);
@@ -1198,27 +1210,49 @@ size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float ba
         double lo = smin, hi = smax, thresh = 0, stable = 0;
         for (int i = 0; i < 128; i++) {
             thresh = (lo + hi) / 2;
-            make_layer(&t, thresh);
-            if (t2_encode(&t, p, maxlen, 0) < 0) { lo = thresh; continue; }
+            make_layer(t, thresh);
+            if (t2_encode(t, p, maxlen, 0) < 0) { lo = thresh; continue; }
             hi = thresh;
             stable = thresh;
         }
         good = stable == 0 ? thresh : stable;
     }
-    make_layer(&t, good);
-    long body = t2_encode(&t, p, room, 1);
-    if (body < 0) { free(o); tile_free(&t); return 0; }
-    p += body;
+    make_layer(t, good);
+    long body = t2_encode(t, p, room, 1);
+    if (body < 0) return NULL;
+    uint8_t *after = p + body;
     /* SOT (A.4.2) / SOD */
-    uint8_t *q = sot, *save = p;
-    p = q;
-    PUT16(0xFF90); PUT16(10); PUT16(0); PUT32(12 + 2 + body); *p++ = 0; *p++ = 1;
+    p = sot;
+    PUT16(0xFF90); PUT16(10); PUT16(isot); PUT32(12 + 2 + body); *p++ = 0; *p++ = 1;
     PUT16(0xFF93);
-    p = save;
+    return after;
+}
+
+/* `tiles` frames of H x W stacked along y, one tile each (ebcc_codec.c:105-180 with n_tiles > 1: cp_tdy = frame
+ * height, one opj_write_tile per frame); tiles == 1 is the single-tile image */
+size_t orc_j2k_encode_tiled(const uint16_t *img, size_t tiles, size_t height, size_t width, float base_cr, uint8_t **out)
+{
+    const int W = (int) width, H = (int) height, F = (int) tiles;
+    int expn[3 * J2K_NRES - 2], mant[3 * J2K_NRES - 2];
+    size_t cap = 1024 + (size_t) W * H * 4 * F;
+    uint8_t *o = (uint8_t *) calloc(cap, 1), *p = o;
+    size_t main_hdr = 0;
+    for (int k = 0; k < F; k++) {
+        tile_t t;
+        j2k_analyse_at(img + (size_t) k * W * H, H, W, k * H, &t, expn, mant);
+        if (k == 0) { p = write_main_header(p, W, H, F, expn, mant); main_hdr = (size_t) (p - o); }
+        p = write_tile_part(&t, p, o + cap, base_cr, main_hdr, F, k);
+        tile_free(&t);
+        if (!p) { free(o); return 0; }
+    }
     PUT16(0xFFD9);
-    tile_free(&t);
     *out = o;
     return (size_t) (p - o);
+}
+
+size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
+{
+    return orc_j2k_encode_tiled(img, 1, height, width, base_cr, out);
 }
 
 /* ================================================================================================

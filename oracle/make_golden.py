@@ -162,6 +162,11 @@ def tiled():
                                     + 0.3 * rng.standard_normal((64, 96))) for k in range(2)]).astype(np.float32),
         "mixed_3x128x160": np.stack([L.era5_like(128, 160, 40 + k, 1.3, 1.5) for k in range(3)]).astype(np.float32),
         "const_2x32x32": np.full((2, 32, 32), 4.5, np.float32),
+        # frame heights that are not a multiple of 32: every tile has its own sub-band extents and low/high parity
+        "odd_2x33x35": np.stack([L.era5_like(33, 35, 60 + k, 1.4, 2.0) for k in range(2)]).astype(np.float32),
+        "odd_3x37x70": np.stack([L.era5_like(37, 70, 63 + k, 1.2, 1.0) for k in range(3)]).astype(np.float32),
+        "odd_2x100x130": np.stack([L.era5_like(100, 130, 66 + k, 1.6, 3.0) for k in range(2)]).astype(np.float32),
+        "odd_5x65x129": np.stack([L.era5_like(65, 129, 70 + k, 1.3, 2.5) for k in range(5)]).astype(np.float32),
     }
     np.savez_compressed(os.path.join(OUT, "tiled_inputs.npz"), **inputs)
     cases = {}
@@ -173,7 +178,12 @@ def tiled():
                                             ("mixed_3x128x160", 30.0, 1, 0.1, "0.1"), ("const_2x32x32", 5.0, 1, 0.1, None),
                                             # residual layer kept (the pure-base fallback switched off): SPIHT over the whole chunk
                                             ("waves_2x64x96", 20.0, 1, 0.02, "0.1+nofallback"), ("mixed_3x128x160", 30.0, 1, 0.1, "0.1+nofallback"),
-                                            ("noise_4x32x64", 10.0, 2, 1e-3, "0.02+nofallback")]:
+                                            ("noise_4x32x64", 10.0, 2, 1e-3, "0.02+nofallback"),
+                                            ("odd_2x33x35", 2.0, 0, 0.0, None), ("odd_2x33x35", 6.0, 1, 0.02, None),
+                                            ("odd_2x33x35", 6.0, 1, 0.02, "0.1+nofallback"), ("odd_3x37x70", 5.0, 1, 0.05, None),
+                                            ("odd_3x37x70", 15.0, 2, 2e-3, "0.05+nofallback"), ("odd_2x100x130", 20.0, 2, 1e-3, None),
+                                            ("odd_2x100x130", 40.0, 1, 0.05, "0.1+nofallback"), ("odd_2x100x130", 40.0, 0, 0.0, None),
+                                            ("odd_5x65x129", 8.0, 1, 0.02, None), ("odd_5x65x129", 30.0, 1, 0.1, "0.2+nofallback")]:
         os.environ.pop("EBCC_INIT_BASE_ERROR_QUANTILE", None)
         os.environ.pop("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", None)
         if quant:

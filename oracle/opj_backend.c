@@ -39,6 +39,8 @@ static struct {
     void *h;
     void (*set_default_encoder_parameters)(opj_cparameters_t *);
     opj_image_t *(*image_create)(OPJ_UINT32, opj_image_cmptparm_t *, OPJ_COLOR_SPACE);
+    opj_image_t *(*image_tile_create)(OPJ_UINT32, opj_image_cmptparm_t *, OPJ_COLOR_SPACE);
+    OPJ_BOOL (*write_tile)(opj_codec_t *, OPJ_UINT32, OPJ_BYTE *, OPJ_UINT32, opj_stream_t *);
     opj_codec_t *(*create_compress)(OPJ_CODEC_FORMAT);
     OPJ_BOOL (*setup_encoder)(opj_codec_t *, opj_cparameters_t *, opj_image_t *);
     opj_stream_t *(*stream_default_create)(OPJ_BOOL);
@@ -68,7 +70,7 @@ static int opj_load(void)
     for (int i = 0; names[i] && !J.h; i++) J.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
     if (!J.h) { fprintf(stderr, "oracle: libopenjp2.so.7 not found\n"); return 0; }
 #define L(f) *(void **) &J.f = dlsym(J.h, "opj_" #f)
-    L(set_default_encoder_parameters); L(image_create); L(create_compress); L(setup_encoder);
+    L(set_default_encoder_parameters); L(image_create); L(image_tile_create); L(write_tile); L(create_compress); L(setup_encoder);
     L(stream_default_create); L(stream_set_user_data); L(stream_set_user_data_length);
     L(stream_set_write_function); L(stream_set_read_function); L(start_compress); L(encode);
     L(end_compress); L(stream_destroy); L(image_destroy); L(destroy_codec);
@@ -80,7 +82,9 @@ static int opj_load(void)
 
 const char *orc_opj_version(void) { return opj_load() ? J.version() : ""; }
 
-size_t orc_opj_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
+/* `tiles` frames of height x width stacked along y; more than one = a tiled image written tile by tile (:121-124,
+ * :145-147, :167-171) */
+size_t orc_opj_encode_tiled(const uint16_t *img, size_t tiles, size_t height, size_t width, float base_cr, uint8_t **out)
 {
     if (!opj_load()) return 0;
     opj_cparameters_t p;
@@ -90,24 +94,41 @@ size_t orc_opj_encode(const uint16_t *img, size_t height, size_t width, float ba
     p.tcp_rates[0] = base_cr / 2;                    /* ebcc_codec.c:116 */
     p.irreversible = 1;
     p.cp_tx0 = 0; p.cp_ty0 = 0;
+    if (tiles > 1) { p.tile_size_on = OPJ_TRUE; p.cp_tdx = (int) width; p.cp_tdy = (int) height; }
+    const size_t rows = tiles * height;
     opj_image_cmptparm_t c; memset(&c, 0, sizeof c);
-    c.dx = 1; c.dy = 1; c.w = (OPJ_UINT32) width; c.h = (OPJ_UINT32) height; c.prec = 16; c.sgnd = 0;
-    opj_image_t *im = J.image_create(1, &c, OPJ_CLRSPC_GRAY);
-    for (size_t i = 0; i < height * width; i++) im->comps[0].data[i] = img[i];
-    im->x0 = 0; im->y0 = 0; im->x1 = (OPJ_UINT32) width; im->y1 = (OPJ_UINT32) height;
+    c.dx = 1; c.dy = 1; c.w = (OPJ_UINT32) width; c.h = (OPJ_UINT32) rows; c.prec = 16; c.sgnd = 0;
+    opj_image_t *im;
+    if (tiles == 1) {
+        im = J.image_create(1, &c, OPJ_CLRSPC_GRAY);
+        for (size_t i = 0; i < rows * width; i++) im->comps[0].data[i] = img[i];
+    } else {
+        im = J.image_tile_create(1, &c, OPJ_CLRSPC_GRAY);
+    }
+    im->x0 = 0; im->y0 = 0; im->x1 = (OPJ_UINT32) width; im->y1 = (OPJ_UINT32) rows;
     opj_codec_t *cd = J.create_compress(OPJ_CODEC_J2K);
-    J.setup_encoder(cd, &p, im);
+    if (!J.setup_encoder(cd, &p, im)) { J.image_destroy(im); J.destroy_codec(cd); return 0; }
     opj_stream_t *st = J.stream_default_create(OPJ_FALSE);
     mem_t m = { 0 };
     J.stream_set_user_data(st, &m, NULL);
     J.stream_set_user_data_length(st, 0);
     J.stream_set_write_function(st, mem_write);
     J.start_compress(cd, im, st);
-    J.encode(cd, st);
+    if (tiles > 1) {
+        for (size_t k = 0; k < tiles; k++)
+            J.write_tile(cd, (OPJ_UINT32) k, (OPJ_BYTE *) (img + k * height * width), (OPJ_UINT32) (height * width * sizeof(uint16_t)), st);
+    } else {
+        J.encode(cd, st);
+    }
     J.end_compress(cd, st);
     J.stream_destroy(st); J.image_destroy(im); J.destroy_codec(cd);
     *out = m.buf;
     return m.len;
+}
+
+size_t orc_opj_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out)
+{
+    return orc_opj_encode_tiled(img, 1, height, width, base_cr, out);
 }
 
 size_t orc_opj_decode(const uint8_t *cs, size_t n, int32_t **samples, size_t *h, size_t *w)

@@ -101,6 +101,8 @@ void orc_last_trace(orc_trace_t *t);
  * OpenJPEG (src/ebcc_codec.c:105-180): irreversible 9/7, 1 layer, rate = base_cr/2, 6 resolutions,
  * 64x64 code-blocks, LRCP, one tile.  *out malloc'd.  Returns bytes or 0. */
 size_t orc_j2k_encode(const uint16_t *img, size_t height, size_t width, float base_cr, uint8_t **out);
+/* `tiles` frames of height x width stacked along y, one tile each (ebcc_codec.c:105-180 with n_tiles > 1) */
+size_t orc_j2k_encode_tiled(const uint16_t *img, size_t tiles, size_t height, size_t width, float base_cr, uint8_t **out);
 
 /* Decode a codestream to int32 samples as OpenJPEG's opj_decode does (src/ebcc_codec.c:1092-1136
  * reads image->comps[0].data).  samples malloc'd. Returns number of pixels or 0. */

@@ -392,6 +392,13 @@ def scale_u16(field):
     return (((field - mn) / (mx - mn)) * np.float32(65535)).astype(np.uint16), mn, mx
 
 
+def opj_version():
+    """Version string of the libopenjp2 the oracle's optional backend found ('' = none)."""
+    lib = oracle()
+    lib.orc_opj_version.restype = ctypes.c_char_p
+    return (lib.orc_opj_version() or b"").decode()
+
+
 def orc_j2k_encode(img_u16, cr):
     lib = oracle()
     img = np.ascontiguousarray(img_u16, np.uint16)

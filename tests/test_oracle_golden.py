@@ -73,6 +73,35 @@ def test_frame_codec_streams(name, monkeypatch):
     assert sha(dec.tobytes()) == c["decoded_sha256"]
 
 
+_tiled = load("tiled.json")
+_tiled_inputs = np.load(os.path.join(L.GOLDEN, "tiled_inputs.npz"))
+
+
+@pytest.mark.parametrize("backend", [0, 1], ids=["restated-j2k", "openjpeg"])
+@pytest.mark.parametrize("name", sorted(_tiled["frames"]), ids=str)
+def test_multi_frame_chunk_streams(name, backend, monkeypatch):
+    """Chunks of several frames: one tile per frame (reference src/ebcc_codec.c:105-180), including frame heights that
+    put every tile at its own sub-band parity (the odd_* inputs)."""
+    c = _tiled["frames"][name]
+    for k in ("EBCC_INIT_BASE_ERROR_QUANTILE", "EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK"):
+        monkeypatch.delenv(k, raising=False)
+    if c["quantile"]:
+        monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", c["quantile"].split("+")[0])
+        if c["quantile"].endswith("+nofallback"):
+            monkeypatch.setenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", "1")
+    if backend == 1 and (not hasattr(L.oracle(), "orc_opj_version") or not L.opj_version()):
+        pytest.skip("OpenJPEG backend not available on this machine")
+    L.oracle().orc_set_j2k_backend(backend)
+    try:
+        x = _tiled_inputs[c["input"]]
+        cfg = L.make_config(x.shape, base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+        want = bytes.fromhex(c["stream_hex"])
+        assert L.orc_encode(x, cfg) == want
+        assert sha(L.orc_decode(want).tobytes()) == c["decoded_sha256"]
+    finally:
+        L.oracle().orc_set_j2k_backend(0)
+
+
 def test_residual_branch_is_exercised():
     assert sum(1 for c in _streams.values() if c["coeffs_size"] > 0) >= 4
 

@@ -133,7 +133,15 @@ int ebcc_hip_device_count(void)
 
 ebcc_hip_ctx *ebcc_hip_create(int device, size_t max_frames, size_t height, size_t width)
 {
-    if (height < 1 || width < 1 || height > 2047 || width > 2047 || max_frames < 1) {
+    return ebcc::create_engine(device, max_frames, height, width, 1);
+}
+
+}  // extern "C"
+
+ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, size_t width, int tile_period)
+{
+    if (height < 1 || width < 1 || height > 2047 || width > 2047 || max_frames < 1 || tile_period < 1 ||
+        (tile_period > 1 && (size_t) tile_period * height > 2047)) {
         set_error("ebcc_hip_create: unsupported geometry %zu x %zu x %zu", max_frames, height, width);
         return nullptr;
     }
@@ -147,6 +155,7 @@ ebcc_hip_ctx *ebcc_hip_create(int device, size_t max_frames, size_t height, size
     ctx->device = device;
     ctx->max_frames = max_frames;
     ctx->height = (int) height;
+    ctx->tile_period = tile_period;
     ctx->width = (int) width;
     ctx->n_pix = height * width;
     EBCC_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -193,6 +202,8 @@ ebcc_hip_ctx *ebcc_hip_create(int device, size_t max_frames, size_t height, size
     EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return ctx;
 }
+
+extern "C" {
 
 void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
 {

@@ -12,6 +12,7 @@ struct ebcc_hip_ctx {
     hipStream_t stream = nullptr;
     size_t max_frames = 0;
     int height = 0, width = 0;
+    int tile_period = 1;                   // > 1: frame f is tile f % tile_period of an image of that many tiles stacked along y (j2k.hpp)
     size_t n_pix = 0;                      // height * width
     size_t bytes = 0;                      // device bytes owned
     ebcc::ResidualBuffers rb{};
@@ -33,6 +34,8 @@ struct ebcc_hip_ctx {
 namespace ebcc {
 
 void set_error(const char *fmt, ...);
+// ebcc_hip_create for frames that are the tiles of images of `tile_period` tiles each (1: plain frames)
+ebcc_hip_ctx *create_engine(int device, size_t max_frames, size_t height, size_t width, int tile_period);
 template <typename T>
 T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count);
 

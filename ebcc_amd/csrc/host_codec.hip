@@ -12,6 +12,7 @@
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <tuple>
 #include <atomic>
 #include <mutex>
 #include <condition_variable>
@@ -26,7 +27,7 @@
 namespace ebcc {
 bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table);
 bool j2k_peek_dims(const uint8_t *cs, size_t n, int *W, int *H, int *tile_w, int *tile_h);
-bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kGeom &g, int tiles, int *tables, size_t *part_off, size_t *part_len);
+bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kBuffers &jb, int tiles, int *tables, size_t *part_off, size_t *part_len);
 }
 using namespace ebcc;
 
@@ -160,19 +161,21 @@ struct RateSearch {
 // context cache: one engine per (device, frame geometry), grown on demand
 // ================================================================================================
 std::mutex g_mutex;
-std::map<std::pair<int, int>, ebcc_hip_ctx *> g_ctx;
+std::map<std::tuple<int, int, int>, ebcc_hip_ctx *> g_ctx;
 
-ebcc_hip_ctx *get_context(int H, int W, size_t frames)
+// `period` > 1: the frames are the tiles of images of that many tiles each, every tile position with its own
+// JPEG 2000 geometry (j2k.hpp)
+ebcc_hip_ctx *get_context(int H, int W, size_t frames, int period = 1)
 {
-    auto key = std::make_pair(H, W);
+    auto key = std::make_tuple(H, W, period);
     auto it = g_ctx.find(key);
     if (it != g_ctx.end() && it->second->max_frames >= frames) return it->second;
     if (it != g_ctx.end()) { ebcc_hip_destroy(it->second); g_ctx.erase(it); }
-    ebcc_hip_ctx *c = ebcc_hip_create(0, frames, (size_t) H, (size_t) W);
+    ebcc_hip_ctx *c = create_engine(0, frames, (size_t) H, (size_t) W, period);
     if (!c && !g_ctx.empty()) {                                 // out of device memory: drop the engines of other geometries
         for (auto &kv : g_ctx) ebcc_hip_destroy(kv.second);
         g_ctx.clear();
-        c = ebcc_hip_create(0, frames, (size_t) H, (size_t) W);
+        c = create_engine(0, frames, (size_t) H, (size_t) W, period);
     }
     if (c) g_ctx[key] = c;
     return c;
@@ -828,7 +831,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     hipStream_t s = ctx->stream;
     const size_t n_pix = ctx->n_pix;
     const J2kGeom &g = jb.geom;
-    std::vector<int> table(n * (size_t) g.nblocks * 4, 0);
+    std::vector<int> table(n * (size_t) g.stride * 4, 0);
     std::vector<std::vector<uint8_t>> coeffs(n);
     PhaseTimer pt;
     fetch_frame_states(ctx, n);
@@ -850,7 +853,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
             if (cnt != n_pix) { log_fatal("const-field length %llu does not match the frame", (unsigned long long) cnt); return 1; }
         } else {
             if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return 1; }
-            if (!j2k_parse_codestream(tail, hd.tail_size, g, table.data() + f * g.nblocks * 4)) return 1;
+            if (!j2k_parse_codestream(tail, hd.tail_size, g, table.data() + f * g.stride * 4)) return 1;
             EBCC_HIP_CHECK(hipMemcpyAsync(jb.stream + f * jb.stream_cap, tail, hd.tail_size, hipMemcpyHostToDevice, s));
             if (hd.compressed_size > 0 && hd.coeffs_size > 0) {                                                    // :1294-1304
                 if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
@@ -913,9 +916,13 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
 }
 
 // Chunks of several frames: the tail is one codestream with a tile per frame (reference :121-125); the tiles are
-// decoded as frames of `ctx`, the residual of the whole chunk image in `rc`.  Tile heights for which every tile has
-// the geometry of a tile at the origin only (see tile_height_supported).
-bool tile_height_supported(size_t h) { return h >= 32 && h <= 1024 && (h & (h - 1)) == 0; }
+// decoded as frames of `ctx`, the residual of the whole chunk image in `rc`.
+// Frame heights a chunk of several frames can have: OpenJPEG cannot set up 6 resolutions on smaller tiles (the
+// reference crashes on them), and the chunk image itself is bounded by the reference's 2047-row limit.
+bool tile_height_supported(size_t h) { return h >= 32 && h <= 1023; }
+// Heights for which every tile has the geometry of a tile at the origin (sub-band extents, parity and code-block
+// partition repeat): the context then needs a single geometry for all tile positions.
+bool tile_geometry_uniform(size_t h) { return h >= 32 && h <= 1024 && (h & (h - 1)) == 0; }
 
 int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *streams, const size_t *sizes, size_t n, size_t tiles,
                  float *d_out)
@@ -924,7 +931,7 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
     hipStream_t s = ctx->stream, rs = rc->stream;
     const J2kGeom &g = jb.geom;
     const size_t tile_pix = ctx->n_pix, n_pix = tile_pix * tiles, nt = n * tiles;
-    std::vector<int> table(nt * (size_t) g.nblocks * 4, 0);
+    std::vector<int> table(nt * (size_t) g.stride * 4, 0);
     std::vector<std::vector<uint8_t>> coeffs(n);
     std::vector<size_t> off(tiles), len(tiles);
     bool any_resid = false;
@@ -946,7 +953,7 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
             if (cnt != n_pix) { log_fatal("const-field length %llu does not match the chunk", (unsigned long long) cnt); return 1; }
             continue;
         }
-        if (!j2k_parse_tiled(hd.tail, hd.tail_size, g, (int) tiles, table.data() + c * tiles * g.nblocks * 4, off.data(), len.data())) {
+        if (!j2k_parse_tiled(hd.tail, hd.tail_size, jb, (int) tiles, table.data() + c * tiles * g.stride * 4, off.data(), len.data())) {
             log_fatal("Invalid encoded data: %s", ebcc_hip_last_error());
             return 1;
         }
@@ -1002,12 +1009,13 @@ bool chunk_engines(int H, int W, size_t chunks, size_t tiles, ebcc_hip_ctx **ctx
         *rc = get_context((int) (tiles * (size_t) H), W, chunks);
         if (!*rc) return false;
     }
-    *ctx = get_context(H, W, chunks * tiles);
+    const int period = tiles > 1 && !tile_geometry_uniform((size_t) H) ? (int) tiles : 1;
+    *ctx = get_context(H, W, chunks * tiles, period);
     if (!*ctx) return false;
     if (tiles > 1) {                                             // (creating the second engine may have evicted the first)
         *rc = get_context((int) (tiles * (size_t) H), W, chunks);
         if (!*rc) return false;
-        if (g_ctx.find(std::make_pair(H, W)) == g_ctx.end()) return false;
+        if (g_ctx.find(std::make_tuple(H, W, period)) == g_ctx.end()) return false;
     }
     return true;
 }
@@ -1150,10 +1158,10 @@ size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
     }
     print_config(config);
     if (config->dims[0] != 1 && !tile_height_supported(config->dims[1])) {
-        // the reference codes such a chunk as one tiled JPEG 2000 image (src/ebcc_codec.c:121-125,167-171); a tile away
-        // from the origin has its own sub-band and code-block geometry unless the tile height is a power of two
-        log_fatal("chunks holding %lu frames of %lu rows are not supported by the MI355X build yet (multi-frame chunks need a "
-                  "power-of-two frame height between 32 and 1024); use one frame per chunk", config->dims[0], config->dims[1]);
+        // the reference codes such a chunk as one tiled JPEG 2000 image (src/ebcc_codec.c:121-125,167-171) and crashes
+        // inside OpenJPEG when the tiles are too small for 6 resolutions
+        log_fatal("chunks holding %lu frames of %lu rows are not supported (a chunk of several frames is a tiled JPEG 2000 "
+                  "image: tiles need at least 32 rows)", config->dims[0], config->dims[1]);
         return 0;
     }
     size_t size = 0;
@@ -1184,7 +1192,7 @@ size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
     }
     const size_t tiles = (size_t) (H / th);
     if (tiles > 1 && !tile_height_supported((size_t) th)) {
-        log_fatal("streams with %zu tiles of %d rows are not supported by the MI355X build yet", tiles, th);
+        log_fatal("streams with %zu tiles of %d rows are not supported", tiles, th);
         return 0;
     }
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -1225,8 +1233,8 @@ size_t ebcc_encode_chunking(float *data, codec_config_t *config, uint8_t **out_b
         cnt[i] = cdiv(config->dims[i], cd[i]);
     }
     if (cd[0] != 1 && !tile_height_supported(cd[1])) {
-        log_fatal("chunks holding %lu frames of %lu rows are not supported by the MI355X build yet (multi-frame chunks need a "
-                  "power-of-two frame height between 32 and 1024); use chunk_dims[0] = 1", cd[0], cd[1]);
+        log_fatal("chunks holding %lu frames of %lu rows are not supported (a chunk of several frames is a tiled JPEG 2000 "
+                  "image: tiles need at least 32 rows); use chunk_dims[0] = 1", cd[0], cd[1]);
         return 0;
     }
     const size_t csize = cd[0] * cd[1] * cd[2], nchunks = cnt[0] * cnt[1] * cnt[2];
@@ -1324,7 +1332,7 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     const size_t csize = cd[0] * cd[1] * cd[2], nchunks = cnt[0] * cnt[1] * cnt[2], total = dims[0] * dims[1] * dims[2];
     if (hd.chunk_size != csize || hd.num_chunks != nchunks) { log_fatal("Invalid chunked EBCC data: inconsistent chunk metadata"); return 0; }
     if (cd[0] != 1 && !tile_height_supported(cd[1])) {
-        log_fatal("chunks holding %lu frames of %lu rows are not supported by the MI355X build yet", cd[0], cd[1]);
+        log_fatal("chunks holding %lu frames of %lu rows are not supported", cd[0], cd[1]);
         return 0;
     }
     std::vector<const uint8_t *> ptrs(nchunks);

@@ -1,5 +1,6 @@
 // j2k.hip - base-layer buffers of a context, host-side codestream parsing for the decode path and the
 // unit-level C-ABI entry points of the JPEG 2000 layer (include/ebcc_hip.h).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -13,20 +14,28 @@ bool j2k_create(ebcc_hip_ctx *ctx)
 {
     J2kBuffers *jb = new J2kBuffers();
     ctx->j2k = jb;
-    std::vector<J2kBlock> blocks;
-    jb->geom = make_j2k_geom(ctx->height, ctx->width, blocks);
+    // one geometry per tile position (j2k.hpp); plain frames: one
+    const int period = ctx->tile_period;
+    std::vector<std::vector<J2kBlock>> tile_blocks((size_t) period);
+    int stride = 0;
+    for (int k = 0; k < period; k++) {
+        jb->geoms.push_back(make_j2k_geom(ctx->height, ctx->width, tile_blocks[(size_t) k], k * ctx->height));
+        stride = std::max(stride, jb->geoms.back().nblocks);
+    }
+    for (J2kGeom &t : jb->geoms) { t.period = period; t.stride = stride; }
+    jb->geom = jb->geoms[0];
     const J2kGeom &g = jb->geom;
     const size_t n_pix = ctx->n_pix, F = ctx->max_frames;
-    const size_t total = F * g.nblocks, groups = (total + 63) / 64;
+    const size_t total = F * (size_t) stride, groups = (total + 63) / 64;
     jb->max_frames = (int) F;
     jb->fs = ctx->rb.fs;
     // the largest codestream keeps every pass: bounded by the code-block slots; 2 bytes/sample is far above
     // anything the 9/7 + MQ coder emits for 16-bit data, and the writer never exceeds the slots it copies from
     jb->stream_cap = ((n_pix * 3 + 4096 + 63) / 64) * 64;
     bool ok = true;
-    ok &= (jb->d_geom = (J2kGeom *) ctx_alloc<uint8_t>(ctx, sizeof(J2kGeom))) != nullptr;
-    ok &= (jb->d_blocks = (J2kBlock *) ctx_alloc<uint8_t>(ctx, sizeof(J2kBlock) * blocks.size())) != nullptr;
-    ok &= (jb->d_blkmap = ctx_alloc<uint16_t>(ctx, n_pix)) != nullptr;
+    ok &= (jb->d_geom = (J2kGeom *) ctx_alloc<uint8_t>(ctx, sizeof(J2kGeom) * (size_t) period)) != nullptr;
+    ok &= (jb->d_blocks = (J2kBlock *) ctx_alloc<uint8_t>(ctx, sizeof(J2kBlock) * (size_t) period * (size_t) stride)) != nullptr;
+    ok &= (jb->d_blkmap = ctx_alloc<uint16_t>(ctx, (size_t) period * n_pix)) != nullptr;
     ok &= (jb->B = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
     ok &= (jb->Q6 = ctx_alloc<int32_t>(ctx, F * n_pix)) != nullptr;
     ok &= (jb->DEC = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
@@ -61,15 +70,20 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->partial = ctx_alloc<double>(ctx, F * kPartials)) != nullptr;
     ok &= (jb->partial_u = ctx_alloc<unsigned long long>(ctx, F * kPartials)) != nullptr;
     if (!ok) return false;
-    if (g.nblocks >= 65535) { set_error("too many code-blocks"); return false; }
-    std::vector<uint16_t> map(n_pix, 0);
-    for (size_t b = 0; b < blocks.size(); b++)
-        for (int y = 0; y < blocks[b].h; y++)
-            for (int x = 0; x < blocks[b].w; x++) map[(size_t) (blocks[b].y + y) * g.W + blocks[b].x + x] = (uint16_t) b;
+    if (stride >= 65535) { set_error("too many code-blocks"); return false; }
+    std::vector<uint16_t> map((size_t) period * n_pix, 0);
+    std::vector<J2kBlock> blocks((size_t) period * (size_t) stride, J2kBlock{});
+    for (int k = 0; k < period; k++) {
+        const std::vector<J2kBlock> &tb = tile_blocks[(size_t) k];
+        std::copy(tb.begin(), tb.end(), blocks.begin() + (size_t) k * (size_t) stride);
+        for (size_t b = 0; b < tb.size(); b++)
+            for (int y = 0; y < tb[b].h; y++)
+                for (int x = 0; x < tb[b].w; x++) map[(size_t) k * n_pix + (size_t) (tb[b].y + y) * g.W + tb[b].x + x] = (uint16_t) b;
+    }
     hipStream_t s = ctx->stream;
-    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_geom, &jb->geom, sizeof(J2kGeom), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_geom, jb->geoms.data(), sizeof(J2kGeom) * (size_t) period, hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blocks, blocks.data(), sizeof(J2kBlock) * blocks.size(), hipMemcpyHostToDevice, s));
-    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blkmap, map.data(), n_pix * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blkmap, map.data(), map.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return true;
@@ -194,7 +208,7 @@ bool parse_tile_part(const uint8_t *cs, size_t n, size_t sot, const uint8_t *ori
     const uint8_t *tile_data = cs + pos + 2;
     const uint8_t *tile_end = psot ? cs + sot + psot : cs + n - 2;
     if (tile_end > cs + n || tile_end < tile_data) { set_error("J2K: tile-part overruns the stream"); return false; }
-    std::memset(table, 0, sizeof(int) * 4 * (size_t) g.nblocks);
+    std::memset(table, 0, sizeof(int) * 4 * (size_t) g.stride);
     p = tile_data;
     for (int r = 0; r < kJ2kRes; r++) {
         BitReader br{p, tile_end};
@@ -260,12 +274,14 @@ bool j2k_peek_dims(const uint8_t *cs, size_t n, int *W, int *H, int *tile_w, int
     return true;
 }
 
-// A codestream of `tiles` tiles of the context's geometry stacked along y (what the reference writes for a
+// A codestream of `tiles` tiles of the context's frame size stacked along y (what the reference writes for a
 // chunk of several frames): tables[t] as above with offsets relative to the tile-part's SOT, and the extent of
-// every tile-part inside cs.
-bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kGeom &g, int tiles, int *tables /* [tiles][nblocks][4] */,
+// every tile-part inside cs.  Tile t is parsed with the context's geometry for that tile position.
+bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kBuffers &jb, int tiles, int *tables /* [tiles][stride][4] */,
                      size_t *part_off, size_t *part_len)
 {
+    const J2kGeom &g = jb.geom;
+    if (g.period > 1 && g.period != tiles) { set_error("J2K: the context holds %d tile positions, the chunk %d", g.period, tiles); return false; }
     MainHeader h;
     if (!parse_main_header(cs, n, h)) return false;
     if (h.W != g.W || h.H != g.H * tiles || h.tile_w != g.W || h.tile_h != g.H || !header_matches(h, g)) {
@@ -280,7 +296,7 @@ bool j2k_parse_tiled(const uint8_t *cs, size_t n, const J2kGeom &g, int tiles, i
         if (pos + 12 > n || be16(cs + pos) != 0xFF90) { set_error("J2K: fewer tile-parts than tiles"); return false; }
         const int peek = (int) be16(cs + pos + 4);
         if (peek < 0 || peek >= tiles || seen[(size_t) peek]) { set_error("J2K: bad tile index %d", peek); return false; }
-        if (!parse_tile_part(cs, n, pos, cs + pos, g, tables + (size_t) peek * g.nblocks * 4, &isot, &next)) return false;
+        if (!parse_tile_part(cs, n, pos, cs + pos, jb.geoms[(size_t) j2k_geom_index(&g, peek)], tables + (size_t) peek * g.stride * 4, &isot, &next)) return false;
         seen[(size_t) peek] = 1;
         part_off[peek] = pos;
         part_len[peek] = next - pos;
@@ -362,11 +378,11 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx
     J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
     hipStream_t s = ctx->stream;
     const J2kGeom &g = jb.geom;
-    std::vector<int> table((size_t) n_frames * g.nblocks * 4);
+    std::vector<int> table((size_t) n_frames * g.stride * 4);
     fetch_frame_states(ctx, n_frames);
     for (size_t f = 0; f < n_frames; f++) {
         if (sizes[f] > jb.stream_cap) { set_error("codestream larger than the slot"); return 1; }
-        if (!j2k_parse_codestream(streams[f], sizes[f], g, table.data() + f * g.nblocks * 4)) return 1;
+        if (!j2k_parse_codestream(streams[f], sizes[f], g, table.data() + f * g.stride * 4)) return 1;
         EBCC_HIP_CHECK(hipMemcpyAsync(jb.stream + f * jb.stream_cap, streams[f], sizes[f], hipMemcpyHostToDevice, s));
         ctx->h_fs[f].minv = minmax[2 * f];
         ctx->h_fs[f].maxv = minmax[2 * f + 1];

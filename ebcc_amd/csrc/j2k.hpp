@@ -4,6 +4,8 @@
 // 64x64 code-blocks, LRCP, 1 quality layer with rate base_cr/2 - bit-exact with OpenJPEG 2.4.0.
 #pragma once
 
+#include <vector>
+
 #include "common.hpp"
 #include "residual.hpp"
 
@@ -37,13 +39,33 @@ struct J2kBlock {
     int cx, cy;                  // position in the band's code-block grid
 };
 
-// geometry shared by all frames of a context (device + host copies)
+// Geometry of a tile of H x W samples whose first row is row ty0 of the image (device + host copies).  A context
+// whose frames are the frames themselves has one geometry (ty0 = 0).  A context whose frames are the tiles of
+// chunks of `period` frames stacked along y (one JPEG 2000 image per chunk, a tile per frame) has `period`
+// geometries, frame f using number f % period: away from the image origin a tile has its own sub-band extents,
+// low/high-pass parity and code-block partition (T.800 B.5-B.7) unless its height is a multiple of 64 * 2^5.
+// Per-code-block arrays are laid out with the common `stride` >= nblocks of every geometry of the context.
 struct J2kGeom {
     int W, H, nblocks, nbands, tree_nodes;
+    int ty0;                      // first row of the tile in the image
+    int period, stride;           // geometries in this context; code-block slots per frame
     int rw[kJ2kRes], rh[kJ2kRes];
+    int ry0[kJ2kRes];             // first row of every resolution in its own coordinates (its parity = first sample is a high-pass one)
     int res_first[kJ2kRes + 1];   // first code-block of every resolution (packet order)
     J2kBand bands[kJ2kBands];
 };
+
+// the geometry, code-blocks and code-block map of a frame of the context
+__host__ __device__ inline int j2k_geom_index(const J2kGeom *g, int frame) { return g->period > 1 ? frame % g->period : 0; }
+__host__ __device__ inline const J2kGeom &j2k_frame_geom(const J2kGeom *g, int frame) { return g[j2k_geom_index(g, frame)]; }
+__host__ __device__ inline const J2kBlock *j2k_frame_blocks(const J2kGeom *g, const J2kBlock *blocks, int frame)
+{
+    return blocks + (size_t) j2k_geom_index(g, frame) * (size_t) g->stride;
+}
+__host__ __device__ inline const std::uint16_t *j2k_frame_blkmap(const J2kGeom *g, const std::uint16_t *map, int frame)
+{
+    return map + (size_t) j2k_geom_index(g, frame) * ((size_t) g->W * (size_t) g->H);
+}
 
 constexpr int kJ2kSymCap = 4096 * (kJ2kMaxPlanes + 1) + 2048;  // decision stream of one code-block: at most planes + 1 decisions per sample, plus stripe markers
 constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
@@ -78,10 +100,11 @@ struct J2kFrame {                 // per-frame scalars (device)
 };
 
 struct J2kBuffers {
-    J2kGeom geom;                 // host copy
-    J2kGeom *d_geom;
-    J2kBlock *d_blocks;
-    std::uint16_t *d_blkmap;      // [H*W] code-block id of every tile-buffer position
+    J2kGeom geom;                 // host copy of the first geometry
+    std::vector<J2kGeom> geoms;   // host copies of all of them (J2kGeom::period entries)
+    J2kGeom *d_geom;              // [period]
+    J2kBlock *d_blocks;           // [period][stride]
+    std::uint16_t *d_blkmap;      // [period][H*W] code-block id of every tile-buffer position
     int max_frames;
     float *B;                     // [frames][H*W] tile buffer (coefficients / samples)
     int32_t *Q6;                  // [frames][H*W] quantised coefficients with 6 fractional bits
@@ -122,7 +145,7 @@ struct J2kBuffers {
 enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
 int t1_lanes_per_wave(int kernel);
 
-J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks);
+J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks, int ty0 = 0);
 
 // ---- launchers (asynchronous on s) ---------------------------------------------------------------
 // check_nan_inf + findMinMaxf (ebcc_codec.c:598-605,515-533) -> fs.minv/maxv/const_field/has_nonfinite

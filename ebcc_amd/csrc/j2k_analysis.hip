@@ -43,14 +43,16 @@ int t1_lanes_per_wave(int kernel)
     return t[kernel & 3];
 }
 
-J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
+J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks, int ty0)
 {
     J2kGeom g{};
-    g.W = W; g.H = H;
-    const int prec = 16, guard = 2;
+    g.W = W; g.H = H; g.ty0 = ty0; g.period = 1;
+    const int prec = 16, guard = 2, ty1 = ty0 + H;
     for (int r = 0; r < kJ2kRes; r++) {
-        g.rw[r] = ceildivpow2(W, kJ2kRes - 1 - r);
-        g.rh[r] = ceildivpow2(H, kJ2kRes - 1 - r);
+        const int lv = kJ2kRes - 1 - r;
+        g.rw[r] = ceildivpow2(W, lv);
+        g.ry0[r] = ceildivpow2(ty0, lv);
+        g.rh[r] = ceildivpow2(ty1, lv) - g.ry0[r];
     }
     blocks.clear();
     int bi = 0, nodes = 0;
@@ -63,14 +65,15 @@ J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
             bd.res = r; bd.level = lv;
             if (r == 0) {
                 bd.orient = 0;
-                bd.x0 = 0; bd.y0 = 0; bd.x1 = g.rw[0]; bd.y1 = g.rh[0];
+                bd.x0 = 0; bd.y0 = g.ry0[0]; bd.x1 = g.rw[0]; bd.y1 = g.ry0[0] + g.rh[0];
                 bd.offx = 0; bd.offy = 0;
             } else {
                 bd.orient = b + 1;
                 int xb = bd.orient & 1, yb = bd.orient >> 1;
-                bd.x0 = 0; bd.y0 = 0;                               // tile origin is (0,0)
+                bd.x0 = 0;                                          // tiles span the image width
+                bd.y0 = std::max(0, ceildivpow2(ty0 - (yb << lv), lv + 1));          // T.800 B-15
                 bd.x1 = ceildivpow2(W - (xb << lv), lv + 1);
-                bd.y1 = ceildivpow2(H - (yb << lv), lv + 1);
+                bd.y1 = ceildivpow2(ty1 - (yb << lv), lv + 1);
                 bd.offx = xb ? g.rw[r - 1] : 0;
                 bd.offy = yb ? g.rh[r - 1] : 0;
             }
@@ -88,15 +91,17 @@ J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
             int bw = bd.x1 - bd.x0, bh = bd.y1 - bd.y0;
             bd.first_block = (int) blocks.size();
             if (bw <= 0 || bh <= 0) { bd.ncw = bd.nch = 0; bd.tree_levels = 0; bd.tree_off = nodes; continue; }
-            bd.ncw = (bd.x1 + 63) / 64;
-            bd.nch = (bd.y1 + 63) / 64;
+            // the code-block partition is anchored at multiples of 64 of the band coordinates (B.7)
+            const int gx0 = bd.x0 / 64, gy0 = bd.y0 / 64;
+            bd.ncw = (bd.x1 + 63) / 64 - gx0;
+            bd.nch = (bd.y1 + 63) / 64 - gy0;
             for (int cy = 0; cy < bd.nch; cy++)
                 for (int cx = 0; cx < bd.ncw; cx++) {
                     J2kBlock k{};
                     k.band = bi; k.cx = cx; k.cy = cy;
-                    int x0 = cx * 64, y0 = cy * 64;
-                    int x1 = std::min(x0 + 64, bd.x1), y1 = std::min(y0 + 64, bd.y1);
-                    k.x = bd.offx + x0; k.y = bd.offy + y0; k.w = x1 - x0; k.h = y1 - y0;
+                    int x0 = std::max((gx0 + cx) * 64, bd.x0), y0 = std::max((gy0 + cy) * 64, bd.y0);
+                    int x1 = std::min((gx0 + cx) * 64 + 64, bd.x1), y1 = std::min((gy0 + cy) * 64 + 64, bd.y1);
+                    k.x = bd.offx + x0 - bd.x0; k.y = bd.offy + y0 - bd.y0; k.w = x1 - x0; k.h = y1 - y0;
                     blocks.push_back(k);
                 }
             // tag-tree level layout (B.10.2)
@@ -114,6 +119,7 @@ J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks)
     }
     g.nbands = bi;
     g.nblocks = (int) blocks.size();
+    g.stride = g.nblocks;
     g.res_first[kJ2kRes] = g.nblocks;
     g.tree_nodes = nodes;
     return g;
@@ -248,28 +254,45 @@ __device__ inline void istep_hi(float *E, float *O, int sn, int dn, int lines, I
     __syncthreads();
 }
 
+// E = low-pass samples, O = high-pass samples of a line that starts with a low-pass sample (cas = 0: rows, and the
+// columns of a tile whose first row at this resolution is even) or with a high-pass one (cas = 1: the neighbour
+// relations of the two lifting steps swap; opj_dwt_encode_1_real / opj_v8dwt_decode with cas)
 template <typename Idx>
-__device__ inline void fdwt_tile(float *E, float *O, int sn, int dn, int lines, Idx at, int tid, int nt)
+__device__ inline void fdwt_tile(float *E, float *O, int sn, int dn, int lines, Idx at, int tid, int nt, int cas = 0)
 {
     const float invK = (float) (1.0 / 1.230174105);
-    fstep_hi(E, O, sn, dn, lines, at, kA, tid, nt);
-    fstep_lo(E, O, sn, dn, lines, at, kB, tid, nt);
-    fstep_hi(E, O, sn, dn, lines, at, kG, tid, nt);
-    fstep_lo(E, O, sn, dn, lines, at, kD, tid, nt);
+    if (cas == 0) {
+        fstep_hi(E, O, sn, dn, lines, at, kA, tid, nt);
+        fstep_lo(E, O, sn, dn, lines, at, kB, tid, nt);
+        fstep_hi(E, O, sn, dn, lines, at, kG, tid, nt);
+        fstep_lo(E, O, sn, dn, lines, at, kD, tid, nt);
+    } else {
+        fstep_lo(O, E, dn, sn, lines, at, kA, tid, nt);
+        fstep_hi(O, E, dn, sn, lines, at, kB, tid, nt);
+        fstep_lo(O, E, dn, sn, lines, at, kG, tid, nt);
+        fstep_hi(O, E, dn, sn, lines, at, kD, tid, nt);
+    }
     for (int t = tid; t < sn * lines; t += nt) { int i = t / lines, l = t - i * lines; E[at(i, l)] *= invK; }
     for (int t = tid; t < dn * lines; t += nt) { int i = t / lines, l = t - i * lines; O[at(i, l)] *= kK; }
     __syncthreads();
 }
 template <typename Idx>
-__device__ inline void idwt_tile(float *E, float *O, int sn, int dn, int lines, Idx at, int tid, int nt)
+__device__ inline void idwt_tile(float *E, float *O, int sn, int dn, int lines, Idx at, int tid, int nt, int cas = 0)
 {
     for (int t = tid; t < sn * lines; t += nt) { int i = t / lines, l = t - i * lines; E[at(i, l)] = E[at(i, l)] * kK; }
     for (int t = tid; t < dn * lines; t += nt) { int i = t / lines, l = t - i * lines; O[at(i, l)] = O[at(i, l)] * kTwoInvK; }
     __syncthreads();
-    istep_lo(E, O, sn, dn, lines, at, -kD, tid, nt);
-    istep_hi(E, O, sn, dn, lines, at, -kG, tid, nt);
-    istep_lo(E, O, sn, dn, lines, at, -kB, tid, nt);
-    istep_hi(E, O, sn, dn, lines, at, -kA, tid, nt);
+    if (cas == 0) {
+        istep_lo(E, O, sn, dn, lines, at, -kD, tid, nt);
+        istep_hi(E, O, sn, dn, lines, at, -kG, tid, nt);
+        istep_lo(E, O, sn, dn, lines, at, -kB, tid, nt);
+        istep_hi(E, O, sn, dn, lines, at, -kA, tid, nt);
+    } else {
+        istep_hi(O, E, dn, sn, lines, at, -kD, tid, nt);
+        istep_lo(O, E, dn, sn, lines, at, -kG, tid, nt);
+        istep_hi(O, E, dn, sn, lines, at, -kB, tid, nt);
+        istep_lo(O, E, dn, sn, lines, at, -kA, tid, nt);
+    }
 }
 
 struct RowIdx { __device__ int operator()(int k, int) const { return k; } };
@@ -277,67 +300,74 @@ template <int CW> struct ColIdx { __device__ int operator()(int k, int l) const 
 
 constexpr int kRowT = 256, kColT = 1024;
 
-// rows of the region [0,n) x [0,rows) of the tile buffer, in place
+// rows of the region [0,n) x [0,rows) of the tile buffer at resolution r, in place (the horizontal extents are the
+// same for every tile: tiles span the image width)
 template <bool FWD>
-__global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, int W, size_t frame_stride, int n, int sn,
-                                                     int rows, const FrameState *fs, const int *active)
+__global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, const J2kGeom *geom, int r, const FrameState *fs,
+                                                     const int *active)
 {
     extern __shared__ float sm[];
     const int frame = blockIdx.y;
     if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    const int W = g.W, n = g.rw[r], sn = g.rw[r - 1], rows = g.rh[r];
     const int dn = n - sn, tid = threadIdx.x;
     float *E = sm, *O = sm + sn;
-    float *buf = B + (size_t) frame * frame_stride;
+    float *buf = B + (size_t) frame * ((size_t) W * g.H);
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        float *r = buf + (size_t) row * W;
+        float *line = buf + (size_t) row * W;
         if (FWD) {
-            for (int i = tid; i < n; i += kRowT) { float v = r[i]; ((i & 1) ? O : E)[i >> 1] = v; }
+            for (int i = tid; i < n; i += kRowT) { float v = line[i]; ((i & 1) ? O : E)[i >> 1] = v; }
         } else {
-            for (int i = tid; i < sn; i += kRowT) E[i] = r[i];
-            for (int i = tid; i < dn; i += kRowT) O[i] = r[sn + i];
+            for (int i = tid; i < sn; i += kRowT) E[i] = line[i];
+            for (int i = tid; i < dn; i += kRowT) O[i] = line[sn + i];
         }
         __syncthreads();
         if (FWD) {
             fdwt_tile(E, O, sn, dn, 1, RowIdx(), tid, kRowT);
-            for (int i = tid; i < sn; i += kRowT) r[i] = E[i];
-            for (int i = tid; i < dn; i += kRowT) r[sn + i] = O[i];
+            for (int i = tid; i < sn; i += kRowT) line[i] = E[i];
+            for (int i = tid; i < dn; i += kRowT) line[sn + i] = O[i];
         } else {
             idwt_tile(E, O, sn, dn, 1, RowIdx(), tid, kRowT);
-            for (int i = tid; i < n; i += kRowT) r[i] = ((i & 1) ? O : E)[i >> 1];
+            for (int i = tid; i < n; i += kRowT) line[i] = ((i & 1) ? O : E)[i >> 1];
         }
         __syncthreads();
     }
 }
 
-// columns of the region [0,cols) x [0,n), CW columns per tile staged through LDS, in place
+// columns of the region [0,cols) x [0,n) at resolution r, CW columns per tile staged through LDS, in place.  The
+// number of rows, of low-pass rows and the parity of the first row belong to the frame's tile position.
 template <bool FWD, int CW>
-__global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, int W, size_t frame_stride, int n, int sn,
-                                                     int cols, const FrameState *fs, const int *active)
+__global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const J2kGeom *geom, int r, const FrameState *fs,
+                                                     const int *active)
 {
     extern __shared__ float sm[];
     const int frame = blockIdx.y;
     if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    const int W = g.W, n = g.rh[r], sn = g.rh[r - 1], cols = g.rw[r], cas = g.ry0[r] & 1;
+    if (n <= 1) return;
     const int dn = n - sn, tid = threadIdx.x;
     float *E = sm, *O = sm + (size_t) sn * CW;
-    float *buf = B + (size_t) frame * frame_stride;
+    float *buf = B + (size_t) frame * ((size_t) W * g.H);
     const int ntiles = (cols + CW - 1) / CW;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int x0 = tile * CW, w = min(CW, cols - x0);
         for (int t = tid; t < n * CW; t += kColT) {
             int y = t / CW, c = t - y * CW;
             float v = c < w ? buf[(size_t) y * W + x0 + c] : 0.0f;
-            if (FWD) ((y & 1) ? O : E)[(y >> 1) * CW + c] = v;
+            if (FWD) (((y ^ cas) & 1) ? O : E)[(y >> 1) * CW + c] = v;
             else     (y < sn ? E : O)[(y < sn ? y : y - sn) * CW + c] = v;
         }
         __syncthreads();
-        if (FWD) fdwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT);
-        else     idwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT);
+        if (FWD) fdwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT, cas);
+        else     idwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT, cas);
         for (int t = tid; t < n * CW; t += kColT) {
             int y = t / CW, c = t - y * CW;
             if (c < w) {
                 float v;
                 if (FWD) v = (y < sn ? E : O)[(y < sn ? y : y - sn) * CW + c];
-                else     v = ((y & 1) ? O : E)[(y >> 1) * CW + c];
+                else     v = (((y ^ cas) & 1) ? O : E)[(y >> 1) * CW + c];
                 buf[(size_t) y * W + x0 + c] = v;
             }
         }
@@ -353,32 +383,37 @@ void big_lds(K k, size_t bytes)
                                            (int) bytes));
 }
 
-template <bool FWD>
-void dwt_cols(float *B, const J2kGeom &g, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+// most rows any tile position has at resolution r
+static int max_rows(const J2kBuffers &jb, int r)
 {
-    int n = g.rh[r], sn = g.rh[r - 1], cols = g.rw[r];
+    int n = 0;
+    for (const J2kGeom &t : jb.geoms) n = std::max(n, t.rh[r]);
+    return n;
+}
+
+template <bool FWD>
+void dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+{
+    const int n = max_rows(jb, r), cols = jb.geom.rw[r];
     if (n <= 1) return;
     if ((size_t) n * 32 * 4 <= 156 * 1024) {
         size_t lds = (size_t) n * 32 * 4;
         auto k = k_j2k_cols<FWD, 32>;
         big_lds(k, lds);
-        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 32), n_frames), dim3(kColT), lds, s, B, g.W, (size_t) g.W * g.H, n, sn, cols,
-                           fs, active);
+        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 32), n_frames), dim3(kColT), lds, s, B, jb.d_geom, r, fs, active);
     } else {
         size_t lds = (size_t) n * 16 * 4;
         auto k = k_j2k_cols<FWD, 16>;
         big_lds(k, lds);
-        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 16), n_frames), dim3(kColT), lds, s, B, g.W, (size_t) g.W * g.H, n, sn, cols,
-                           fs, active);
+        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 16), n_frames), dim3(kColT), lds, s, B, jb.d_geom, r, fs, active);
     }
 }
 template <bool FWD>
-void dwt_rows(float *B, const J2kGeom &g, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+void dwt_rows(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
 {
-    int n = g.rw[r], sn = g.rw[r - 1], rows = g.rh[r];
+    const int n = jb.geom.rw[r], rows = max_rows(jb, r);
     if (n <= 1) return;
-    hipLaunchKernelGGL(k_j2k_rows<FWD>, dim3(min(rows, 96), n_frames), dim3(kRowT), (size_t) n * 4, s, B, g.W,
-                       (size_t) g.W * g.H, n, sn, rows, fs, active);
+    hipLaunchKernelGGL(k_j2k_rows<FWD>, dim3(min(rows, 96), n_frames), dim3(kRowT), (size_t) n * 4, s, B, jb.d_geom, r, fs, active);
 }
 
 // ================================================================================================
@@ -392,13 +427,15 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
     __shared__ int smax[4];
     const int frame = blockIdx.y, bi = blockIdx.x;
     if (fs[frame].const_field) return;
+    const int gid = frame * geom->stride + bi;
+    blocks = j2k_frame_blocks(geom, blocks, frame);                   // (slots past the tile's last code-block hold empty ones)
+    geom = &j2k_frame_geom(geom, frame);
     const J2kBlock blk = blocks[bi];
     const float step = geom->bands[blk.band].step_enc;
     const int W = geom->W;
     const size_t n_pix = (size_t) W * geom->H;
     const float *b = B + (size_t) frame * n_pix;
     int32_t *q = Q6 + (size_t) frame * n_pix;
-    const int gid = frame * geom->nblocks + bi;
     const size_t grp = (size_t) (gid >> 6);
     const int gl = gid & 63;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -543,9 +580,11 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
     const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
-    const int nb = geom->nblocks;
+    const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
     if (fs[frame].const_field) return;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
     const J2kBlock blk = blocks[bi];
     const int orient = geom->bands[blk.band].orient;
     const int m = blkmax[gid];
@@ -614,9 +653,11 @@ __global__ __launch_bounds__(64) void k_t1_symbols(unsigned long long *T1S, cons
     const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
     const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
-    const int nb = geom->nblocks;
+    const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
     if (fs[frame].const_field) return;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
     const J2kBlock blk = blocks[bi];
     const int orient = geom->bands[blk.band].orient;
     const int m = blkmax[gid];
@@ -702,9 +743,11 @@ __global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t
     const int gid0 = blockIdx.x * lpw;
     const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
-    const int nb = geom->nblocks;
+    const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
     if (fs[frame].const_field) return;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
     const int np = totalpasses[gid];
     if (numbps[gid] <= 0 || np <= 0) return;
     const J2kBlock blk = blocks[bi];
@@ -734,7 +777,9 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
     __shared__ short lut[4 * 128];
     const int frame = blockIdx.y, bi = blockIdx.x;
     if (fs[frame].const_field) return;
-    const int gid = frame * geom->nblocks + bi;
+    const int gid = frame * geom->stride + bi;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
     const int P = numbps[gid], np = totalpasses[gid];
     if (np <= 0) return;
     for (int i = threadIdx.x; i < kJ2kMaxPasses; i += 256) nms[i] = 0;
@@ -824,16 +869,16 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     const FrameState *fs = jb.fs;
     const J2kGeom &g = jb.geom;
     const size_t n_pix = (size_t) g.W * g.H;
-    const int total = n_frames * g.nblocks;
+    const int total = n_frames * g.stride;
     const size_t groups = ((size_t) total + 63) / 64;
     hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
     timing_begin("j2k_dwt_fwd", s);
     for (int r = kJ2kRes - 1; r >= 1; r--) {                           // opj_dwt_encode_procedure: vertical, then horizontal
-        dwt_cols<true>(jb.B, g, r, n_frames, fs, nullptr, s);
-        dwt_rows<true>(jb.B, g, r, n_frames, fs, nullptr, s);
+        dwt_cols<true>(jb.B, jb, r, n_frames, fs, nullptr, s);
+        dwt_rows<true>(jb.B, jb, r, n_frames, fs, nullptr, s);
     }
     timing_end("j2k_dwt_fwd", s);
-    hipLaunchKernelGGL(k_quantize, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
+    hipLaunchKernelGGL(k_quantize, dim3(g.stride, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
                        jb.d_geom, jb.d_blocks, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.SPS, 0, groups * 64 * 64 * sizeof(unsigned long long), s));
@@ -858,16 +903,16 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
         timing_end("t1_mq", s);
     }
     timing_end("t1_encode", s);
-    hipLaunchKernelGGL(k_distortion, dim3(g.nblocks, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
+    hipLaunchKernelGGL(k_distortion, dim3(g.stride, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
 }
 
 // inverse transform of the tile buffers, used by both decode flavours (j2k_rate.hip)
-void j2k_inverse_dwt(float *B, const J2kGeom &g, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+void j2k_inverse_dwt(float *B, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
 {
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
-        dwt_rows<false>(B, g, r, n_frames, fs, active, s);
-        dwt_cols<false>(B, g, r, n_frames, fs, active, s);
+        dwt_rows<false>(B, jb, r, n_frames, fs, active, s);
+        dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
     }
 }
 

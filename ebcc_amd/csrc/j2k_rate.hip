@@ -16,7 +16,7 @@
 
 namespace ebcc {
 
-void j2k_inverse_dwt(float *B, const J2kGeom &g, int n_frames, const FrameState *fs, const int *active, hipStream_t s);
+void j2k_inverse_dwt(float *B, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s);
 
 namespace {
 
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     __shared__ double s_min[kRateThreads / 64], s_max[kRateThreads / 64];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
-    const J2kGeom &g = *geom;
-    const int gid0 = frame * g.nblocks;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    const int gid0 = frame * g.stride;
     RateLds L;
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
     trees_static<kRateThreads>(g, L, numbps, gid0, lane);
@@ -626,8 +626,8 @@ __global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__
     __shared__ int s_hdr[kJ2kRes], s_body[kJ2kRes], s_off[kJ2kRes + 1];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
-    const J2kGeom &g = *geom;
-    const int gid0 = frame * g.nblocks;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    const int gid0 = frame * g.stride;
     RateLds L;
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
     trees_static<kWriteThreads>(g, L, numbps, gid0, lane);
@@ -823,9 +823,11 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
     const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
     const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
-    const int nb = geom->nblocks;
+    const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
     if (fs[frame].const_field) return;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
     const int *e = dec_table + (size_t) gid * 4;
     const int len = e[1], P = e[2], np = e[3];
     const uint8_t *src = bytes + (size_t) frame * stream_cap + e[0];
@@ -854,13 +856,13 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
-    const int frame = gid / geom->nblocks;
+    const int frame = gid / geom->stride;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const int n = npass[gid], P = numbps[gid];
     int plan = -1;
     if (n > 0 && P > 0) {
         const int len = rates[(size_t) gid * kJ2kMaxPasses + n - 1];
-        const int nstr = (blocks[gid - frame * geom->nblocks].h + 3) >> 2;
+        const int nstr = (j2k_frame_blocks(geom, blocks, frame)[gid - frame * geom->stride].h + 3) >> 2;
         const J2kCkptView ck = J2kCkptView::of(ckpt, (size_t) gid);
         // latest checkpoint taken before the decoder touched a byte at/after the truncation point (pos is
         // non-decreasing in coding order); slot 0 is the initial state and always usable
@@ -888,7 +890,9 @@ __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ 
     const size_t n_pix = (size_t) W * geom->H;
     const int32_t *q = Q6 + (size_t) frame * n_pix;
     int32_t *v = V + (size_t) frame * n_pix;
-    const int gid0 = frame * geom->nblocks;
+    const int gid0 = frame * geom->stride;
+    blkmap = j2k_frame_blkmap(geom, blkmap, frame);
+    blocks = j2k_frame_blocks(geom, blocks, frame);
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
         const int bi = blkmap[i], gid = gid0 + bi;
         const int plan = rpass[gid];
@@ -930,9 +934,11 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
     const int gid = gid0 + threadIdx.x;
     if (gid >= total) return;
-    const int nb = geom->nblocks;
+    const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
     if ((active && !active[frame]) || fs[frame].const_field) return;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
     const int plan = rpass[gid];
     if (plan < 0) return;
     const int r = plan & 0xFF, stripe = plan >> 8;
@@ -985,11 +991,19 @@ __global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, 
     const size_t n_pix = (size_t) geom->W * geom->H;
     const int32_t *v = V + (size_t) frame * n_pix;
     float *b = B + (size_t) frame * n_pix;
+    blkmap = j2k_frame_blkmap(geom, blkmap, frame);
+    blocks = j2k_frame_blocks(geom, blocks, frame);                   // (the step sizes are the same at every tile position)
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x)
         b[i] = (float) v[i] * (0.5f * geom->bands[blocks[blkmap[i]].band].step_dec);
 }
 
-size_t rate_lds(const J2kGeom &g) { return rate_lds_bytes(g.nblocks, g.tree_nodes); }
+// LDS carve-up of the rate / write kernels for the largest tile position of the context
+size_t rate_lds(const J2kBuffers &jb)
+{
+    size_t n = 0;
+    for (const J2kGeom &g : jb.geoms) n = std::max(n, rate_lds_bytes(g.nblocks, g.tree_nodes));
+    return n;
+}
 
 }  // namespace
 
@@ -998,9 +1012,9 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
 {
     ScopedTiming t("rate_alloc", s);
     // dynamic LDS: the carve-up, the per-block table offsets, then as many (rate, distortion) entries as fit
-    const size_t head = ((rate_lds(jb.geom) + 15) & ~(size_t) 15) + (((size_t) (jb.geom.nblocks + 1) * 4 + 15) & ~(size_t) 15);
+    const size_t head = ((rate_lds(jb) + 15) & ~(size_t) 15) + (((size_t) (jb.geom.stride + 1) * 4 + 15) & ~(size_t) 15);
     const size_t budget = 150 * 1024;
-    size_t want = (size_t) jb.geom.nblocks * kJ2kMaxPasses;
+    size_t want = (size_t) jb.geom.stride * kJ2kMaxPasses;
     if (head + want * 12 > budget) want = head < budget ? (budget - head) / 12 : 0;
     const size_t lds = head + want * 12;
     static std::once_flag once;
@@ -1013,7 +1027,7 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
 
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_write, dim3(n_frames), dim3(kWriteThreads), rate_lds(jb.geom), s, jb.numbps, jb.rates, jb.npass,
+    hipLaunchKernelGGL(k_write, dim3(n_frames), dim3(kWriteThreads), rate_lds(jb), s, jb.numbps, jb.rates, jb.npass,
                        jb.cblk_bytes, jb.stream, jb.stream_cap, jb.d_geom, jb.jf, jb.fs, d_active);
 }
 
@@ -1022,7 +1036,7 @@ static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, c
     const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
     hipLaunchKernelGGL(k_dequant, dim3(128, n_frames), dim3(256), 0, s, jb.V, jb.d_blkmap, jb.B, jb.d_geom, jb.d_blocks, jb.fs,
                        d_active);
-    j2k_inverse_dwt(jb.B, jb.geom, n_frames, jb.fs, d_active, s);
+    j2k_inverse_dwt(jb.B, jb, n_frames, jb.fs, d_active, s);
     if (stats) {
         hipLaunchKernelGGL(k_finish<true>, dim3(kPartials, n_frames), dim3(256), 0, s, jb.B, data, jb.DEC, n_pix, jb.fs, jb.jf,
                            jb.partial, jb.partial_u, d_active);
@@ -1036,7 +1050,7 @@ static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, c
 
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
-    const int total = n_frames * jb.geom.nblocks;
+    const int total = n_frames * jb.geom.stride;
     void *ck = jb.ckpt;
     hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
                        jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
@@ -1054,7 +1068,7 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
 {
     const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
-    const int total = n_frames * jb.geom.nblocks;
+    const int total = n_frames * jb.geom.stride;
     const size_t groups = ((size_t) total + 63) / 64;
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));

@@ -203,7 +203,8 @@ def tiled():
     os.environ.pop("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", None)
     make_data = lambda shape: np.ascontiguousarray(idx(shape)[0] * 100.0 + idx(shape)[1] * 1.5 + idx(shape)[2] * 0.25, np.float32)
     ebck = {}
-    for shape, chunk in [((3, 33, 35), (2, 32, 32)), ((2, 32, 32), (4, 32, 32)), ((2, 32, 32), (0, 0, 0)), ((5, 64, 64), (2, 64, 32))]:
+    for shape, chunk in [((3, 33, 35), (2, 32, 32)), ((2, 32, 32), (4, 32, 32)), ((2, 32, 32), (0, 0, 0)), ((5, 64, 64), (2, 64, 32)),
+                         ((5, 45, 91), (2, 45, 91)), ((4, 100, 130), (3, 50, 65)), ((3, 33, 35), (0, 0, 0)), ((6, 40, 48), (6, 40, 48))]:
         for mode, err in ((1, 0.01), (0, 0.0)):
             cfg = L.make_config(shape, chunk if any(chunk) else None, base_cr=2.0, error=err, residual_type=mode)
             s = ref_encode(make_data(shape), cfg, "ebcc_encode_chunking")

@@ -85,7 +85,7 @@ _tiled = json.load(open(os.path.join(L.GOLDEN, "tiled.json")))
 _tiled_inputs = np.load(os.path.join(L.GOLDEN, "tiled_inputs.npz"))
 
 
-@pytest.mark.parametrize("name", sorted(k for k in _tiled["frames"] if not k.startswith("odd_")), ids=str)
+@pytest.mark.parametrize("name", sorted(_tiled["frames"]), ids=str)
 def test_multi_frame_chunks_bit_exact(name, monkeypatch):
     """Chunks of several frames = one multi-tile JPEG 2000 image + SPIHT over the stacked image (reference
     src/ebcc_codec.c:105-180); golden streams from the reference build (oracle/make_golden.py tiled)."""

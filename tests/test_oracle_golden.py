@@ -128,6 +128,19 @@ def test_ebck_containers(name):
     assert ver == 1 and ndims == 3 and dims == shape
 
 
+@pytest.mark.parametrize("name", sorted(_tiled["ebck"]), ids=str)
+def test_multi_frame_chunk_containers(name):
+    """EBCK containers whose chunks hold several frames (reference tests/test_c_api.py:194-258 shapes plus frame heights
+    that are not a multiple of 32)."""
+    c = _tiled["ebck"][name]
+    shape, chunk = tuple(c["shape"]), tuple(c["chunk"])
+    cfg = L.make_config(shape, chunk if any(chunk) else None, base_cr=2.0, error=c["error"], residual_type=c["mode"])
+    L.oracle().orc_set_j2k_backend(0)
+    s = L.orc_encode(_make_data(shape), cfg, "orc_ebcc_encode_chunking")
+    assert len(s) == c["n"] and sha(s) == c["stream_sha256"]
+    assert sha(L.orc_decode(s, "orc_ebcc_decode_chunking").tobytes()) == c["decoded_sha256"]
+
+
 @pytest.mark.skipif(not os.path.exists(L.REF_SO), reason="reference build only exists in the dev container")
 def test_j2k_restatement_matches_openjpeg_live():
     lib = L.oracle()

@@ -211,7 +211,17 @@ def tiled():
             d = ref_decode(s, "ebcc_decode_chunking")
             ebck[f"{shape}_{chunk}_m{mode}"] = {"shape": shape, "chunk": chunk, "mode": mode, "error": err, "n": len(s),
                                                 "stream_sha256": sha(s), "decoded_sha256": sha(d.tobytes())}
-    json.dump({"frames": cases, "ebck": ebck}, open(os.path.join(OUT, "tiled.json"), "w"), indent=0)
+    # full-size and extreme multi-frame chunks on formula inputs (hashes only): two ERA5-sized frames per chunk, the
+    # most tiles a chunk can hold (63 x 32 rows), the tallest tiles (2 x 1023 rows)
+    big = {}
+    for shape, cr, mode, err in [((2, 721, 1440), 30.0, 1, 0.5), ((2, 721, 1440), 100.0, 0, 0.0), ((63, 32, 40), 4.0, 1, 0.05),
+                                 ((62, 33, 48), 4.0, 1, 0.05), ((2, 1023, 33), 6.0, 2, 1e-3)]:
+        cfg = L.make_config(shape, base_cr=cr, error=err, residual_type=mode)
+        s = ref_encode(L.formula_frames(*shape), cfg)
+        big["x".join(map(str, shape)) + f"_cr{cr:g}_m{mode}"] = {"shape": shape, "base_cr": cr, "mode": mode, "error": err, "n": len(s),
+                                                               "stream_sha256": sha(s), "decoded_sha256": sha(ref_decode(s).tobytes())}
+        print(shape, cr, mode, len(s), flush=True)
+    json.dump({"frames": cases, "ebck": ebck, "big": big}, open(os.path.join(OUT, "tiled.json"), "w"), indent=0)
     print("tiled fixtures written")
 
 

@@ -453,3 +453,10 @@ def era5_like(h, w, seed, slope=1.5, amp=2.5):
     n /= n.std()
     lat = np.linspace(-1, 1, h)[:, None]
     return (235 + 50 * np.cos(lat * np.pi / 2) + amp * n).astype(np.float32)
+
+
+def formula_frames(n, h, w):
+    """Integer-formula frames (exactly reproducible anywhere): frame k of an n x h x w stack."""
+    k, y, x = np.mgrid[0:n, 0:h, 0:w]
+    return (250.0 + ((x * 3 + y * 5 + k * 11) % 1024).astype(np.float32) / np.float32(64.0)
+            + (((x // 16) * 7 + (y // 16) * 13 + k * 5) % 97).astype(np.float32)).astype(np.float32)

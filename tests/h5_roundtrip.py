@@ -41,7 +41,7 @@ print("OK direct-chunk bytes == callback bytes", sum(len(r) for r in raw_dc))
 assert np.array_equal(via_callback, back) and np.array_equal(via_batch, back)
 print("OK batch read == callback read")
 # (3) chunks of two frames: the filter callback receives both frames at once (one multi-tile codestream per chunk)
-h2, w2 = 32, 64
+h2, w2 = 45, 64                          # (not a multiple of 32: the second tile of a chunk has its own JPEG 2000 geometry)
 multi = np.stack([(260 + 8 * np.sin(x[:h2, :w2] / (5.0 + k)) + rng.normal(0, 0.2, (h2, w2))).astype(np.float32) for k in range(4)])
 kw = dict(EBCC_Filter(base_cr=10, height=h2, width=w2, residual_opt=("max_error_target", 0.05), data_dim=3))
 kw["chunks"] = (2, h2, w2)

@@ -120,6 +120,27 @@ def test_multi_frame_chunk_containers_bit_exact(name):
         assert np.allclose(d.reshape(shape), data, atol=0.02)
 
 
+@pytest.mark.parametrize("name", sorted(_tiled["big"]), ids=str)
+def test_multi_frame_chunk_extremes_bit_exact(name):
+    """Two ERA5-sized frames per chunk, 63 tiles of 32 rows, 62 tiles of 33 rows (every tile position its own
+    geometry), two tiles of 1023 rows: formula inputs, hashes from the reference build."""
+    c = _tiled["big"][name]
+    shape = tuple(c["shape"])
+    cfg = L.make_config(shape, base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+    s = api_encode(L.formula_frames(*shape), cfg)
+    assert len(s) == c["n"] and sha(s) == c["stream_sha256"]
+    assert sha(api_decode(s).tobytes()) == c["decoded_sha256"]
+
+
+def test_multi_frame_chunks_with_short_frames_are_refused():
+    """Tiles of fewer than 32 rows: OpenJPEG cannot set up 6 resolutions and the reference crashes; here an error."""
+    lib = L.product()
+    x = L.formula_frames(4, 16, 64)
+    out = ctypes.c_void_p()
+    cfg = L.make_config(x.shape, base_cr=4.0, error=0.1, residual_type=L.MAX_ERROR)
+    assert lib.ebcc_encode(x.ctypes.data, ctypes.byref(cfg), ctypes.byref(out)) == 0
+
+
 def test_full_size_formula_frames_bit_exact():
     big = json.load(open(os.path.join(L.GOLDEN, "codec_big.json")))
     y, x = np.mgrid[0:721, 0:1440]

@@ -141,6 +141,19 @@ def test_multi_frame_chunk_containers(name):
     assert sha(L.orc_decode(s, "orc_ebcc_decode_chunking").tobytes()) == c["decoded_sha256"]
 
 
+@pytest.mark.parametrize("name", sorted(_tiled["big"]), ids=str)
+def test_multi_frame_chunk_extremes(name):
+    """Two ERA5-sized frames per chunk, the most tiles a chunk can hold (63), the tallest tiles (1023 rows): formula
+    inputs, hashes from the reference build."""
+    c = _tiled["big"][name]
+    shape = tuple(c["shape"])
+    cfg = L.make_config(shape, base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+    L.oracle().orc_set_j2k_backend(0)
+    s = L.orc_encode(L.formula_frames(*shape), cfg)
+    assert len(s) == c["n"] and sha(s) == c["stream_sha256"]
+    assert sha(L.orc_decode(s).tobytes()) == c["decoded_sha256"]
+
+
 @pytest.mark.skipif(not os.path.exists(L.REF_SO), reason="reference build only exists in the dev container")
 def test_j2k_restatement_matches_openjpeg_live():
     lib = L.oracle()

@@ -124,6 +124,10 @@ __device__ int packet_header(int r, const J2kGeom &g, const Trees &t, const shor
     return bio.n;
 }
 
+// k_rate's own arrays behind the carve-up: the per-block table offsets, then three sets of path masks and a flag
+__host__ __device__ inline size_t rate_off_bytes(int nblocks) { return ((size_t) (nblocks + 1) * 4 + 15) & ~(size_t) 15; }
+__host__ __device__ inline size_t rate_path_bytes(int nblocks) { return (size_t) nblocks * 2 * 8 * 3 + (((size_t) nblocks + 7) & ~(size_t) 7); }
+
 __host__ __device__ inline size_t rate_lds_bytes(int nblocks, int nodes)
 {
     return 2 * ((((size_t) nblocks * 2 + 7) / 8) * 8) + (size_t) nodes * 16 + (size_t) nblocks * 20 + 128;
@@ -225,13 +229,13 @@ __device__ void trees_reset(const J2kGeom &g, RateLds &L, int lane)
 }
 
 // Per-pass rate / distortion tables of one frame.  k_rate walks them ~60 times per call, so they are staged in
-// LDS when all code-blocks of the frame fit (12 bytes per coding pass); otherwise they are read from global
+// LDS when all code-blocks of the frame fit (10 bytes per coding pass); otherwise they are read from global
 // memory as they are.
 struct PassTab {
     const int *rates;              // [nblocks][kJ2kMaxPasses] of this frame (global memory)
     const double *disto;
     const __attribute__((address_space(3))) double *l_disto;   // LDS copies, code-block b at l_off[b] .. + totalpasses
-    const __attribute__((address_space(3))) int *l_rate;
+    const __attribute__((address_space(3))) unsigned short *l_rate;   // (a code-block's bytes fit its 16 KB slot)
     const __attribute__((address_space(3))) int *l_off;
     bool lds;
     // (kept in their own address spaces: a pointer that may be either would turn every access into a flat load)
@@ -241,10 +245,15 @@ struct PassTab {
 };
 
 // opj_tcd_makelayer for one quality layer
+// `path` (optional): [2][nblocks] bit masks of the passes taken, i.e. the whole greedy walk and not just its end;
+// `frozen` (optional): code-blocks whose walk cannot change any more (k_rate) keep their assignment
 template <int NT, bool LDS>
-__device__ void make_layer_impl(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane)
+__device__ void make_layer_impl(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane,
+                                unsigned long long *path, const unsigned char *frozen)
 {
     for (int b = lane; b < g.nblocks; b += NT) {
+        if (frozen && frozen[b]) continue;
+        unsigned long long m0 = 0, m1 = 0;
         int tp;
         if constexpr (LDS) tp = pt.l_off[b + 1] - pt.l_off[b]; else tp = totalpasses[gid0 + b];
         const int base = pt.base_of<LDS>(b);
@@ -272,19 +281,24 @@ __device__ void make_layer_impl(const J2kGeom &g, RateLds &L, const int *totalpa
                     else if (thresh >= 1e-4 && dd <= tdr * 0.99999999999) take = false;
                     else take = thresh - (dd / dr) < DBL_EPSILON;
                 }
-                if (take) { n = p + 1; rbase = rp; dbase = dp; }
+                if (take) {
+                    n = p + 1; rbase = rp; dbase = dp;
+                    if (p < 64) m0 |= 1ull << p; else m1 |= 1ull << (p - 64);
+                }
             }
         }
         L.npass[b] = (short) n;
+        if (path) { path[b] = m0; path[g.nblocks + b] = m1; }
     }
     __syncthreads();
 }
 
 template <int NT>
-__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane)
+__device__ void make_layer(const J2kGeom &g, RateLds &L, const int *totalpasses, const PassTab &pt, int gid0, double thresh, int lane,
+                           unsigned long long *path = nullptr, const unsigned char *frozen = nullptr)
 {
-    if (pt.lds) make_layer_impl<NT, true>(g, L, totalpasses, pt, gid0, thresh, lane);
-    else make_layer_impl<NT, false>(g, L, totalpasses, pt, gid0, thresh, lane);
+    if (pt.lds) make_layer_impl<NT, true>(g, L, totalpasses, pt, gid0, thresh, lane, path, frozen);
+    else make_layer_impl<NT, false>(g, L, totalpasses, pt, gid0, thresh, lane, path, frozen);
 }
 
 // total packet bytes of the current assignment (one lane per resolution)
@@ -489,7 +503,13 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     __shared__ int s_fit;
     unsigned char *extra = lds_raw + ((rate_lds_bytes(g.nblocks, g.tree_nodes) + 15) & ~(size_t) 15);
     int *l_off = (int *) extra;
-    double *l_disto = (double *) (extra + (((size_t) (g.nblocks + 1) * 4 + 15) & ~(size_t) 15));
+    // greedy walks (make_layer_impl `path`) at the current threshold and at the two ends of the bisection bracket,
+    // and the code-blocks whose walk is settled
+    unsigned long long *p_cur = (unsigned long long *) (extra + rate_off_bytes(g.nblocks));
+    unsigned long long *p_lo = p_cur + 2 * g.nblocks, *p_hi = p_lo + 2 * g.nblocks;
+    unsigned char *frozen = (unsigned char *) (p_hi + 2 * g.nblocks);
+    double *l_disto = (double *) (frozen + (((size_t) g.nblocks + 7) & ~(size_t) 7));
+    for (int b = lane; b < g.nblocks; b += kRateThreads) frozen[b] = 0;
     for (int b = lane; b < g.nblocks; b += kRateThreads) l_off[b] = totalpasses[gid0 + b];
     __syncthreads();
     if (lane == 0) {
@@ -500,16 +520,17 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     }
     __syncthreads();
     const int n_entries = s_fit;
-    int *l_rate = (int *) (l_disto + (n_entries > 0 ? n_entries : 0));
+    unsigned short *l_rate = (unsigned short *) (l_disto + (n_entries > 0 ? n_entries : 0));
     typedef __attribute__((address_space(3))) double lds_double;
     typedef __attribute__((address_space(3))) int lds_int;
+    typedef __attribute__((address_space(3))) unsigned short lds_ushort;
     PassTab pt{rates + (size_t) gid0 * kJ2kMaxPasses, disto + (size_t) gid0 * kJ2kMaxPasses, (const lds_double *) l_disto,
-               (const lds_int *) l_rate, (const lds_int *) l_off, n_entries >= 0};
+               (const lds_ushort *) l_rate, (const lds_int *) l_off, n_entries >= 0};
     if (pt.lds) {
         for (int b = lane; b < g.nblocks; b += kRateThreads) {
             const int tp = totalpasses[gid0 + b], o = l_off[b];
             for (int p = 0; p < tp; p++) {
-                l_rate[o + p] = pt.rates[(size_t) b * kJ2kMaxPasses + p];
+                l_rate[o + p] = (unsigned short) pt.rates[(size_t) b * kJ2kMaxPasses + p];
                 l_disto[o + p] = pt.disto[(size_t) b * kJ2kMaxPasses + p];
             }
         }
@@ -578,26 +599,54 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
 #define RP_ADD(acc)
 #endif
     double good = -1;                                                // rate 0: every pass
+    bool converged = false;
     if (rate > 0.0f) {
         const long long maxlen = (long long) ceil((double) rate);
         double lo = mn, hi = mx, thresh = 0, stable = 0, prev = -1;
+        bool lo_seen = false, hi_seen = false;
+        int bytes_lo = 0, bytes_hi = 0;
         for (int i = 0; i < 128; i++) {
             thresh = (lo + hi) / 2;
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
-            { RP_T0; make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane); RP_ADD(t_ml); }
+            { RP_T0; make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane, p_cur, frozen); RP_ADD(t_ml); }
+            // late iterations alternate between the assignments of the two bracket ends: their sizes are known
+            int at_lo = lo_seen, at_hi = hi_seen;
+            for (int b = lane; b < g.nblocks; b += kRateThreads) {
+                if (frozen[b]) continue;
+                if (p_cur[b] != p_lo[b] || p_cur[g.nblocks + b] != p_lo[g.nblocks + b]) at_lo = 0;
+                if (p_cur[b] != p_hi[b] || p_cur[g.nblocks + b] != p_hi[g.nblocks + b]) at_hi = 0;
+            }
+            at_lo = __syncthreads_and(at_lo);
+            at_hi = __syncthreads_and(at_hi);
             int bytes;
-            { RP_T0; bytes = sized(); RP_ADD(t_sz); }
+            if (at_lo) bytes = bytes_lo;
+            else if (at_hi) bytes = bytes_hi;
+            else { RP_T0; bytes = sized(); RP_ADD(t_sz); }
 #ifdef EBCC_RATE_PROFILE
-            n_it++; n_real += s_changed;
+            n_it++; n_real += (at_lo || at_hi) ? 0 : s_changed;
 #endif
-            if ((long long) bytes > maxlen) { lo = thresh; continue; }
-            hi = thresh;
-            stable = thresh;
+            const bool fits = (long long) bytes <= maxlen;
+            if (fits) bytes_hi = bytes; else bytes_lo = bytes;
+            if (fits) { hi = thresh; stable = thresh; hi_seen = true; } else { lo = thresh; lo_seen = true; }
+            // A pass is taken iff fl(thresh - slope) < DBL_EPSILON, which is monotone in thresh: a code-block whose
+            // greedy walks at the two ends of the bracket are the same walk takes that walk at every threshold in
+            // between, i.e. for the rest of the bisection (frozen: make_layer skips it).  When that holds for all
+            // of them, all remaining iterations see this assignment and this size, and whichever end they settle on
+            // (`stable` = hi when it does not fit, the limit point when it does) the layer is the current one.
+            unsigned long long *end = fits ? p_hi : p_lo;
+            int same = lo_seen && hi_seen;
+            for (int b = lane; b < g.nblocks; b += kRateThreads) {
+                if (frozen[b]) continue;
+                end[b] = p_cur[b]; end[g.nblocks + b] = p_cur[g.nblocks + b];
+                if (lo_seen && hi_seen && p_lo[b] == p_hi[b] && p_lo[g.nblocks + b] == p_hi[g.nblocks + b]) frozen[b] = 1;
+                else same = 0;
+            }
+            if (__syncthreads_and(same)) { converged = true; break; }
         }
         good = stable == 0 ? thresh : stable;
     }
-    make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, good, lane);
+    if (!converged) make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, good, lane);
     const int body = sized();
     for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
     if (lane == 0) {
@@ -1012,11 +1061,11 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
 {
     ScopedTiming t("rate_alloc", s);
     // dynamic LDS: the carve-up, the per-block table offsets, then as many (rate, distortion) entries as fit
-    const size_t head = ((rate_lds(jb) + 15) & ~(size_t) 15) + (((size_t) (jb.geom.stride + 1) * 4 + 15) & ~(size_t) 15);
+    const size_t head = ((rate_lds(jb) + 15) & ~(size_t) 15) + rate_off_bytes(jb.geom.stride) + rate_path_bytes(jb.geom.stride);
     const size_t budget = 150 * 1024;
     size_t want = (size_t) jb.geom.stride * kJ2kMaxPasses;
-    if (head + want * 12 > budget) want = head < budget ? (budget - head) / 12 : 0;
-    const size_t lds = head + want * 12;
+    if (head + want * 10 + 16 > budget) want = head + 16 < budget ? (budget - head - 16) / 10 : 0;
+    const size_t lds = head + want * 10 + 16;
     static std::once_flag once;
     std::call_once(once, [] {
         EBCC_HIP_CHECK(hipFuncSetAttribute((const void *) k_rate, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

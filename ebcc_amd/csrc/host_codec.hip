@@ -1047,10 +1047,17 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
 
 }  // namespace
 
-// Slices of a batch: EBCC_HIP_SLICES (encode, default 2, 1 = off) / EBCC_HIP_DECODE_SLICES (default 1) engines of max_frames / slices frames each, created on
-// first use.  Small batches stay on the context's own engine.  More than two slices only pay when the HIP
-// runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the application's streams):
-// streams that share a queue run one after the other.
+// Slices of a batch: EBCC_HIP_SLICES (encode, 1 = off) / EBCC_HIP_DECODE_SLICES (default 1) engines of max_frames / slices
+// frames each, created on first use.  Small batches stay on the context's own engine.  More than two slices only
+// pay when the HIP runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the
+// application's streams; it is read when the runtime starts, so the application sets it): streams that share a
+// queue run one after the other.  Default for encode: 4 slices when the process runs with GPU_MAX_HW_QUEUES >= 8
+// (measured best on MI355X: the host-side zstd of one slice hides behind the GPU phases of the others), else 2.
+static size_t default_encode_slices()
+{
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    return e && atoi(e) >= 8 ? 4 : 2;
+}
 static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames, const char *env_name, size_t k)
 {
     if (const char *e = getenv(env_name)) k = (size_t) std::max(1L, strtol(e, nullptr, 10));
@@ -1132,7 +1139,7 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }   // on error: free the non-null ones
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
         return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo, next);
-    }, "EBCC_HIP_SLICES", 2);
+    }, "EBCC_HIP_SLICES", default_encode_slices());
 }
 
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,

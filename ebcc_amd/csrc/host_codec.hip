@@ -12,6 +12,9 @@
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <tuple>
 #include <atomic>
 #include <mutex>
@@ -679,6 +682,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         EBCC_HIP_CHECK(hipStreamSynchronize(rs));
         std::atomic<size_t> next_frame{0};
         auto zworker = [&]() {
+            // below the threads that steer the GPU (this one, the other slices'): they must not wait for a core
+            setpriority(PRIO_PROCESS, (id_t) syscall(SYS_gettid), 10);
             for (size_t f = next_frame++; f < n; f = next_frame++) {
                 Job &j = jobs[f];
                 if (j.coeffs_size == 0) continue;
@@ -1064,10 +1069,16 @@ static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames, const char *env_
     k = std::min<size_t>(k, 8);
     if (k < 2 || n_frames < 4 * k) return 1;
     const size_t per = (ctx->max_frames + k - 1) / k;
-    while (ctx->lanes.size() + 1 < k) {                     // slice 0 runs on the context's own engine
+    for (size_t i = 0; i + 1 < k; i++) {                    // slice 0 runs on the context's own engine
+        if (i < ctx->lanes.size() && ctx->lanes[i]->max_frames >= per) continue;
+        // (a lane made for a finer slicing - encode and decode choose their own - is too small for this one)
+        if (i < ctx->lanes.size()) { ebcc_hip_destroy(ctx->lanes[i]); ctx->lanes[i] = nullptr; }
         ebcc_hip_ctx *c = ebcc_hip_create(ctx->device, per, (size_t) ctx->height, (size_t) ctx->width);
-        if (!c) return 1;                                   // out of memory: fall back to the single engine
-        ctx->lanes.push_back(c);
+        if (i < ctx->lanes.size()) ctx->lanes[i] = c; else if (c) ctx->lanes.push_back(c);
+        if (!c) {                                           // out of memory: fall back to the single engine
+            ctx->lanes.erase(std::remove(ctx->lanes.begin(), ctx->lanes.end(), (ebcc_hip_ctx *) nullptr), ctx->lanes.end());
+            return 1;
+        }
     }
     return k;
 }

@@ -205,9 +205,14 @@ def test_sliced_batches_equal_single_engine(monkeypatch):
     res = {}
     for k in ("1", "2", "4"):
         monkeypatch.setenv("EBCC_HIP_SLICES", k)
+        monkeypatch.setenv("EBCC_HIP_DECODE_SLICES", {"1": "1", "2": "1", "4": "2"}[k])    # (a coarser slicing than the encoder's)
         with L.Context(len(frames), 96, 160) as ctx:
             got = ctx.encode_frames(frames, cfg)
             res[k] = (got, ctx.decode_frames(got))
+            if k == "4":                                        # and a finer one again on the same engines
+                monkeypatch.setenv("EBCC_HIP_DECODE_SLICES", "3")
+                assert np.array_equal(ctx.decode_frames(got), res[k][1])
+                assert ctx.encode_frames(frames, cfg) == got
     L.oracle().orc_set_j2k_backend(0)
     for f in (0, 5, 18):
         assert res["1"][0][f] == L.orc_encode(frames[f], cfg), f

@@ -61,6 +61,8 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->totalpasses = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->cblk_len = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->npass = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->rate_path = (int *) ctx_alloc<int32_t>(ctx, F * 64)) != nullptr;
+    ok &= (jb->rate_path_n = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
     ok &= (jb->rates = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
     ok &= (jb->disto = ctx_alloc<double>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
     ok &= (jb->cblk_bytes = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kCblkBytes)) != nullptr;
@@ -85,6 +87,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blocks, blocks.data(), sizeof(J2kBlock) * blocks.size(), hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blkmap, map.data(), map.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
+    EBCC_HIP_CHECK(hipMemsetAsync(jb->rate_path_n, 0, sizeof(int) * F, s));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return true;
 }

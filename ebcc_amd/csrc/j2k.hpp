@@ -126,6 +126,8 @@ struct J2kBuffers {
     int *rates;                   // [frames*nblocks][kJ2kMaxPasses]
     double *disto;                // [frames*nblocks][kJ2kMaxPasses]
     int *npass;                   // [frames*nblocks] passes in the current layer
+    int *rate_path;               // [frames][64] packet bytes along the all-fitting start of the rate bisection (k_rate), valid for
+    int *rate_path_n;             // [frames] that many steps; reset by the analysis
     uint8_t *cblk_bytes;          // [frames*nblocks][kJ2kCblkBytes]
     uint8_t *stream;              // [frames][stream_cap] codestream
     size_t stream_cap;

@@ -21,6 +21,7 @@ void j2k_inverse_dwt(float *B, const J2kBuffers &jb, int n_frames, const FrameSt
 namespace {
 
 constexpr int kMainHeaderBytes = 135;
+constexpr int kRatePathLen = 64;      // recorded steps of the all-fitting bisection path of a frame (k_rate)
 constexpr int kRateThreads = 512;     // k_rate: one workgroup per frame, about one code-block per thread
 constexpr int kWriteThreads = 256;    // k_write: one workgroup per frame (headers by one lane per resolution, bodies by all)
 
@@ -483,7 +484,8 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
 __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ numbps, const int *__restrict__ totalpasses,
                                                         const int *__restrict__ rates, const double *__restrict__ disto,
                                                         int *__restrict__ npass_out, const J2kGeom *geom, J2kFrame *jf,
-                                                        const FrameState *fs, const int *active, int pass_capacity)
+                                                        const FrameState *fs, const int *active, int pass_capacity,
+                                                        int *__restrict__ path_bytes, int *__restrict__ path_n)
 {
     extern __shared__ unsigned char lds_raw[];
     __shared__ int s_sum, s_changed;
@@ -605,10 +607,26 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         double lo = mn, hi = mx, thresh = 0, stable = 0, prev = -1;
         bool lo_seen = false, hi_seen = false;
         int bytes_lo = 0, bytes_hi = 0;
+        // The bisection starts from the same bracket [mn, mx] at every call for this frame, and as long as every size
+        // so far fitted it visits the same thresholds: those sizes are remembered across calls (path_bytes, reset by
+        // the analysis), so a call replays its first ~25 steps - the expensive ones, no code-block is settled yet -
+        // from the record and starts computing where its budget first differs or the record ends.
+        const int known = path_n[frame];
+        int *const rec = path_bytes + (size_t) frame * kRatePathLen;
+        bool on_path = true, lo_from_rec = false, hi_from_rec = false;
         for (int i = 0; i < 128; i++) {
             thresh = (lo + hi) / 2;
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
+            if (on_path && i < known) {
+                const int bytes = rec[i];
+                if ((long long) bytes <= maxlen) { hi = thresh; stable = thresh; bytes_hi = bytes; hi_from_rec = true; }
+                else { lo = thresh; bytes_lo = bytes; lo_from_rec = true; on_path = false; }
+                continue;
+            }
+            // the walks at bracket ends that came from the record (needed to tell settled code-blocks)
+            if (hi_from_rec) { make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, hi, lane, p_hi); hi_seen = true; hi_from_rec = false; }
+            if (lo_from_rec) { make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, lo, lane, p_lo); lo_seen = true; lo_from_rec = false; }
             { RP_T0; make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane, p_cur, frozen); RP_ADD(t_ml); }
             // late iterations alternate between the assignments of the two bracket ends: their sizes are known
             int at_lo = lo_seen, at_hi = hi_seen;
@@ -627,6 +645,10 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             n_it++; n_real += (at_lo || at_hi) ? 0 : s_changed;
 #endif
             const bool fits = (long long) bytes <= maxlen;
+            if (on_path && i < kRatePathLen) {                       // (i == number of entries on record: the path is walked in order)
+                if (lane == 0) { rec[i] = bytes; path_n[frame] = i + 1; }
+            }
+            if (!fits) on_path = false;
             if (fits) bytes_hi = bytes; else bytes_lo = bytes;
             if (fits) { hi = thresh; stable = thresh; hi_seen = true; } else { lo = thresh; lo_seen = true; }
             // A pass is taken iff fl(thresh - slope) < DBL_EPSILON, which is monotone in thresh: a code-block whose
@@ -1071,7 +1093,7 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
         EBCC_HIP_CHECK(hipFuncSetAttribute((const void *) k_rate, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     });
     hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), lds, s, jb.numbps, jb.totalpasses, jb.rates,
-                       jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want);
+                       jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want, jb.rate_path, jb.rate_path_n);
 }
 
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)

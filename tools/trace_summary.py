@@ -38,7 +38,8 @@ for s, e, n in step:
         gaps.append((s - cur_e, cur_e - t0, last, n))
         cur_s, cur_e, last = s, e, n
 busy += cur_e - cur_s
-print(f"step: {(t1 - t0) / 1e6:.2f} ms wall, GPU busy (any kernel running) {busy / 1e6:.2f} ms, idle {(t1 - t0 - busy) / 1e6:.2f} ms, {len(step)} kernels")
+print(f"step: {(t1 - t0) / 1e6:.2f} ms wall, GPU busy (any kernel running) {busy / 1e6:.2f} ms, idle {(t1 - t0 - busy) / 1e6:.2f} ms, "
+      f"sum of kernel durations {sum(e - s for s, e, _ in step) / 1e6:.2f} ms, {len(step)} kernels")
 per = {}
 for s, e, n in step:
     a = per.setdefault(n, [0, 0])

@@ -61,7 +61,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->totalpasses = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->cblk_len = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->npass = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
-    ok &= (jb->rate_path = (int *) ctx_alloc<int32_t>(ctx, F * 64)) != nullptr;
+    ok &= (jb->rate_path = (int *) ctx_alloc<int32_t>(ctx, F * 1536 * 3)) != nullptr;
     ok &= (jb->rate_path_n = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
     ok &= (jb->rates = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
     ok &= (jb->disto = ctx_alloc<double>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;

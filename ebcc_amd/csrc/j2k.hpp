@@ -126,8 +126,8 @@ struct J2kBuffers {
     int *rates;                   // [frames*nblocks][kJ2kMaxPasses]
     double *disto;                // [frames*nblocks][kJ2kMaxPasses]
     int *npass;                   // [frames*nblocks] passes in the current layer
-    int *rate_path;               // [frames][64] packet bytes along the all-fitting start of the rate bisection (k_rate), valid for
-    int *rate_path_n;             // [frames] that many steps; reset by the analysis
+    int *rate_path;               // [frames][1536][3] packet bytes at the steps of the rate bisection k_rate has visited, as a trie
+    int *rate_path_n;             // [frames] nodes in it; reset by the analysis
     uint8_t *cblk_bytes;          // [frames*nblocks][kJ2kCblkBytes]
     uint8_t *stream;              // [frames][stream_cap] codestream
     size_t stream_cap;

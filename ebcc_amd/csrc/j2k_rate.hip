@@ -21,7 +21,7 @@ void j2k_inverse_dwt(float *B, const J2kBuffers &jb, int n_frames, const FrameSt
 namespace {
 
 constexpr int kMainHeaderBytes = 135;
-constexpr int kRatePathLen = 64;      // recorded steps of the all-fitting bisection path of a frame (k_rate)
+constexpr int kRateTrieNodes = 1536;  // recorded bisection steps of a frame (k_rate): ~80 per call less what calls share
 constexpr int kRateThreads = 512;     // k_rate: one workgroup per frame, about one code-block per thread
 constexpr int kWriteThreads = 256;    // k_write: one workgroup per frame (headers by one lane per resolution, bodies by all)
 
@@ -607,21 +607,30 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         double lo = mn, hi = mx, thresh = 0, stable = 0, prev = -1;
         bool lo_seen = false, hi_seen = false;
         int bytes_lo = 0, bytes_hi = 0;
-        // The bisection starts from the same bracket [mn, mx] at every call for this frame, and as long as every size
-        // so far fitted it visits the same thresholds: those sizes are remembered across calls (path_bytes, reset by
-        // the analysis), so a call replays its first ~25 steps - the expensive ones, no code-block is settled yet -
-        // from the record and starts computing where its budget first differs or the record ends.
+        // The bisection starts from the same bracket [mn, mx] at every call for this frame, so the threshold of a step
+        // is a function of the fits / does-not-fit outcomes before it.  The sizes found are kept across calls in a
+        // binary trie over those outcomes (reset by the analysis): a call replays its steps from the trie for as long
+        // as its budget leads it along recorded ones - the first ~25 always (everything fits while the threshold is
+        // far above the slopes that matter; they are the expensive steps, no code-block is settled yet), and most of
+        // the way for the later probes of a rate search, whose budgets differ little - and computes from there.
+        //   node = {bytes, child after "does not fit", child after "fits"}; node 0 = the first step
+        int *const trie = path_bytes + (size_t) frame * kRateTrieNodes * 3;
         const int known = path_n[frame];
-        int *const rec = path_bytes + (size_t) frame * kRatePathLen;
-        bool on_path = true, lo_from_rec = false, hi_from_rec = false;
+        int n_nodes = known;
+        int cur = known > 0 ? 0 : -1, parent = -1, pdir = 0;         // the node of this step (-1: not recorded yet) and its link
+        bool lo_from_rec = false, hi_from_rec = false;
         for (int i = 0; i < 128; i++) {
             thresh = (lo + hi) / 2;
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
-            if (on_path && i < known) {
-                const int bytes = rec[i];
-                if ((long long) bytes <= maxlen) { hi = thresh; stable = thresh; bytes_hi = bytes; hi_from_rec = true; }
-                else { lo = thresh; bytes_lo = bytes; lo_from_rec = true; on_path = false; }
+            if (cur >= 0) {
+                const int bytes = trie[3 * cur];
+                const int f = (long long) bytes <= maxlen;
+                if (f) { hi = thresh; stable = thresh; bytes_hi = bytes; hi_from_rec = true; hi_seen = false; }
+                else { lo = thresh; bytes_lo = bytes; lo_from_rec = true; lo_seen = false; }
+                parent = cur; pdir = f;
+                const int nxt = trie[3 * cur + 1 + f];               // (written by earlier launches only: nodes made in
+                cur = nxt > 0 ? nxt : -1;                            //  this one are never followed, see below)
                 continue;
             }
             // the walks at bracket ends that came from the record (needed to tell settled code-blocks)
@@ -645,10 +654,16 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             n_it++; n_real += (at_lo || at_hi) ? 0 : s_changed;
 #endif
             const bool fits = (long long) bytes <= maxlen;
-            if (on_path && i < kRatePathLen) {                       // (i == number of entries on record: the path is walked in order)
-                if (lane == 0) { rec[i] = bytes; path_n[frame] = i + 1; }
+            if (n_nodes < kRateTrieNodes && (parent >= 0 || n_nodes == 0)) {   // record this step and hang it under the previous one
+                if (lane == 0) {
+                    trie[3 * n_nodes] = bytes; trie[3 * n_nodes + 1] = 0; trie[3 * n_nodes + 2] = 0;
+                    if (parent >= 0) trie[3 * parent + 1 + pdir] = n_nodes;
+                    path_n[frame] = n_nodes + 1;
+                }
+                parent = n_nodes++; pdir = fits;
+            } else {
+                parent = -1;                                         // trie full: stop recording
             }
-            if (!fits) on_path = false;
             if (fits) bytes_hi = bytes; else bytes_lo = bytes;
             if (fits) { hi = thresh; stable = thresh; hi_seen = true; } else { lo = thresh; lo_seen = true; }
             // A pass is taken iff fl(thresh - slope) < DBL_EPSILON, which is monotone in thresh: a code-block whose

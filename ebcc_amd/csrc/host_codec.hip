@@ -11,6 +11,8 @@
 #include <cstdarg>
 #include <cstring>
 #include <ctime>
+#include <sched.h>
+#include <condition_variable>
 #include <map>
 #include <sys/resource.h>
 #include <sys/syscall.h>
@@ -18,7 +20,6 @@
 #include <tuple>
 #include <atomic>
 #include <mutex>
-#include <condition_variable>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -272,6 +273,21 @@ hipStream_t second_stream(ebcc_hip_ctx *c)
 {
     if (!c->stream2) EBCC_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     return c->stream2;
+}
+
+// Host threads of one encode call for the entropy stage (level-22 zstd of the residual streams is the longest host
+// step): EBCC_HOST_THREADS, default the CPUs in the affinity mask, at most 32.  Measured on the MI355X box (a 16-CPU
+// container quota on a 256-thread host; tools/gpu/threads_sweep.sh): the work comes in short bursts - 6 ms per
+// frame, once per slice - that stay far below the quota on average, so more threads than the quota's CPU count
+// shorten the burst (32 per slice: 251 ms/step, 16: 262, 64: 255); a process-wide pool shared by the slices was
+// slower than threads of the call's own at every size.
+unsigned entropy_threads()
+{
+    if (const char *e = getenv("EBCC_HOST_THREADS")) return (unsigned) std::max(1L, strtol(e, nullptr, 10));
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned) CPU_COUNT(&set);
+    return std::min(32u, std::max(4u, n));
 }
 
 // The base layer of a batch of chunks.  A chunk is one frame, or `tiles` frames stacked along the row axis that
@@ -680,6 +696,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
         }
         EBCC_HIP_CHECK(hipStreamSynchronize(rs));
+        // one job per frame on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so
+        // the host is never oversubscribed however many slices run
         std::atomic<size_t> next_frame{0};
         auto zworker = [&]() {
             // below the threads that steer the GPU (this one, the other slices'): they must not wait for a core
@@ -693,13 +711,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
         };
         std::vector<std::thread> zpool;
-        {
-            unsigned hw = std::thread::hardware_concurrency();
-            unsigned nthreads = hw ? std::min(16u, hw) : 4u;
-            if (const char *e = getenv("EBCC_HOST_THREADS")) nthreads = (unsigned) std::max(1L, strtol(e, nullptr, 10));
-            nthreads = (unsigned) std::min<size_t>(nthreads, n);
-            for (unsigned t = 0; t < nthreads; t++) zpool.emplace_back(zworker);
-        }
+        for (size_t t = 0; t < std::min<size_t>(entropy_threads(), n); t++) zpool.emplace_back(zworker);
         auto zjoin = [&]() { for (auto &t : zpool) if (t.joinable()) t.join(); };
         pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)

@@ -301,10 +301,13 @@ template <int CW> struct ColIdx { __device__ int operator()(int k, int l) const 
 constexpr int kRowT = 256, kColT = 1024;
 
 // rows of the region [0,n) x [0,rows) of the tile buffer at resolution r, in place (the horizontal extents are the
-// same for every tile: tiles span the image width)
+// same for every tile: tiles span the image width).  The inverse transform can take the three detail bands of the
+// level (and at r == 1 the LL band too) straight from the tier-1 decoder's output V (half-step units, same layout
+// as B), dequantising on the way: (float) v * (0.5f * step) as opj_t1_decode_cblk does; the LL quadrant of r > 1
+// is the previous level's result in B.
 template <bool FWD>
-__global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, const J2kGeom *geom, int r, const FrameState *fs,
-                                                     const int *active)
+__global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, const int32_t *__restrict__ V, const J2kGeom *geom, int r,
+                                                     const FrameState *fs, const int *active)
 {
     extern __shared__ float sm[];
     const int frame = blockIdx.y;
@@ -314,10 +317,21 @@ __global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, const
     const int dn = n - sn, tid = threadIdx.x;
     float *E = sm, *O = sm + sn;
     float *buf = B + (size_t) frame * ((size_t) W * g.H);
+    const int32_t *vbuf = V ? V + (size_t) frame * ((size_t) W * g.H) : nullptr;
+    const int rows_lo = g.rh[r - 1];                                     // rows of the LL / HL bands; LH / HH below
+    const float s_ll = 0.5f * g.bands[0].step_dec, s_hl = 0.5f * g.bands[3 * (r - 1) + 1].step_dec,
+                s_lh = 0.5f * g.bands[3 * (r - 1) + 2].step_dec, s_hh = 0.5f * g.bands[3 * (r - 1) + 3].step_dec;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         float *line = buf + (size_t) row * W;
         if (FWD) {
             for (int i = tid; i < n; i += kRowT) { float v = line[i]; ((i & 1) ? O : E)[i >> 1] = v; }
+        } else if (vbuf) {
+            const int32_t *vline = vbuf + (size_t) row * W;
+            const bool top = row < rows_lo;
+            const float s_lo = top ? s_ll : s_lh, s_hi = top ? s_hl : s_hh;
+            const bool lo_from_v = !top || r == 1;
+            for (int i = tid; i < sn; i += kRowT) E[i] = lo_from_v ? (float) vline[i] * s_lo : line[i];
+            for (int i = tid; i < dn; i += kRowT) O[i] = (float) vline[sn + i] * s_hi;
         } else {
             for (int i = tid; i < sn; i += kRowT) E[i] = line[i];
             for (int i = tid; i < dn; i += kRowT) O[i] = line[sn + i];
@@ -409,11 +423,10 @@ void dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameSt
     }
 }
 template <bool FWD>
-void dwt_rows(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+void dwt_rows(float *B, const int32_t *V, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
 {
     const int n = jb.geom.rw[r], rows = max_rows(jb, r);
-    if (n <= 1) return;
-    hipLaunchKernelGGL(k_j2k_rows<FWD>, dim3(min(rows, 96), n_frames), dim3(kRowT), (size_t) n * 4, s, B, jb.d_geom, r, fs, active);
+    hipLaunchKernelGGL(k_j2k_rows<FWD>, dim3(min(rows, 96), n_frames), dim3(kRowT), (size_t) n * 4, s, B, V, jb.d_geom, r, fs, active);
 }
 
 // ================================================================================================
@@ -876,7 +889,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     timing_begin("j2k_dwt_fwd", s);
     for (int r = kJ2kRes - 1; r >= 1; r--) {                           // opj_dwt_encode_procedure: vertical, then horizontal
         dwt_cols<true>(jb.B, jb, r, n_frames, fs, nullptr, s);
-        dwt_rows<true>(jb.B, jb, r, n_frames, fs, nullptr, s);
+        if (g.rw[r] > 1) dwt_rows<true>(jb.B, nullptr, jb, r, n_frames, fs, nullptr, s);
     }
     timing_end("j2k_dwt_fwd", s);
     hipLaunchKernelGGL(k_quantize, dim3(g.stride, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
@@ -908,11 +921,12 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
 }
 
-// inverse transform of the tile buffers, used by both decode flavours (j2k_rate.hip)
-void j2k_inverse_dwt(float *B, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+// dequantisation + inverse transform of the tier-1 decoder's output V into the tile buffers B, used by both decode
+// flavours (j2k_rate.hip)
+void j2k_inverse_dwt(float *B, const int32_t *V, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
 {
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
-        dwt_rows<false>(B, jb, r, n_frames, fs, active, s);
+        dwt_rows<false>(B, V, jb, r, n_frames, fs, active, s);
         dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
     }
 }

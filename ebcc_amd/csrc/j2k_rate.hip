@@ -16,7 +16,7 @@
 
 namespace ebcc {
 
-void j2k_inverse_dwt(float *B, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s);
+void j2k_inverse_dwt(float *B, const int32_t *V, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s);
 
 namespace {
 
@@ -1068,21 +1068,6 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
                       np, r, stripe, ck, tab);
 }
 
-__global__ __launch_bounds__(256) void k_dequant(const int32_t *__restrict__ V, const std::uint16_t *__restrict__ blkmap,
-                                                  float *__restrict__ B, const J2kGeom *geom, const J2kBlock *blocks,
-                                                  const FrameState *fs, const int *active)
-{
-    const int frame = blockIdx.y;
-    if ((active && !active[frame]) || fs[frame].const_field) return;
-    const size_t n_pix = (size_t) geom->W * geom->H;
-    const int32_t *v = V + (size_t) frame * n_pix;
-    float *b = B + (size_t) frame * n_pix;
-    blkmap = j2k_frame_blkmap(geom, blkmap, frame);
-    blocks = j2k_frame_blocks(geom, blocks, frame);                   // (the step sizes are the same at every tile position)
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x)
-        b[i] = (float) v[i] * (0.5f * geom->bands[blocks[blkmap[i]].band].step_dec);
-}
-
 // LDS carve-up of the rate / write kernels for the largest tile position of the context
 size_t rate_lds(const J2kBuffers &jb)
 {
@@ -1120,9 +1105,7 @@ void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, h
 static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s)
 {
     const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
-    hipLaunchKernelGGL(k_dequant, dim3(128, n_frames), dim3(256), 0, s, jb.V, jb.d_blkmap, jb.B, jb.d_geom, jb.d_blocks, jb.fs,
-                       d_active);
-    j2k_inverse_dwt(jb.B, jb, n_frames, jb.fs, d_active, s);
+    j2k_inverse_dwt(jb.B, jb.V, jb, n_frames, jb.fs, d_active, s);    // (dequantisation happens in the row passes)
     if (stats) {
         hipLaunchKernelGGL(k_finish<true>, dim3(kPartials, n_frames), dim3(256), 0, s, jb.B, data, jb.DEC, n_pix, jb.fs, jb.jf,
                            jb.partial, jb.partial_u, d_active);

@@ -349,11 +349,23 @@ __global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, const
     }
 }
 
+// What the last inverse column pass does with its result instead of storing it (FIN): DC level shift + rounding +
+// clamp (opj_tcd_dc_level_shift_decode), u16 -> fp32 (ebcc_codec.c:1130) into DEC, and with `data` the error
+// statistics against the input (get_mean_error :494-501, get_error_target_quantile :503-513) as one partial sum per
+// column tile.
+struct J2kFinish {
+    const float *data;             // nullptr: no statistics
+    float *DEC;
+    const J2kFrame *jf;
+    double *partial;               // [frames][kPartials]
+    unsigned long long *partial_u;
+};
+
 // columns of the region [0,cols) x [0,n) at resolution r, CW columns per tile staged through LDS, in place.  The
 // number of rows, of low-pass rows and the parity of the first row belong to the frame's tile position.
-template <bool FWD, int CW>
+template <bool FWD, int CW, bool FIN = false>
 __global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const J2kGeom *geom, int r, const FrameState *fs,
-                                                     const int *active)
+                                                     const int *active, J2kFinish fin = J2kFinish{})
 {
     extern __shared__ float sm[];
     const int frame = blockIdx.y;
@@ -376,13 +388,57 @@ __global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const
         __syncthreads();
         if (FWD) fdwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT, cas);
         else     idwt_tile(E, O, sn, dn, CW, ColIdx<CW>(), tid, kColT, cas);
-        for (int t = tid; t < n * CW; t += kColT) {
-            int y = t / CW, c = t - y * CW;
-            if (c < w) {
-                float v;
-                if (FWD) v = (y < sn ? E : O)[(y < sn ? y : y - sn) * CW + c];
-                else     v = (((y ^ cas) & 1) ? O : E)[(y >> 1) * CW + c];
-                buf[(size_t) y * W + x0 + c] = v;
+        if constexpr (FIN) {
+            __shared__ double red[kColT / 64];
+            __shared__ unsigned int redu[kColT / 64];
+            const size_t n_pix = (size_t) W * g.H;
+            const float *x = fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
+            float *d = fin.DEC + (size_t) frame * n_pix;
+            const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
+            const float target = x ? fin.jf[frame].target : 0.0f;
+            double acc = 0;
+            unsigned int bad = 0;
+            for (int t = tid; t < n * CW; t += kColT) {
+                int y = t / CW, c = t - y * CW;
+                if (c >= w) continue;
+                const float v = (((y ^ cas) & 1) ? O : E)[(y >> 1) * CW + c];
+                long long q;
+                if (v > 2147483647.0f) q = 65535;
+                else if (v < -2147483648.0f) q = 0;
+                else {
+                    q = (long long) __float2int_rn(v) + 32768;
+                    q = q < 0 ? 0 : (q > 65535 ? 65535 : q);
+                }
+                const float dv = ((float) (int) q / 65535.0f) * rng + mn;
+                const size_t i = (size_t) y * W + x0 + c;
+                d[i] = dv;
+                if (x) {
+                    const float e = x[i] - (dv + 0.0f);
+                    acc += (double) e;
+                    if (fabsf(e) > target) bad++;
+                }
+            }
+            if (x) {
+                for (int k = 32; k >= 1; k >>= 1) { acc += __shfl_xor(acc, k); bad += __shfl_xor(bad, k); }
+                if ((tid & 63) == 0) { red[tid >> 6] = acc; redu[tid >> 6] = bad; }
+                __syncthreads();
+                if (tid == 0) {
+                    double a = 0;
+                    unsigned long long b = 0;
+                    for (int k = 0; k < kColT / 64; k++) { a += red[k]; b += redu[k]; }
+                    fin.partial[(size_t) frame * kPartials + tile] = a;
+                    fin.partial_u[(size_t) frame * kPartials + tile] = b;
+                }
+            }
+        } else {
+            for (int t = tid; t < n * CW; t += kColT) {
+                int y = t / CW, c = t - y * CW;
+                if (c < w) {
+                    float v;
+                    if (FWD) v = (y < sn ? E : O)[(y < sn ? y : y - sn) * CW + c];
+                    else     v = (((y ^ cas) & 1) ? O : E)[(y >> 1) * CW + c];
+                    buf[(size_t) y * W + x0 + c] = v;
+                }
             }
         }
         __syncthreads();
@@ -405,22 +461,25 @@ static int max_rows(const J2kBuffers &jb, int r)
     return n;
 }
 
-template <bool FWD>
-void dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+// returns the number of column tiles (= statistics partials per frame when FIN)
+template <bool FWD, bool FIN = false>
+int dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s,
+             J2kFinish fin = J2kFinish{})
 {
     const int n = max_rows(jb, r), cols = jb.geom.rw[r];
-    if (n <= 1) return;
+    if (n <= 1) return 0;
     if ((size_t) n * 32 * 4 <= 156 * 1024) {
         size_t lds = (size_t) n * 32 * 4;
-        auto k = k_j2k_cols<FWD, 32>;
+        auto k = k_j2k_cols<FWD, 32, FIN>;
         big_lds(k, lds);
-        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 32), n_frames), dim3(kColT), lds, s, B, jb.d_geom, r, fs, active);
-    } else {
-        size_t lds = (size_t) n * 16 * 4;
-        auto k = k_j2k_cols<FWD, 16>;
-        big_lds(k, lds);
-        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 16), n_frames), dim3(kColT), lds, s, B, jb.d_geom, r, fs, active);
+        hipLaunchKernelGGL(k, dim3(ceil_div(cols, 32), n_frames), dim3(kColT), lds, s, B, jb.d_geom, r, fs, active, fin);
+        return ceil_div(cols, 32);
     }
+    size_t lds = (size_t) n * 16 * 4;
+    auto k = k_j2k_cols<FWD, 16, FIN>;
+    big_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(ceil_div(cols, 16), n_frames), dim3(kColT), lds, s, B, jb.d_geom, r, fs, active, fin);
+    return ceil_div(cols, 16);
 }
 template <bool FWD>
 void dwt_rows(float *B, const int32_t *V, const J2kBuffers &jb, int r, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
@@ -921,14 +980,19 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
 }
 
-// dequantisation + inverse transform of the tier-1 decoder's output V into the tile buffers B, used by both decode
-// flavours (j2k_rate.hip)
-void j2k_inverse_dwt(float *B, const int32_t *V, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s)
+// dequantisation + inverse transform of the tier-1 decoder's output V through the tile buffers B to the decoded
+// field jb.DEC, with the error statistics against `data` (if given) left as partial sums per frame; used by both
+// decode flavours (j2k_rate.hip).  Returns the number of partials per frame.
+int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuffers &jb, int n_frames, const FrameState *fs,
+                    const int *active, hipStream_t s)
 {
+    int partials = 0;
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
         dwt_rows<false>(B, V, jb, r, n_frames, fs, active, s);
-        dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
+        if (r + 1 < kJ2kRes) dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
+        else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, jb.DEC, jb.jf, jb.partial, jb.partial_u});
     }
+    return partials;
 }
 
 }  // namespace ebcc

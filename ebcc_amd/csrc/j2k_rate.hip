@@ -16,7 +16,8 @@
 
 namespace ebcc {
 
-void j2k_inverse_dwt(float *B, const int32_t *V, const J2kBuffers &jb, int n_frames, const FrameState *fs, const int *active, hipStream_t s);
+int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuffers &jb, int n_frames, const FrameState *fs,
+                    const int *active, hipStream_t s);
 
 namespace {
 
@@ -782,63 +783,15 @@ __global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__
     }
 }
 
-// DC level shift + rounding + clamp (opj_tcd_dc_level_shift_decode), u16 -> fp32 (ebcc_codec.c:1130), statistics
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_finish(const float *__restrict__ B, const float *__restrict__ data,
-                                                 float *__restrict__ DEC, size_t n_pix, const FrameState *fs, J2kFrame *jf,
-                                                 double *partial, unsigned long long *partial_u, const int *active)
-{
-    __shared__ double red[256];
-    __shared__ unsigned int redu[256];
-    const int frame = blockIdx.y;
-    if ((active && !active[frame]) || fs[frame].const_field) return;
-    const float *b = B + (size_t) frame * n_pix;
-    const float *x = STATS ? data + (size_t) frame * n_pix : nullptr;
-    float *d = DEC + (size_t) frame * n_pix;
-    const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
-    const float target = STATS ? jf[frame].target : 0.0f;
-    const size_t chunk = (n_pix + gridDim.x - 1) / gridDim.x;
-    const size_t lo = (size_t) blockIdx.x * chunk, hi = lo + chunk < n_pix ? lo + chunk : n_pix;
-    double acc = 0;
-    unsigned int bad = 0;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-        float v = b[i];
-        long long s;
-        if (v > 2147483647.0f) s = 65535;
-        else if (v < -2147483648.0f) s = 0;
-        else {
-            s = (long long) __float2int_rn(v) + 32768;
-            s = s < 0 ? 0 : (s > 65535 ? 65535 : s);
-        }
-        float dv = ((float) (int) s / 65535.0f) * rng + mn;
-        d[i] = dv;
-        if (STATS) {
-            float t = x[i] - (dv + 0.0f);
-            acc += (double) t;                                           // get_mean_error, :494-501
-            if (fabsf(t) > target) bad++;                                // get_error_target_quantile, :503-513
-        }
-    }
-    if (!STATS) return;
-    red[threadIdx.x] = acc; redu[threadIdx.x] = bad;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int) threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; redu[threadIdx.x] += redu[threadIdx.x + s]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        partial[(size_t) frame * kPartials + blockIdx.x] = red[0];
-        partial_u[(size_t) frame * kPartials + blockIdx.x] = redu[0];
-    }
-}
-
-__global__ void k_finish_reduce(const double *partial, const unsigned long long *partial_u, J2kFrame *jf, int n,
+// sums the per-tile statistics the last inverse column pass left (k_j2k_cols FIN, j2k_analysis.hip)
+__global__ void k_finish_reduce(const double *partial, const unsigned long long *partial_u, J2kFrame *jf, int n, int n_partials,
                                 const FrameState *fs, const int *active)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n || (active && !active[f]) || fs[f].const_field) return;
     double s = 0;
     unsigned long long b = 0;
-    for (int i = 0; i < kPartials; i++) { s += partial[(size_t) f * kPartials + i]; b += partial_u[(size_t) f * kPartials + i]; }
+    for (int i = 0; i < n_partials; i++) { s += partial[(size_t) f * kPartials + i]; b += partial_u[(size_t) f * kPartials + i]; }
     jf[f].err_sum = s;
     jf[f].nbad = b;
 }
@@ -1104,17 +1057,11 @@ void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, h
 
 static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s)
 {
-    const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
-    j2k_inverse_dwt(jb.B, jb.V, jb, n_frames, jb.fs, d_active, s);    // (dequantisation happens in the row passes)
-    if (stats) {
-        hipLaunchKernelGGL(k_finish<true>, dim3(kPartials, n_frames), dim3(256), 0, s, jb.B, data, jb.DEC, n_pix, jb.fs, jb.jf,
-                           jb.partial, jb.partial_u, d_active);
+    // dequantisation happens in the row passes, the mapping to the fp32 field and the statistics in the last column pass
+    const int partials = j2k_inverse_dwt(jb.B, jb.V, stats ? data : nullptr, jb, n_frames, jb.fs, d_active, s);
+    if (stats)
         hipLaunchKernelGGL(k_finish_reduce, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.partial, jb.partial_u, jb.jf,
-                           n_frames, jb.fs, d_active);
-    } else {
-        hipLaunchKernelGGL(k_finish<false>, dim3(kPartials, n_frames), dim3(256), 0, s, jb.B, (const float *) nullptr, jb.DEC,
-                           n_pix, jb.fs, jb.jf, jb.partial, jb.partial_u, d_active);
-    }
+                           n_frames, partials, jb.fs, d_active);
 }
 
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)

@@ -200,12 +200,13 @@ def main():
                 kern[name.decode()] = {"ms_avg": round(a.value / c.value, 4), "launches": c.value}
         def pmc_traffic(frames_per_launch):
             """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r01_pmc_*.json,
-            tools/gpu/profile.sh: separate FETCH_SIZE and WRITE_SIZE runs of `--frames 64` = 32 frames per dispatch).
-            gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB."""
+            tools/gpu/profile.sh: separate FETCH_SIZE and WRITE_SIZE runs of `--frames 64` on one slice = 64 frames per
+            dispatch).  gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB."""
             try:
-                f = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))["kernels"]
-                w = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write_size.json")))["kernels"]
-                per_frame = sum(2.0 * f[k]["per_dispatch"] + w[k]["per_dispatch"] for k in ("k_t1_symbols", "k_t1_mq")) * 1024.0 / 32.0
+                fj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
+                wj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write_size.json")))
+                f, w, per = fj["kernels"], wj["kernels"], float(fj.get("frames_per_dispatch") or 32)
+                per_frame = sum(2.0 * f[k]["per_dispatch"] + w[k]["per_dispatch"] for k in ("k_t1_symbols", "k_t1_mq")) * 1024.0 / per
                 return int(per_frame * frames_per_launch)
             except Exception:
                 return None

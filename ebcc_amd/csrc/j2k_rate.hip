@@ -354,8 +354,10 @@ __device__ inline unsigned int raw_byte(const unsigned int *raw, int pos)
     return (unsigned int) ((x << sh) >> 56);
 }
 
+// hdr_out (optional, LDS): header bytes of every resolution's packet.  Leaves the unstuffed header bits in L.raw
+// (resolution r at bit res_first[r] * 128) and every leaf's bit offset in L.leafbits for the writer.
 template <int NT>
-__device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum)
+__device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, int gid0, int lane, int *s_sum, int *hdr_out = nullptr)
 {
     const int INF = 0x7FFFFFFF;
     for (int i = lane; i < g.tree_nodes; i += NT) L.firstinc[i] = INF;
@@ -455,6 +457,7 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
     for (int r = lane >> 6; r < kJ2kRes; r += NT / 64) {
         const int region = g.res_first[r] * 128;
         const int T = 1 + L.leafbits[g.res_first[r + 1]] - L.leafbits[g.res_first[r]];
+        const int count_before = count;
         int p = 0;
         for (;;) {
             // first full byte == 0xFF at or after bit p (8-bit groups)
@@ -471,6 +474,7 @@ __device__ int layer_bytes_fast(const J2kGeom &g, RateLds &L, const int *rates, 
             p += 8 * (found + 1) + 7;
             if (p >= T) break;
         }
+        if (hdr_out && wl == 0) hdr_out[r] = count - count_before;
     }
     if (wl == 0) atomicAdd(s_sum, body + count);
     __syncthreads();
@@ -722,9 +726,23 @@ __global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__
     __syncthreads();
     uint8_t *base = stream + (size_t) frame * stream_cap;
 
-    // pass 1: sizes
-    trees_reset<kWriteThreads>(g, L, lane);
-    if (lane < kJ2kRes) { int body = 0; s_hdr[lane] = packet_header(lane, g, L.t, L.npass, rates, gid0, nullptr, &body); s_body[lane] = body; }
+    // Packet headers: the closed-form header bits of layer_bytes_fast (the evaluation k_rate sizes layers with), then
+    // the bit stuffing of B.10.1 - a byte that follows 0xFF carries 7 bits - as one short serial walk per resolution.
+    __shared__ int s_sum, s_T[kJ2kRes];
+    layer_bytes_fast<kWriteThreads>(g, L, rates, gid0, lane, &s_sum, s_hdr);
+    if (lane < kJ2kRes) {
+        s_body[lane] = 0;
+        s_T[lane] = 1 + L.leafbits[g.res_first[lane + 1]] - L.leafbits[g.res_first[lane]];
+    }
+    __syncthreads();
+    // segment lengths: per resolution totals, and (below) an exclusive scan in packet order for the destinations
+    for (int b = lane; b < g.nblocks; b += kWriteThreads) {
+        const int n = L.npass[b];
+        if (!n) continue;
+        int bi = 0;
+        while (bi + 1 < g.nbands && g.bands[bi + 1].first_block <= b) bi++;
+        atomicAdd(&s_body[g.bands[bi].res], rates[(size_t) (gid0 + b) * kJ2kMaxPasses + n - 1]);
+    }
     __syncthreads();
     if (lane == 0) {
         int off = kMainHeaderBytes + 14;
@@ -732,32 +750,49 @@ __global__ __launch_bounds__(kWriteThreads) void k_write(const int *__restrict__
         s_off[kJ2kRes] = off;
     }
     __syncthreads();
-    // pass 2: headers
-    trees_reset<kWriteThreads>(g, L, lane);
-    if (lane < kJ2kRes) { int body = 0; packet_header(lane, g, L.t, L.npass, rates, gid0, base + s_off[lane], &body); }
-    // bodies: destination offsets by a serial walk per resolution (cheap), then every thread copies
-    __syncthreads();
     if (lane < kJ2kRes) {
-        int off = s_off[lane] + s_hdr[lane];
-        for (int bi = 0; bi < g.nbands; bi++) {
-            const J2kBand &bd = g.bands[bi];
-            if (bd.res != lane) continue;
-            for (int k = 0; k < bd.ncw * bd.nch; k++) {
-                const int blk = bd.first_block + k, n = L.npass[blk];
-                L.leafbits[blk] = off;
-                if (n) off += rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
-            }
+        const int region = g.res_first[lane] * 128, T = s_T[lane];
+        uint8_t *o = base + s_off[lane];
+        int p = 0, nb = 0;
+        unsigned int last = 0;
+        while (p < T) {                                             // (bits past T are zero: the flush padding)
+            const int take = last == 0xFFu ? 7 : 8;
+            last = raw_byte(L.raw, region + p) >> (8 - take);
+            o[nb++] = (uint8_t) last;
+            p += take;
         }
+        if (last == 0xFFu) o[nb++] = 0;                             // Bio::flush after a 0xFF byte
     }
     __syncthreads();
+    {
+        __shared__ int s_wave[kWriteThreads / 64];
+        int running = 0;
+        for (int base_b = 0; base_b < g.nblocks; base_b += kWriteThreads) {
+            const int b = base_b + lane;
+            int v = 0;
+            if (b < g.nblocks && L.npass[b]) v = rates[(size_t) (gid0 + b) * kJ2kMaxPasses + L.npass[b] - 1];
+            int x = v;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((lane & 63) >= d) x += y; }
+            if ((lane & 63) == 63) s_wave[lane >> 6] = x;
+            __syncthreads();
+            int before = running, tot = 0;
+            for (int w = 0; w < kWriteThreads / 64; w++) { if (w < (lane >> 6)) before += s_wave[w]; tot += s_wave[w]; }
+            if (b < g.nblocks) L.leafbits[b] = before + x - v;      // bytes of the segments before this one, all resolutions
+            running += tot;
+            __syncthreads();
+        }
+    }
     {
         const int wave = lane >> 6, wl = lane & 63;
         for (int blk = wave; blk < g.nblocks; blk += kWriteThreads / 64) {           // one wave per code-block segment
             const int n = L.npass[blk];
             if (!n) continue;
+            int bi = 0;
+            while (bi + 1 < g.nbands && g.bands[bi + 1].first_block <= blk) bi++;
+            const int res = g.bands[bi].res;
             const int seglen = rates[(size_t) (gid0 + blk) * kJ2kMaxPasses + n - 1];
             const uint8_t *src = cblk_bytes + (size_t) (gid0 + blk) * kJ2kCblkBytes;
-            uint8_t *dst = base + L.leafbits[blk];
+            uint8_t *dst = base + s_off[res] + s_hdr[res] + (L.leafbits[blk] - L.leafbits[g.res_first[res]]);
             for (int i = wl; i < seglen; i += 64) dst[i] = src[i];
         }
     }

@@ -12,22 +12,22 @@ with open(sys.argv[1]) as f:
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         name = re.sub(r"^void ", "", name)
         name = name.split("(")[0].replace("ebcc::", "")
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 rows.sort()
 # last step = from the last k_in_init (input statistics open an encode batch) of the first slice onwards; keep it
 # simple: take the last 'k_in_init' whose predecessor gap is > 2 ms
 starts = [i for i, r in enumerate(rows) if r[2].startswith("k_in_init")]
 first = starts[-1]
 for i in reversed(starts):
-    if i == 0 or rows[i][0] - max(e for _, e, _ in rows[max(0, i - 50):i]) > 2_000_000:
+    if i == 0 or rows[i][0] - max(r[1] for r in rows[max(0, i - 50):i]) > 2_000_000:
         first = i
         break
 step = rows[first:]
-t0, t1 = step[0][0], max(e for _, e, _ in step)
+t0, t1 = step[0][0], max(r[1] for r in step)
 # union of busy intervals
 busy, cur_s, cur_e = 0, None, None
 gaps = []
-for s, e, n in step:
+for s, e, n, _q in step:
     if cur_e is None:
         cur_s, cur_e, last = s, e, n
     elif s <= cur_e:
@@ -39,9 +39,9 @@ for s, e, n in step:
         cur_s, cur_e, last = s, e, n
 busy += cur_e - cur_s
 print(f"step: {(t1 - t0) / 1e6:.2f} ms wall, GPU busy (any kernel running) {busy / 1e6:.2f} ms, idle {(t1 - t0 - busy) / 1e6:.2f} ms, "
-      f"sum of kernel durations {sum(e - s for s, e, _ in step) / 1e6:.2f} ms, {len(step)} kernels")
+      f"sum of kernel durations {sum(r[1] - r[0] for r in step) / 1e6:.2f} ms, {len(step)} kernels")
 per = {}
-for s, e, n in step:
+for s, e, n, _q in step:
     a = per.setdefault(n, [0, 0])
     a[0] += e - s
     a[1] += 1
@@ -55,7 +55,18 @@ for g, off, a, b in sorted(gaps, reverse=True)[:ng]:
 tot = sum(g for g, *_ in gaps)
 print(f"gaps: {len(gaps)}, total {tot / 1e6:.2f} ms; gaps > 100 us: {sum(1 for g, *_ in gaps if g > 100_000)} totalling {sum(g for g, *_ in gaps if g > 100_000) / 1e6:.2f} ms")
 # rounds: time between consecutive k_rate launches
-kr = [s for s, e, n in step if n == "k_rate"]
+kr = [r[0] for r in step if r[2] == "k_rate"]
 if len(kr) > 1:
     d = [(b - a) / 1e6 for a, b in zip(kr, kr[1:])]
     print("k_rate to k_rate (ms):", " ".join(f"{x:.2f}" for x in d))
+
+# per hardware queue: span, kernel time, time with nothing of this queue running (host turnaround + queueing)
+qs = {}
+for s_, e_, n_, q_ in step:
+    qs.setdefault(q_, []).append((s_, e_, n_))
+print("per queue: first..last (ms), kernels, kernel time (ms), idle inside the span (ms)")
+for q_, ks in sorted(qs.items(), key=lambda kv: kv[1][0][0]):
+    ks.sort()
+    span0, span1 = ks[0][0], max(e for _, e, _ in ks)
+    kt = sum(e - s for s, e, _ in ks)
+    print(f"  queue {q_}: {(span0 - t0) / 1e6:7.1f} .. {(span1 - t0) / 1e6:7.1f}  {len(ks):5d}  {kt / 1e6:8.1f}  {(span1 - span0 - kt) / 1e6:8.1f}   first {ks[0][2]}  last {ks[-1][2]}")

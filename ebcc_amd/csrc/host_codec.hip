@@ -623,8 +623,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64b, rc->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
                 b.push_ractive();
                 launch_reconstruct(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
-                launch_synthesis(rc->rb, (int) n, rc->d_active, rs);
-                launch_probe_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+                launch_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
                 fetch_frame_states(rc, n);
             };
             probe_residual();
@@ -912,12 +911,12 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s2));
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, n * sizeof(int), hipMemcpyHostToDevice, s2));
         launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n, ctx->d_active, s2);
-        launch_synthesis(ctx->rb, (int) n, ctx->d_active, s2);
+        launch_synthesis_head(ctx->rb, (int) n, ctx->d_active, s2);
         if (s2 != s) {
             EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
             EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
         }
-        launch_add_residual(jb.DEC, ctx->rb, (int) n, ctx->d_active, s);
+        launch_synthesis_tail_add(jb.DEC, ctx->rb, (int) n, ctx->d_active, s);       // last row pass: DEC += residual
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
     // constant fields: fill on the host side of the copy (rare path)
@@ -1003,8 +1002,8 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
         EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64b, rc->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
         EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_active, rc->h_active, n * sizeof(int), hipMemcpyHostToDevice, rs));
         launch_spiht_decode((const uint8_t *) rc->rb.stream, slot, rc->d_u64a, rc->d_u64b, rc->rb, (int) n, rc->d_active, rs);
-        launch_synthesis(rc->rb, (int) n, rc->d_active, rs);
-        launch_add_residual(jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+        launch_synthesis_head(rc->rb, (int) n, rc->d_active, rs);
+        launch_synthesis_tail_add(jb.DEC, rc->rb, (int) n, rc->d_active, rs);
         EBCC_HIP_CHECK(hipStreamSynchronize(rs));
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));

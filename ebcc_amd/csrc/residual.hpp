@@ -83,6 +83,12 @@ void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned 
 
 // idwt2full on A (dwt.h:305-317); result in A
 void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
+// the same with the last pass feeding the error statistics (as launch_probe_stats) / the addition (as
+// launch_add_residual) instead of storing the grid
+void launch_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames, const int *d_active,
+                            hipStream_t s);
+void launch_synthesis_head(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
+void launch_synthesis_tail_add(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
 
 // add_dc + crop + /255 (dwt.h:336-353, spiht_re.c:512-516) then r*(rmax-rmin)+rmin and the error
 // statistics of src/ebcc_codec.c:477-501 against data/decoded  -> fs.maxerr_bits, fs.err_sum

@@ -159,6 +159,86 @@ __global__ __launch_bounds__(kRowThreads) void k_rows_fwd(const float *__restric
     }
 }
 
+// residual pixel from the synthesised grid: add_dc (dwt.h:345-350), /255 (spiht_re.c:514),
+// de-normalisation (ebcc_codec.c:752)
+__device__ inline float residual_value(float a, float dc, float rmin, float rng)
+{
+    float v = floorf(a + dc);
+    v = v > 255.0f ? 255.0f : (v < 0.0f ? 0.0f : v);
+    float rn = v / 255.0f;
+    return rn * rng + rmin;
+}
+
+// What the last synthesis pass does with its rows instead of storing the grid (k_rows_inv_use):
+//   statistics (data != nullptr): max |x - (decoded + r)| and the sum of x - (decoded + r) per frame
+//                                 (ebcc_codec.c:481,498), one partial sum per workgroup;
+//   addition   (data == nullptr): out += r (ebcc_codec.c:1307).
+struct RowUse {
+    const float *data;
+    const float *decoded;          // statistics: the base layer's field; addition: unused
+    float *out;                    // addition: the field the residual is added to
+    int size_x, size_y;            // the image inside the padded grid
+    size_t n_pix;
+    FrameState *fs;
+    double *partial;               // [frames][kPartials]
+};
+
+__global__ __launch_bounds__(kRowThreads) void k_rows_inv_use(const float *__restrict__ src, int stride, size_t frame_stride, int n,
+                                                               int rows, const int *active, RowUse u)
+{
+    extern __shared__ float sm[];
+    __shared__ double red[kRowThreads / 64];
+    __shared__ float redm[kRowThreads / 64];
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const int half = n >> 1;
+    float *E = sm, *O = sm + half;
+    src += (size_t) frame * frame_stride;
+    const int tid = threadIdx.x;
+    const bool stats = u.data != nullptr;
+    const float *x = stats ? u.data + (size_t) frame * u.n_pix : nullptr;
+    const float *d = stats ? u.decoded + (size_t) frame * u.n_pix : nullptr;
+    float *o = stats ? nullptr : u.out + (size_t) frame * u.n_pix;
+    const float dc = stats ? u.fs[frame].dc : (float) u.fs[frame].dec_dc, rmin = u.fs[frame].rmin, rng = u.fs[frame].rmax - u.fs[frame].rmin;
+    double acc = 0;
+    float mx = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *s = src + (size_t) row * stride;
+        for (int k = tid; k < half; k += kRowThreads) {
+            E[k] = s[k];
+            O[k] = s[half + k];
+        }
+        __syncthreads();
+        lift_inverse_tile(E, O, half, 1, RowIdx(), tid, kRowThreads);
+        if (row < u.size_y) {
+            for (int xx = tid; xx < u.size_x; xx += kRowThreads) {
+                const float r = residual_value((xx & 1) ? O[xx >> 1] : E[xx >> 1], dc, rmin, rng);
+                const size_t i = (size_t) row * u.size_x + xx;
+                if (stats) {
+                    const float t = x[i] - (d[i] + r);
+                    acc += (double) t;
+                    const float e = fabsf(t);
+                    mx = e > mx ? e : mx;
+                } else {
+                    o[i] = o[i] + r;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!stats) return;
+    for (int k = 32; k >= 1; k >>= 1) { acc += __shfl_xor(acc, k); mx = fmaxf(mx, __shfl_xor(mx, k)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = acc; redm[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0;
+        float m = 0;
+        for (int k = 0; k < kRowThreads / 64; k++) { a += red[k]; m = fmaxf(m, redm[k]); }
+        u.partial[(size_t) frame * kPartials + blockIdx.x] = a;
+        atomicMax(&u.fs[frame].maxerr_bits, __float_as_uint(m));
+    }
+}
+
 __global__ __launch_bounds__(kRowThreads) void k_rows_inv(const float *__restrict__ src, float *__restrict__ dst,
                                                            int stride, size_t frame_stride, int n, int rows,
                                                            const int *active)
@@ -502,16 +582,6 @@ __global__ void k_probe_init(FrameState *fs, int n_frames, const int *active)
     }
 }
 
-// residual pixel from the synthesised grid: add_dc (dwt.h:345-350), /255 (spiht_re.c:514),
-// de-normalisation (ebcc_codec.c:752)
-__device__ inline float residual_value(float a, float dc, float rmin, float rng)
-{
-    float v = floorf(a + dc);
-    v = v > 255.0f ? 255.0f : (v < 0.0f ? 0.0f : v);
-    float rn = v / 255.0f;
-    return rn * rng + rmin;
-}
-
 __global__ __launch_bounds__(256) void k_probe_stats(const float *__restrict__ data, const float *__restrict__ decoded,
                                                       const float *__restrict__ A, Grid g, size_t n_pix, size_t np,
                                                       FrameState *fs, double *partial, const int *active)
@@ -721,6 +791,50 @@ void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_acti
         cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
         rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
     }
+}
+
+// the synthesis whose last row pass consumes the rows (RowUse) instead of storing the grid; returns the workgroups
+// per frame of that pass (= partial sums per frame)
+// every pass of the synthesis but the last row pass (result in rb.T)
+void launch_synthesis_head(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
+{
+    const Grid &g = rb.g;
+    for (int lv = g.stages - 1; lv >= 1; lv--) {
+        int nx = g.nx >> lv, ny = g.ny >> lv;
+        cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
+        rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
+    }
+    cols_pass<false>(rb.A, rb.T, rb, g.ny, g.nx, n_frames, d_active, s);
+}
+
+static int synthesis_tail(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s, RowUse u)
+{
+    const Grid &g = rb.g;
+    const int blocks = min(g.ny, 96);
+    u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
+    hipLaunchKernelGGL(k_rows_inv_use, dim3(blocks, n_frames), dim3(kRowThreads), (size_t) g.nx * sizeof(float), s, rb.T, g.nx, rb.np,
+                       g.nx, g.ny, d_active, u);
+    return blocks;
+}
+
+// synthesis + statistics of data - (decoded + residual) in one go (the grid itself is not kept)
+void launch_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames, const int *d_active,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(k_probe_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, d_active);
+    RowUse u{};
+    u.data = data; u.decoded = decoded;
+    launch_synthesis_head(rb, n_frames, d_active, s);
+    const int partials = synthesis_tail(rb, n_frames, d_active, s, u);
+    hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, partials, rb.fs, n_frames, d_active);
+}
+
+// after launch_synthesis_head: the last row pass with out += residual (ebcc_codec.c:1307) instead of a stored grid
+void launch_synthesis_tail_add(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
+{
+    RowUse u{};
+    u.out = out;
+    synthesis_tail(rb, n_frames, d_active, s, u);
 }
 
 void launch_probe_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,

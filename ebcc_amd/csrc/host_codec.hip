@@ -1063,7 +1063,7 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
 
 }  // namespace
 
-// Slices of a batch: EBCC_HIP_SLICES (encode, 1 = off) / EBCC_HIP_DECODE_SLICES (default 1) engines of max_frames / slices
+// Slices of a batch: EBCC_HIP_SLICES (encode, 1 = off) / EBCC_HIP_DECODE_SLICES engines of max_frames / slices
 // frames each, created on first use.  Small batches stay on the context's own engine.  More than two slices only
 // pay when the HIP runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the
 // application's streams; it is read when the runtime starts, so the application sets it): streams that share a
@@ -1174,7 +1174,9 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     const size_t n_pix = ctx->n_pix;
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
         return decode_batch(c, streams + lo, sizes + lo, cnt, d_frames_out + lo * n_pix, next);
-    }, "EBCC_HIP_DECODE_SLICES", 1);      // decode overlaps its two layers on the engine's two streams instead (decode_batch)
+    }, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);
+    // (decode overlaps its two layers on the engine's two streams, decode_batch; a second slice hides the host side -
+    //  parsing, zstd, uploads - of one half behind the kernels of the other when there are hardware queues for four streams)
 }
 
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)

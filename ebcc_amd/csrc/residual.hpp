@@ -83,20 +83,15 @@ void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned 
 
 // idwt2full on A (dwt.h:305-317); result in A
 void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
-// the same with the last pass feeding the error statistics (as launch_probe_stats) / the addition (as
-// launch_add_residual) instead of storing the grid
+// The same with the last row pass consuming the rows instead of storing the grid:
+//   _stats:    add_dc + crop + /255 (dwt.h:336-353, spiht_re.c:512-516), r*(rmax-rmin)+rmin and the error statistics
+//              of src/ebcc_codec.c:477-501 against data / decoded -> fs.maxerr_bits, fs.err_sum;
+//   _tail_add: out += r*(rmax-rmin)+rmin (src/ebcc_codec.c:1306-1308), dc from fs.dec_dc; after launch_synthesis_head
+//              (every pass but the last, possibly on another stream).
 void launch_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames, const int *d_active,
                             hipStream_t s);
 void launch_synthesis_head(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
 void launch_synthesis_tail_add(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
-
-// add_dc + crop + /255 (dwt.h:336-353, spiht_re.c:512-516) then r*(rmax-rmin)+rmin and the error
-// statistics of src/ebcc_codec.c:477-501 against data/decoded  -> fs.maxerr_bits, fs.err_sum
-void launch_probe_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
-                        const int *d_active, hipStream_t s);
-
-// add_dc + crop + /255 and out += r*(rmax-rmin)+rmin   (src/ebcc_codec.c:1306-1308); dc from fs.dec_dc
-void launch_add_residual(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
 
 // plain spiht_decode output image in [0,1] (spiht_re.c:508-516) for the unit entry point
 void launch_emit_image(float *image_out, const ResidualBuffers &rb, int n_frames, hipStream_t s);

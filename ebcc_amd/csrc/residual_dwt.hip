@@ -582,47 +582,6 @@ __global__ void k_probe_init(FrameState *fs, int n_frames, const int *active)
     }
 }
 
-__global__ __launch_bounds__(256) void k_probe_stats(const float *__restrict__ data, const float *__restrict__ decoded,
-                                                      const float *__restrict__ A, Grid g, size_t n_pix, size_t np,
-                                                      FrameState *fs, double *partial, const int *active)
-{
-    __shared__ double red[256];
-    __shared__ float redm[256];
-    const int frame = blockIdx.y;
-    if (active && !active[frame]) return;
-    const float *x = data + (size_t) frame * n_pix;
-    const float *d = decoded + (size_t) frame * n_pix;
-    const float *a = A + (size_t) frame * np;
-    const float dc = fs[frame].dc, rmin = fs[frame].rmin, rng = fs[frame].rmax - fs[frame].rmin;
-    const size_t chunk = (n_pix + gridDim.x - 1) / gridDim.x;
-    const size_t lo = (size_t) blockIdx.x * chunk;
-    const size_t hi = lo + chunk < n_pix ? lo + chunk : n_pix;
-    double acc = 0;
-    float mx = 0;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-        int y = (int) (i / g.size_x), xx = (int) (i - (size_t) y * g.size_x);
-        float r = residual_value(a[(size_t) y * g.nx + xx], dc, rmin, rng);
-        float t = x[i] - (d[i] + r);                                // ebcc_codec.c:481,498
-        acc += (double) t;
-        float e = fabsf(t);
-        mx = e > mx ? e : mx;
-    }
-    red[threadIdx.x] = acc;
-    redm[threadIdx.x] = mx;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int) threadIdx.x < s) {
-            red[threadIdx.x] += red[threadIdx.x + s];
-            redm[threadIdx.x] = fmaxf(redm[threadIdx.x], redm[threadIdx.x + s]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        partial[(size_t) frame * kPartials + blockIdx.x] = red[0];
-        atomicMax(&fs[frame].maxerr_bits, __float_as_uint(redm[0]));
-    }
-}
-
 __global__ void k_probe_finish(const double *partial, int n_partials, FrameState *fs, int n_frames, const int *active)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -630,20 +589,6 @@ __global__ void k_probe_finish(const double *partial, int n_partials, FrameState
     double s = 0;
     for (int i = 0; i < n_partials; i++) s += partial[(size_t) f * kPartials + i];
     fs[f].err_sum = s;
-}
-
-__global__ __launch_bounds__(256) void k_add_residual(float *__restrict__ out, const float *__restrict__ A, Grid g,
-                                                       size_t n_pix, size_t np, const FrameState *fs, const int *active)
-{
-    const int frame = blockIdx.y;
-    if (active && !active[frame]) return;
-    float *o = out + (size_t) frame * n_pix;
-    const float *a = A + (size_t) frame * np;
-    const float dc = (float) fs[frame].dec_dc, rmin = fs[frame].rmin, rng = fs[frame].rmax - fs[frame].rmin;
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
-        int y = (int) (i / g.size_x), xx = (int) (i - (size_t) y * g.size_x);
-        o[i] = o[i] + residual_value(a[(size_t) y * g.nx + xx], dc, rmin, rng);    // ebcc_codec.c:1307
-    }
 }
 
 __global__ __launch_bounds__(256) void k_emit_image(float *__restrict__ out, const float *__restrict__ A, Grid g,
@@ -835,24 +780,6 @@ void launch_synthesis_tail_add(float *out, const ResidualBuffers &rb, int n_fram
     RowUse u{};
     u.out = out;
     synthesis_tail(rb, n_frames, d_active, s, u);
-}
-
-void launch_probe_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
-                        const int *d_active, hipStream_t s)
-{
-    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
-    hipLaunchKernelGGL(k_probe_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, d_active);
-    hipLaunchKernelGGL(k_probe_stats, dim3(kPartials, n_frames), dim3(256), 0, s, data, decoded, rb.A, rb.g, n_pix,
-                       rb.np, rb.fs, rb.partial, d_active);
-    hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, kPartials, rb.fs,
-                       n_frames, d_active);
-}
-
-void launch_add_residual(float *out, const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
-{
-    size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
-    hipLaunchKernelGGL(k_add_residual, dim3(128, n_frames), dim3(256), 0, s, out, rb.A, rb.g, n_pix, rb.np, rb.fs,
-                       d_active);
 }
 
 void launch_emit_image(float *image_out, const ResidualBuffers &rb, int n_frames, hipStream_t s)

@@ -1036,6 +1036,46 @@ bool chunk_engines(int H, int W, size_t chunks, size_t tiles, ebcc_hip_ctx **ctx
     return true;
 }
 
+// Chunk <-> array copies of the chunking entry points (reference :311-370) as row copies: a chunk is a box, its rows
+// are contiguous in the array; rows / frames / columns past the array's edge repeat the last one (index clamping).
+struct ChunkBox {
+    size_t dims[3], cd[3], cnt[3];
+    size_t csize() const { return cd[0] * cd[1] * cd[2]; }
+    void origin(size_t cl, size_t org[3]) const { for (int d = 3; d-- > 0;) { org[d] = (cl % cnt[d]) * cd[d]; cl /= cnt[d]; } }
+    bool inside(size_t cl) const { size_t o[3]; origin(cl, o); return o[0] + cd[0] <= dims[0] && o[1] + cd[1] <= dims[1] && o[2] + cd[2] <= dims[2]; }
+    // chunks that are whole frames of the array: chunk cl is the contiguous range [cl * csize, (cl + 1) * csize)
+    bool slabs() const { return cd[1] == dims[1] && cd[2] == dims[2]; }
+    void gather(const float *data, size_t cl, float *dst) const
+    {
+        size_t org[3];
+        origin(cl, org);
+        const size_t w = std::min(cd[2], dims[2] - org[2]);
+        for (size_t z = 0; z < cd[0]; z++) {
+            const size_t zi = std::min(org[0] + z, dims[0] - 1);
+            for (size_t y = 0; y < cd[1]; y++) {
+                const size_t yi = std::min(org[1] + y, dims[1] - 1);
+                const float *src = data + (zi * dims[1] + yi) * dims[2] + org[2];
+                float *row = dst + (z * cd[1] + y) * cd[2];
+                memcpy(row, src, w * sizeof(float));
+                for (size_t x = w; x < cd[2]; x++) row[x] = src[w - 1];
+            }
+        }
+    }
+    void scatter(const float *src, size_t cl, float *out) const
+    {
+        size_t org[3];
+        origin(cl, org);
+        const size_t w = std::min(cd[2], dims[2] - org[2]);
+        for (size_t z = 0; z < cd[0] && org[0] + z < dims[0]; z++)
+            for (size_t y = 0; y < cd[1] && org[1] + y < dims[1]; y++)
+                memcpy(out + ((org[0] + z) * dims[1] + org[1] + y) * dims[2] + org[2], src + (z * cd[1] + y) * cd[2], w * sizeof(float));
+    }
+};
+
+int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, const float *h_frames, size_t n_frames, const codec_config_t *cfg,
+                      uint8_t **outs, size_t *sizes);
+int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out, float *h_out);
+
 // host-pointer convenience used by the reference-compatible entry points
 // n chunks of `tiles` frames of H x W each, contiguous in host memory
 size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
@@ -1051,8 +1091,14 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
     size_t done = 0;
     while (done < n) {
         size_t k = std::min(cap, n - done);
-        EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
-        int rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
+        int rcode;
+        if (tiles == 1) {
+            // one-frame chunks: the batch runs as concurrent slices, each uploading its own frames on its own stream
+            rcode = run_encode_slices(ctx, d, data + done * n_pix, k, cfg, outs + done, sizes + done);
+        } else {
+            EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
+            rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
+        }
         if (rcode == 2) { hipFree(d); exit(1); }                                               // check_nan_inf, :598-605
         if (rcode) { hipFree(d); return 0; }
         done += k;
@@ -1118,6 +1164,38 @@ static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env
     return worst;
 }
 
+namespace {
+
+// n_frames one-frame chunks as concurrent slices.  h_frames (optional): the frames in host memory - every slice then
+// uploads its own part into d_frames on its own stream first, so the uploads of later slices run beside the kernels of
+// earlier ones.
+int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, const float *h_frames, size_t n_frames, const codec_config_t *cfg,
+                      uint8_t **outs, size_t *sizes)
+{
+    const size_t n_pix = ctx->n_pix;
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
+        if (h_frames)
+            EBCC_HIP_CHECK(hipMemcpyAsync(const_cast<float *>(d_frames) + lo * n_pix, h_frames + lo * n_pix, cnt * n_pix * sizeof(float),
+                                          hipMemcpyHostToDevice, c->stream));
+        return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next);
+    }, "EBCC_HIP_SLICES", default_encode_slices());
+}
+
+// the decode counterpart; h_out (optional): every slice downloads its frames when they are done
+int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out, float *h_out)
+{
+    const size_t n_pix = ctx->n_pix;
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
+        const int r = decode_batch(c, streams + lo, sizes + lo, cnt, d_out + lo * n_pix, next);
+        if (r || !h_out) return r;
+        EBCC_HIP_CHECK(hipMemcpyAsync(h_out + lo * n_pix, d_out + lo * n_pix, cnt * n_pix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        EBCC_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return 0;
+    }, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);
+}
+
+}  // namespace
+
 extern "C" {
 
 void free_buffer(void *p) { if (p) free(p); }
@@ -1157,11 +1235,8 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     log_set_level_from_env();
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-    const size_t n_pix = ctx->n_pix;
     for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }   // on error: free the non-null ones
-    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
-        return encode_batch(c, d_frames + lo * n_pix, cnt, config, out_streams + lo, out_sizes + lo, next);
-    }, "EBCC_HIP_SLICES", default_encode_slices());
+    return run_encode_slices(ctx, d_frames, nullptr, n_frames, config, out_streams, out_sizes);
 }
 
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
@@ -1171,12 +1246,9 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     std::lock_guard<std::mutex> lock(g_mutex);
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-    const size_t n_pix = ctx->n_pix;
-    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
-        return decode_batch(c, streams + lo, sizes + lo, cnt, d_frames_out + lo * n_pix, next);
-    }, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);
     // (decode overlaps its two layers on the engine's two streams, decode_batch; a second slice hides the host side -
     //  parsing, zstd, uploads - of one half behind the kernels of the other when there are hardware queues for four streams)
+    return run_decode_slices(ctx, streams, sizes, n_frames, d_frames_out, nullptr);
 }
 
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
@@ -1274,27 +1346,23 @@ size_t ebcc_encode_chunking(float *data, codec_config_t *config, uint8_t **out_b
     if (padded > total && padded - total > total / 10)
         log_warn("Chunk padding adds %lu values over %lu real values (%.2f%%)", padded - total, total,
                  ((double) (padded - total) / (double) total) * 100.0);
-    // gather the chunks in C order of chunk index (:311-318), edge chunks padded by index clamping (:339-351)
-    std::vector<float> gathered(nchunks * csize);
-    for (size_t cl = 0; cl < nchunks; cl++) {
-        size_t org[3], t = cl;
-        for (int d = 3; d-- > 0;) { org[d] = (t % cnt[d]) * cd[d]; t /= cnt[d]; }
-        float *dst = gathered.data() + cl * csize;
-        for (size_t li = 0; li < csize; li++) {
-            size_t rem = li, idx[3];
-            for (int d = 3; d-- > 0;) {
-                size_t k = org[d] + rem % cd[d];
-                idx[d] = k < config->dims[d] - 1 ? k : config->dims[d] - 1;
-                rem /= cd[d];
-            }
-            dst[li] = data[(idx[0] * config->dims[1] + idx[1]) * config->dims[2] + idx[2]];
-        }
+    // the chunks in C order of chunk index (:311-318), edge chunks padded by index clamping (:339-351).  Chunks that
+    // are whole frames of the array need no copy at all.
+    ChunkBox box;
+    for (int i = 0; i < 3; i++) { box.dims[i] = config->dims[i]; box.cd[i] = cd[i]; box.cnt[i] = cnt[i]; }
+    bool in_place = box.slabs();
+    for (size_t cl = 0; cl < nchunks && in_place; cl++) in_place = box.inside(cl);
+    std::vector<float> gathered;
+    if (!in_place) {
+        gathered.resize(nchunks * csize);
+        for (size_t cl = 0; cl < nchunks; cl++) box.gather(data, cl, gathered.data() + cl * csize);
     }
+    const float *chunk_data = in_place ? data : gathered.data();
     codec_config_t cc = *config;
     for (int i = 0; i < 3; i++) { cc.dims[i] = cd[i]; cc.chunk_dims[i] = 0; }
     std::vector<uint8_t *> outs(nchunks, nullptr);
     std::vector<size_t> sizes(nchunks, 0);
-    if (encode_host_frames(gathered.data(), nchunks, (int) cd[1], (int) cd[2], &cc, outs.data(), sizes.data(), cd[0]) != nchunks) {
+    if (encode_host_frames(chunk_data, nchunks, (int) cd[1], (int) cd[2], &cc, outs.data(), sizes.data(), cd[0]) != nchunks) {
         for (auto p : outs) free(p);
         return 0;
     }
@@ -1378,38 +1446,41 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     }
     if (p != end) { log_fatal("Invalid chunked EBCC data: trailing payload bytes"); return 0; }
     const int H = (int) cd[1], W = (int) cd[2];
-    std::vector<float> chunks(nchunks * csize);
+    ChunkBox box;
+    for (int i = 0; i < 3; i++) { box.dims[i] = dims[i]; box.cd[i] = cd[i]; box.cnt[i] = cnt[i]; }
+    bool in_place = box.slabs();                               // chunks = whole frames of the array: decode straight into it
+    for (size_t cl = 0; cl < nchunks && in_place; cl++) in_place = box.inside(cl);
+    float *o = (float *) malloc(total * sizeof(float));
+    if (!o) { log_fatal("Failed to allocate chunked EBCC decode output"); return 0; }
+    std::vector<float> chunks;
+    if (!in_place) chunks.resize(nchunks * csize);
+    float *h_chunks = in_place ? o : chunks.data();
     {
         std::lock_guard<std::mutex> lock(g_mutex);
         const size_t tiles = cd[0];
         const size_t cap = std::min(nchunks, batch_capacity(csize));
         ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
-        if (!chunk_engines(H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+        if (!chunk_engines(H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); free(o); return 0; }
         float *d = nullptr;
         EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * csize * sizeof(float)));
         for (size_t done = 0; done < nchunks;) {
             size_t k = std::min(cap, nchunks - done);
-            const int rcode = tiles > 1 ? decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d)
-                                        : decode_batch(ctx, ptrs.data() + done, lens.data() + done, k, d);
-            if (rcode) { hipFree(d); return 0; }
-            EBCC_HIP_CHECK(hipMemcpy(chunks.data() + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
+            int rcode;
+            if (tiles > 1) {
+                rcode = decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d);
+                if (!rcode) EBCC_HIP_CHECK(hipMemcpy(h_chunks + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
+            } else {
+                EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+                if (!zstd().ok) { log_fatal("libzstd not available"); rcode = 1; }
+                else rcode = run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d, h_chunks + done * csize);
+            }
+            if (rcode) { hipFree(d); free(o); return 0; }
             done += k;
         }
         hipFree(d);
     }
-    float *o = (float *) malloc(total * sizeof(float));
-    if (!o) { log_fatal("Failed to allocate chunked EBCC decode output"); return 0; }
-    for (size_t cl = 0; cl < nchunks; cl++) {
-        size_t org[3], t = cl;
-        for (int d = 3; d-- > 0;) { org[d] = (t % cnt[d]) * cd[d]; t /= cnt[d]; }
-        const float *src = chunks.data() + cl * csize;
-        for (size_t li = 0; li < csize; li++) {                                                // :353-370
-            size_t rem = li, idx[3];
-            bool inb = true;
-            for (int d = 3; d-- > 0;) { idx[d] = org[d] + rem % cd[d]; if (idx[d] >= dims[d]) inb = false; rem /= cd[d]; }
-            if (inb) o[(idx[0] * dims[1] + idx[1]) * dims[2] + idx[2]] = src[li];
-        }
-    }
+    if (!in_place)
+        for (size_t cl = 0; cl < nchunks; cl++) box.scatter(chunks.data() + cl * csize, cl, o);          // :353-370
     *out_buffer = o;
     return total;
 }

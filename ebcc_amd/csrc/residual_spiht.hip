@@ -19,7 +19,12 @@ namespace ebcc {
 
 namespace {
 
-constexpr int kEncThreads = 256;
+// list entries swept per step (one per thread).  A step costs its scans and barriers, not its work: 512 entries per
+// step take 5.0 ms per launch where 256 took 8.5 (tools/gpu/spiht_threads.sh); 1024 does not build into a correct kernel.
+#ifndef EBCC_SPIHT_ENC_THREADS
+#define EBCC_SPIHT_ENC_THREADS 512
+#endif
+constexpr int kEncThreads = EBCC_SPIHT_ENC_THREADS;
 constexpr int kEncWaves = kEncThreads / kWave;
 constexpr int kHeaderBits = 120;      // IMS header incl. the 8-bit step (spiht_re.c:448-464,63)
 constexpr int kMaxEntryBits = 9;      // set bit + 4 x (significance + sign)

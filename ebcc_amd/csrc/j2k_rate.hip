@@ -23,7 +23,10 @@ namespace {
 
 constexpr int kMainHeaderBytes = 135;
 constexpr int kRateTrieNodes = 1536;  // recorded bisection steps of a frame (k_rate): ~80 per call less what calls share
-constexpr int kRateThreads = 512;     // k_rate: one workgroup per frame, about one code-block per thread
+#ifndef EBCC_RATE_THREADS
+#define EBCC_RATE_THREADS 512
+#endif
+constexpr int kRateThreads = EBCC_RATE_THREADS;     // k_rate: one workgroup per frame, about one code-block per thread
 constexpr int kWriteThreads = 256;    // k_write: one workgroup per frame (headers by one lane per resolution, bodies by all)
 
 __device__ inline int floorlog2d(int a) { return a > 1 ? 31 - __clz(a) : 0; }

@@ -55,6 +55,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     }
     ok &= (jb->nsym = ctx_alloc<uint32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->qplane = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->lastnp = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;
     ok &= (jb->blkmax = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->numbps = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;

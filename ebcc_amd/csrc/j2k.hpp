@@ -117,7 +117,8 @@ struct J2kBuffers {
     void *ckpt;                   // [frames*nblocks][passes * 16 stripes][9 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
     uint8_t *SYM;                 // [frames*nblocks][kJ2kSymCap] decision streams of the two-phase encoder (t1_core.hpp)
     std::uint32_t *nsym;          // [frames*nblocks] bytes in the stream
-    int *qplane;                  // [frames*nblocks] where the current probe's decode restarts: pass | stripe << 8 (-1: nothing)
+    int *qplane;                  // [frames*nblocks] where the current probe's decode restarts: pass | stripe << 8 (-1: nothing, -2: V is up to date)
+    int *lastnp;                  // [frames*nblocks] passes the code-block had in the frame's previous probe decode (-1: none yet; reset by the analysis)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
     int *blkmax;                  // [frames*nblocks] max |q6|
     int *numbps;                  // [frames*nblocks]

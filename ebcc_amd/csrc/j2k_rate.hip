@@ -928,7 +928,7 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
 //                  registers from the checkpoint, then only passes r .. n-1 on the truncated bytes
 // ================================================================================================
 __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restrict__ npass, const int *__restrict__ rates,
-                             void *ckpt, int *__restrict__ rpass, const J2kGeom *geom,
+                             void *ckpt, int *__restrict__ rpass, int *__restrict__ lastnp, const J2kGeom *geom,
                              const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -936,6 +936,10 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
     const int frame = gid / geom->stride;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const int n = npass[gid], P = numbps[gid];
+    // a code-block that keeps the passes it had in the frame's previous probe keeps its decoded values: V still
+    // holds them (later bisection steps move few code-blocks)
+    if (lastnp[gid] == n) { rpass[gid] = -2; return; }
+    lastnp[gid] = n;
     int plan = -1;
     if (n > 0 && P > 0) {
         const int len = rates[(size_t) gid * kJ2kMaxPasses + n - 1];
@@ -973,6 +977,7 @@ __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ 
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
         const int bi = blkmap[i], gid = gid0 + bi;
         const int plan = rpass[gid];
+        if (plan == -2) continue;                                       // unchanged code-block: V is up to date
         const int q6 = q[i];
         const unsigned int a = (unsigned int) (q6 < 0 ? -q6 : q6) >> 6;
         int out = 0;
@@ -1107,7 +1112,7 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
     const int total = n_frames * jb.geom.stride;
     void *ck = jb.ckpt;
     hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
-                       jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
+                       jb.lastnp, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
     hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.numbps, jb.SPS, jb.d_blkmap, jb.V,
                        jb.d_geom, jb.d_blocks, jb.fs, d_active);
     timing_begin("t1_probe_decode", s);

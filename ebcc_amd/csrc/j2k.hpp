@@ -144,7 +144,7 @@ struct J2kBuffers {
 // union of its lanes' paths, and with 76 288 code-blocks a full 64-lane mapping leaves ~1 wave per SIMD, so
 // the SIMDs sit idle between dependent instructions.  Fewer code-blocks per wave = more waves in flight and
 // smaller unions.  Defaults measured on MI355X (profiles/): decision pass 64 and MQ pass 64 (their lanes share one
-// instruction stream), probe restart 16, decode 8; EBCC_T1_LPW="<n>" or "<a>,<b>,<c>,<d>" overrides them.
+// instruction stream), probe restart 4, decode 4 (the per-sample decoder is branchy: fewer lanes, smaller unions); EBCC_T1_LPW="<n>" or "<a>,<b>,<c>,<d>" overrides them.
 enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
 int t1_lanes_per_wave(int kernel);
 

@@ -30,14 +30,14 @@ static const double kNormsReal[4][10] = {
 
 int t1_lanes_per_wave(int kernel)
 {
-    // EBCC_T1_LPW = "<n>" (all kernels) or "<decision pass>,<MQ pass>,<probe restart>,<decode>", each 8, 16, 32 or 64
+    // EBCC_T1_LPW = "<n>" (all kernels) or "<decision pass>,<MQ pass>,<probe restart>,<decode>", each a power of two up to 64
     // (read at every launch: a tuning knob, results do not depend on it)
-    int t[4] = {64, 64, 16, 8};
+    int t[4] = {64, 64, 4, 4};
     if (const char *e = getenv("EBCC_T1_LPW")) {
         int v[4], n = sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
         for (int i = 0; i < 4; i++) {
             const int x = n == 1 ? v[0] : (i < n ? v[i] : 0);
-            if (x == 8 || x == 16 || x == 32 || x == 64) t[i] = x;
+            if (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32 || x == 64) t[i] = x;
         }
     }
     return t[kernel & 3];

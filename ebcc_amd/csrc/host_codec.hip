@@ -348,14 +348,15 @@ struct Batch {
     // the chunk mask for the residual engine's kernels
     void push_ractive() { EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_active, active.data(), sizeof(int) * n, hipMemcpyHostToDevice, rs)); }
     // one probe of the base layer for the active chunks: rate allocation at jf[c].cr (+ decode and statistics)
-    void launch_probe(bool decode)
+    // keep_field = false: only the statistics are wanted, jb.DEC stays what it was
+    void launch_probe(bool decode, bool keep_field = true)
     {
         push_jf();
         push_active();
         launch_j2k_rate(jb, (int) nt, d_active, s);
-        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) nt, d_active, s);
+        if (decode) launch_j2k_probe_decode(d_frames, jb, (int) nt, d_active, s, keep_field);
     }
-    void probe(bool decode) { launch_probe(decode); fetch_jf(); }
+    void probe(bool decode, bool keep_field = true) { launch_probe(decode, keep_field); fetch_jf(); }
     // codestream of the current layer assignment of the active chunks -> jobs[c].tail
     template <class Jobs>
     void collect_tails(Jobs &jobs)
@@ -437,12 +438,12 @@ void run_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
             if (j.want[k]) { b.active[f] = 1; b.jf[f].cr = j.want_cr[k]; any = true; }
         }
         if (!any) break;
-        b.probe(true);
+        b.probe(true, k == 0);                                   // (search 1 uses the statistics only: the field of search 0 stays)
         for (size_t f = 0; f < n; f++) {
             if (!b.active[f]) continue;
             Job &j = jobs[f];
             const J2kFrame &r = b.jf[f];
-            b.state_cr[f] = r.cr;
+            if (k == 0) b.state_cr[f] = r.cr;
             if (!j.find_probe(r.cr)) j.probes.push_back(ProbeRec{r.cr, r.nbad, r.stream_bytes, r.err_sum});
             log_trace("frame %zu (search %d): cr %f 1-quantile %.1e jp2_length %d", f, k, r.cr, (double) r.nbad / (double) n_pix,
                       r.stream_bytes);

@@ -161,8 +161,10 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
 // write the codestream of the current layer assignment into jb.stream
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
 // what opj_decode returns for the current layer assignment (decoded in place from the code-block
-// slots), mapped to fp32 as :1130 -> jb.DEC, and the error statistics against `data`
-void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
+// slots), mapped to fp32 as :1130 -> jb.DEC (keep_field; a probe that is only asked for the statistics leaves jb.DEC
+// as it is), and the error statistics against `data`
+void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s,
+                             bool keep_field = true);
 // true decode of codestreams whose packet headers were parsed on the host into jb.dec_table
 // (fs[f].minv/maxv must hold the header's values); result in jb.DEC
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s);

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const
             __shared__ unsigned int redu[kColT / 64];
             const size_t n_pix = (size_t) W * g.H;
             const float *x = fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
-            float *d = fin.DEC + (size_t) frame * n_pix;
+            float *d = fin.DEC ? fin.DEC + (size_t) frame * n_pix : nullptr;     // (null: statistics only)
             const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
             const float target = x ? fin.jf[frame].target : 0.0f;
             double acc = 0;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const
                 }
                 const float dv = ((float) (int) q / 65535.0f) * rng + mn;
                 const size_t i = (size_t) y * W + x0 + c;
-                d[i] = dv;
+                if (d) d[i] = dv;
                 if (x) {
                     const float e = x[i] - (dv + 0.0f);
                     acc += (double) e;
@@ -985,13 +985,13 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
 // field jb.DEC, with the error statistics against `data` (if given) left as partial sums per frame; used by both
 // decode flavours (j2k_rate.hip).  Returns the number of partials per frame.
 int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuffers &jb, int n_frames, const FrameState *fs,
-                    const int *active, hipStream_t s)
+                    const int *active, hipStream_t s, bool keep_field)
 {
     int partials = 0;
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
         dwt_rows<false>(B, V, jb, r, n_frames, fs, active, s);
         if (r + 1 < kJ2kRes) dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
-        else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, jb.DEC, jb.jf, jb.partial, jb.partial_u});
+        else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u});
     }
     return partials;
 }

@@ -17,7 +17,7 @@
 namespace ebcc {
 
 int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuffers &jb, int n_frames, const FrameState *fs,
-                    const int *active, hipStream_t s);
+                    const int *active, hipStream_t s, bool keep_field);
 
 namespace {
 
@@ -1098,16 +1098,17 @@ void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, h
                        jb.cblk_bytes, jb.stream, jb.stream_cap, jb.d_geom, jb.jf, jb.fs, d_active);
 }
 
-static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s)
+static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s,
+                        bool keep_field = true)
 {
     // dequantisation happens in the row passes, the mapping to the fp32 field and the statistics in the last column pass
-    const int partials = j2k_inverse_dwt(jb.B, jb.V, stats ? data : nullptr, jb, n_frames, jb.fs, d_active, s);
+    const int partials = j2k_inverse_dwt(jb.B, jb.V, stats ? data : nullptr, jb, n_frames, jb.fs, d_active, s, keep_field);
     if (stats)
         hipLaunchKernelGGL(k_finish_reduce, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.partial, jb.partial_u, jb.jf,
                            n_frames, partials, jb.fs, d_active);
 }
 
-void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
+void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, bool keep_field)
 {
     const int total = n_frames * jb.geom.stride;
     void *ck = jb.ckpt;
@@ -1121,7 +1122,7 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
                        jb.VISP, jb.cblk_bytes, jb.numbps, jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs,
                        d_active, total, lpw);
     timing_end("t1_probe_decode", s);
-    decode_tail(data, jb, n_frames, d_active, true, s);
+    decode_tail(data, jb, n_frames, d_active, true, s, keep_field);
 }
 
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)

@@ -134,6 +134,8 @@ def main():
     n = args.frames
     ctx = lib.ebcc_hip_create(local_rank, n, H, W)
     assert ctx, lib.ebcc_hip_last_error()
+    lib.ebcc_hip_prepare.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert lib.ebcc_hip_prepare(ctx, n) == 0                    # slice engines: part of the context, not of a step
     frames = synth_frames(torch, n, device, seed=rank)
     out = torch.empty_like(frames)
     torch.cuda.synchronize()

@@ -1224,6 +1224,18 @@ void print_config(codec_config_t *c)
     if (t == RELATIVE_ERROR) log_info("relative error:\t%f", c->error);
 }
 
+int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
+{
+    if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_prepare: bad batch"); return 1; }
+    std::lock_guard<std::mutex> lock(g_mutex);
+    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    slice_engines(ctx, n_frames, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);   // (the coarser slicing first:
+    slice_engines(ctx, n_frames, "EBCC_HIP_SLICES", default_encode_slices());                        //  its lanes serve both)
+    second_stream(ctx);
+    for (ebcc_hip_ctx *c : ctx->lanes) second_stream(c);
+    return 0;
+}
+
 int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
                            uint8_t **out_streams, size_t *out_sizes)
 {

@@ -86,8 +86,11 @@ int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const 
  * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
  * one frame / ebcc_encode_chunking with chunk_dims {1,H,W} produce).  Streams are malloc'd (free_buffer).
  * Return 0 = ok, 1 = error, 2 = NaN/Inf in the input; on failure entries of out_streams that are not NULL
- * still have to be freed.  A batch is coded as EBCC_HIP_SLICES (default 2) concurrent slices, each on its own
- * stream and host thread; results do not depend on the slicing. */
+ * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default 4 when the process has
+ * GPU_MAX_HW_QUEUES >= 8, else 2), each on its own engine, stream and host thread; results do not depend on the
+ * slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
+ * n_frames (part of setting a context up, like ebcc_hip_create).  Returns 0. */
+int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
 int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
                            uint8_t **out_streams, size_t *out_sizes);
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,

@@ -250,6 +250,46 @@ struct PassTab {
 };
 
 // opj_tcd_makelayer for one quality layer
+// opj_tcd_makelayer's greedy walk over the passes of code-block b: passes taken (count returned, bit mask in m0 / m1)
+template <bool LDS>
+__device__ inline int walk_block(const PassTab &pt, const int *totalpasses, int gid0, int b, double thresh, unsigned long long &m0,
+                                 unsigned long long &m1)
+{
+    m0 = m1 = 0;
+    int tp;
+    if constexpr (LDS) tp = pt.l_off[b + 1] - pt.l_off[b]; else tp = totalpasses[gid0 + b];
+    const int base = pt.base_of<LDS>(b);
+    int n = 0;
+    if (thresh < 0) return tp;
+    int rbase = 0;                                                   // rate / distortion of the last pass taken
+    double dbase = 0;
+    for (int p = 0; p < tp; p++) {
+        const int rp = pt.rate<LDS>(base, p);
+        const double dp = pt.dist<LDS>(base, p);
+        unsigned int dr;
+        double dd;
+        if (n == 0) { dr = (unsigned int) rp; dd = dp; }
+        else { dr = (unsigned int) (rp - rbase); dd = dp - dbase; }
+        // OpenJPEG's test is  thresh - fl(dd / dr) < DBL_EPSILON.  The outcome is already certain whenever dd and
+        // thresh * dr differ by more than rounding can bridge (1e-11 relative, against 2^-52 per operation); only the
+        // narrow band in between is divided.  (The reject shortcut also needs DBL_EPSILON to be negligible next to
+        // thresh.)
+        bool take;
+        if (!dr) take = dd != 0;
+        else {
+            const double tdr = thresh * (double) dr;
+            if (dd >= tdr * 1.00000000001) take = true;
+            else if (thresh >= 1e-4 && dd <= tdr * 0.99999999999) take = false;
+            else take = thresh - (dd / dr) < DBL_EPSILON;
+        }
+        if (take) {
+            n = p + 1; rbase = rp; dbase = dp;
+            if (p < 64) m0 |= 1ull << p; else m1 |= 1ull << (p - 64);
+        }
+    }
+    return n;
+}
+
 // `path` (optional): [2][nblocks] bit masks of the passes taken, i.e. the whole greedy walk and not just its end;
 // `frozen` (optional): code-blocks whose walk cannot change any more (k_rate) keep their assignment
 template <int NT, bool LDS>
@@ -258,40 +298,8 @@ __device__ void make_layer_impl(const J2kGeom &g, RateLds &L, const int *totalpa
 {
     for (int b = lane; b < g.nblocks; b += NT) {
         if (frozen && frozen[b]) continue;
-        unsigned long long m0 = 0, m1 = 0;
-        int tp;
-        if constexpr (LDS) tp = pt.l_off[b + 1] - pt.l_off[b]; else tp = totalpasses[gid0 + b];
-        const int base = pt.base_of<LDS>(b);
-        int n = 0;
-        if (thresh < 0) n = tp;
-        else {
-            int rbase = 0;                                           // rate / distortion of the last pass taken
-            double dbase = 0;
-            for (int p = 0; p < tp; p++) {
-                const int rp = pt.rate<LDS>(base, p);
-                const double dp = pt.dist<LDS>(base, p);
-                unsigned int dr;
-                double dd;
-                if (n == 0) { dr = (unsigned int) rp; dd = dp; }
-                else { dr = (unsigned int) (rp - rbase); dd = dp - dbase; }
-                // OpenJPEG's test is  thresh - fl(dd / dr) < DBL_EPSILON.  The outcome is already certain whenever dd
-                // and thresh * dr differ by more than rounding can bridge (1e-11 relative, against 2^-52 per
-                // operation); only the narrow band in between is divided.  (The reject shortcut also needs
-                // DBL_EPSILON to be negligible next to thresh.)
-                bool take;
-                if (!dr) take = dd != 0;
-                else {
-                    const double tdr = thresh * (double) dr;
-                    if (dd >= tdr * 1.00000000001) take = true;
-                    else if (thresh >= 1e-4 && dd <= tdr * 0.99999999999) take = false;
-                    else take = thresh - (dd / dr) < DBL_EPSILON;
-                }
-                if (take) {
-                    n = p + 1; rbase = rp; dbase = dp;
-                    if (p < 64) m0 |= 1ull << p; else m1 |= 1ull << (p - 64);
-                }
-            }
-        }
+        unsigned long long m0, m1;
+        const int n = walk_block<LDS>(pt, totalpasses, gid0, b, thresh, m0, m1);
         L.npass[b] = (short) n;
         if (path) { path[b] = m0; path[g.nblocks + b] = m1; }
     }
@@ -501,6 +509,8 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     const long long t_start = wall_clock64();                        // 100 MHz
 #endif
     __shared__ double s_min[kRateThreads / 64], s_max[kRateThreads / 64];
+    __shared__ double s_td[5];                                        // state handed between the block-wide loop and its tail
+    __shared__ int s_ti[5], s_nun, s_list[64];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
     const J2kGeom &g = j2k_frame_geom(geom, frame);
@@ -645,6 +655,8 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             if (hi_from_rec) { make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, hi, lane, p_hi); hi_seen = true; hi_from_rec = false; }
             if (lo_from_rec) { make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, lo, lane, p_lo); lo_seen = true; lo_from_rec = false; }
             { RP_T0; make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, thresh, lane, p_cur, frozen); RP_ADD(t_ml); }
+            if (lane == 0) s_nun = 0;       // (after the barrier make_layer ends with: every thread is done with the previous
+                                            //  step's value; before the barriers below: ahead of this step's additions)
             // late iterations alternate between the assignments of the two bracket ends: their sizes are known
             int at_lo = lo_seen, at_hi = hi_seen;
             for (int b = lane; b < g.nblocks; b += kRateThreads) {
@@ -685,9 +697,61 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                 if (frozen[b]) continue;
                 end[b] = p_cur[b]; end[g.nblocks + b] = p_cur[g.nblocks + b];
                 if (lo_seen && hi_seen && p_lo[b] == p_hi[b] && p_lo[g.nblocks + b] == p_hi[g.nblocks + b]) frozen[b] = 1;
-                else same = 0;
+                else {
+                    same = 0;
+                    const int k = atomicAdd(&s_nun, 1);              // the code-blocks still open, for the tail below
+                    if (k < 64) s_list[k] = b;
+                }
             }
             if (__syncthreads_and(same)) { converged = true; break; }
+            // Tail: once both ends of the bracket are known and at most 64 code-blocks are still open, the steps that
+            // land on one of the two end assignments again (nearly all of the ~45 that remain: the bisection is
+            // closing in on one slope) need no barrier and no sizing - one wave walks the open code-blocks, a lane
+            // each, until the thresholds repeat or a step produces a third assignment, which goes back through the
+            // block-wide path above.
+            if (lo_seen && hi_seen && s_nun <= 64) {
+                if (lane < 64) {
+                    const int nb = g.nblocks, b = lane < s_nun ? s_list[lane] : -1;
+                    double tlo = lo, thi = hi, tprev = prev, tstable = stable, tthresh = thresh;
+                    int ti = i, tn = n_nodes, tparent = parent, tpdir = pdir, status = 0;
+                    for (int j = i + 1; j < 128; j++) {
+                        const double t = (tlo + thi) / 2;
+                        if (t == tprev) { tthresh = t; break; }      // the bisection has ended
+                        unsigned long long m0 = 0, m1 = 0;
+                        if (b >= 0) {
+                            if (pt.lds) walk_block<true>(pt, totalpasses, gid0, b, t, m0, m1);
+                            else walk_block<false>(pt, totalpasses, gid0, b, t, m0, m1);
+                        }
+                        const int all_lo = __all(b < 0 || (m0 == p_lo[b] && m1 == p_lo[nb + b]));
+                        const int all_hi = __all(b < 0 || (m0 == p_hi[b] && m1 == p_hi[nb + b]));
+                        if (!all_lo && !all_hi) { status = 1; break; }   // a third assignment: not committed here
+                        tthresh = t; tprev = t; ti = j;
+                        const int bytes = all_lo ? bytes_lo : bytes_hi;
+                        const bool fits = (long long) bytes <= maxlen;
+                        if (tn < kRateTrieNodes && (tparent >= 0 || tn == 0)) {
+                            if (lane == 0) {
+                                trie[3 * tn] = bytes; trie[3 * tn + 1] = 0; trie[3 * tn + 2] = 0;
+                                if (tparent >= 0) trie[3 * tparent + 1 + tpdir] = tn;
+                                path_n[frame] = tn + 1;
+                            }
+                            tparent = tn++; tpdir = fits;
+                        } else {
+                            tparent = -1;
+                        }
+                        if (fits) { thi = t; tstable = t; } else { tlo = t; }
+                    }
+                    if (lane == 0) {
+                        s_td[0] = tlo; s_td[1] = thi; s_td[2] = tprev; s_td[3] = tstable; s_td[4] = tthresh;
+                        s_ti[0] = ti; s_ti[1] = tn; s_ti[2] = tparent; s_ti[3] = tpdir; s_ti[4] = status;
+                    }
+                }
+                __syncthreads();
+                lo = s_td[0]; hi = s_td[1]; prev = s_td[2]; stable = s_td[3]; thresh = s_td[4];
+                i = s_ti[0]; n_nodes = s_ti[1]; parent = s_ti[2]; pdir = s_ti[3];
+                const int status = s_ti[4];
+                __syncthreads();                                     // (s_td / s_ti are written again on the next visit)
+                if (status == 0) break;                              // ended in the tail: thresh, stable as the loop leaves them
+            }
         }
         good = stable == 0 ? thresh : stable;
     }

@@ -1,6 +1,7 @@
 // engine.hip - context management and the residual-layer C-ABI (include/ebcc_hip.h).
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 #include <mutex>
 #include <string>
@@ -46,6 +47,65 @@ template uint8_t *ctx_alloc<uint8_t>(ebcc_hip_ctx *, size_t);
 template double *ctx_alloc<double>(ebcc_hip_ctx *, size_t);
 template unsigned long long *ctx_alloc<unsigned long long>(ebcc_hip_ctx *, size_t);
 template FrameState *ctx_alloc<FrameState>(ebcc_hip_ctx *, size_t);
+
+// ---- staging of per-frame pieces --------------------------------------------------------------------
+namespace {
+
+// pack = true:  staged[off[f] .. + len[f]) = slot f; false: the other way.  Slots and offsets are 4-byte aligned;
+// lengths are rounded up to whole words (inside the slot / the 16-byte aligned piece).
+__global__ __launch_bounds__(256) void k_stage(uint8_t *slots, size_t stride, const unsigned long long *pack, uint8_t *staged, int to_stage)
+{
+    const int f = blockIdx.x;
+    const unsigned long long off = pack[2 * f], len = pack[2 * f + 1];
+    if (!len) return;
+    uint32_t *a = (uint32_t *) (slots + (size_t) f * stride), *b = (uint32_t *) (staged + off);
+    const size_t words = (size_t) ((len + 3) / 4);
+    for (size_t i = (size_t) blockIdx.y * blockDim.x + threadIdx.x; i < words; i += (size_t) gridDim.y * blockDim.x) {
+        if (to_stage) b[i] = a[i]; else a[i] = b[i];
+    }
+}
+
+size_t stage_layout(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n)
+{
+    size_t total = 0;
+    for (size_t f = 0; f < n; f++) {
+        off[f] = total;
+        ctx->h_pack[2 * f] = total; ctx->h_pack[2 * f + 1] = len[f];
+        total += (len[f] + 15) & ~(size_t) 15;
+    }
+    if (total > ctx->stage_cap) {                                    // grow (rare: sized by the largest batch seen)
+        if (ctx->h_stage) EBCC_HIP_CHECK(hipHostFree(ctx->h_stage));
+        if (ctx->d_stage) EBCC_HIP_CHECK(hipFree(ctx->d_stage));
+        ctx->stage_cap = total + total / 2 + 4096;
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_stage, ctx->stage_cap));
+        EBCC_HIP_CHECK(hipMalloc((void **) &ctx->d_stage, ctx->stage_cap));
+    }
+    return total;
+}
+
+}  // namespace
+
+void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s)
+{
+    const size_t total = stage_layout(ctx, len, off, n);
+    if (!total) return;
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_pack, ctx->h_pack, 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_stage, dim3((unsigned) n, 4), dim3(256), 0, s, const_cast<uint8_t *>(src), stride, ctx->d_pack, ctx->d_stage, 1);
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_stage, ctx->d_stage, total, hipMemcpyDeviceToHost, s));
+    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n) { stage_layout(ctx, len, off, n); }
+
+void stage_upload(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, const size_t *len, const size_t *off, size_t n, hipStream_t s)
+{
+    size_t total = 0;
+    for (size_t f = 0; f < n; f++) if (len[f]) total = std::max(total, off[f] + ((len[f] + 15) & ~(size_t) 15));
+    if (!total) return;
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_pack, ctx->h_pack, 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, total, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_stage, dim3((unsigned) n, 4), dim3(256), 0, s, dst, stride, ctx->d_pack, ctx->d_stage, 0);
+}
 
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n)
 {
@@ -186,12 +246,14 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     ok &= (ctx->d_u64b = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
+    ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 2 * max_frames)) != nullptr;
     if (ok) {
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64a, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64b, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64c, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_active, max_frames * sizeof(int)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 2 * max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
     }
@@ -219,6 +281,9 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_u64c) hipHostFree(ctx->h_u64c);
     if (ctx->h_active) hipHostFree(ctx->h_active);
     if (ctx->h_fs) hipHostFree(ctx->h_fs);
+    if (ctx->h_pack) hipHostFree(ctx->h_pack);
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

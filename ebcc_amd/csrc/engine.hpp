@@ -29,6 +29,11 @@ struct ebcc_hip_ctx {
     // Sub-batch engines of the frames API: a batch is cut into a few slices that run concurrently, each on its
     // own stream and host thread (the kernels of one slice are latency-bound and leave most of the chip idle).
     std::vector<ebcc_hip_ctx *> lanes;
+    // Staging for the many small per-frame transfers (codestreams, SPIHT bytes): the pieces are packed by a kernel
+    // into one device buffer and cross PCIe as one copy into / out of one pinned buffer (engine.hip: stage_*).
+    uint8_t *h_stage = nullptr, *d_stage = nullptr;
+    size_t stage_cap = 0;
+    unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 * max_frames]: offset, length of every frame's piece
 };
 
 namespace ebcc {
@@ -38,6 +43,14 @@ void set_error(const char *fmt, ...);
 ebcc_hip_ctx *create_engine(int device, size_t max_frames, size_t height, size_t width, int tile_period);
 template <typename T>
 T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count);
+
+// Device -> host: the first len[f] bytes of the slot src + f * stride of every frame with len[f] > 0, as ONE copy.
+// Fills off[f] (offsets into ctx->h_stage, 16-byte aligned) and returns after the data has arrived.
+void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s);
+// Host -> device: space for pieces of len[f] bytes in ctx->h_stage (off[f] filled in); after the caller has written
+// them, stage_upload sends them as one copy and scatters them to the slots dst + f * stride (asynchronous on s).
+void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n);
+void stage_upload(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, const size_t *len, const size_t *off, size_t n, hipStream_t s);
 
 // synchronous copy of the frame states to ctx->h_fs
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n_frames);

@@ -365,13 +365,12 @@ struct Batch {
         launch_j2k_write(jb, (int) nt, d_active, s);
         fetch_jf();
         if (tiles == 1) {
+            // all codestreams of the batch in one packed download (engine.hip: stage_download)
+            std::vector<size_t> len(n, 0), off(n, 0);
+            for (size_t f = 0; f < n; f++) if (active[f]) len[f] = (size_t) jf[f].stream_bytes;
+            stage_download(ctx, jb.stream, jb.stream_cap, len.data(), off.data(), n, s);
             for (size_t f = 0; f < n; f++)
-                if (active[f]) {
-                    jobs[f].tail.resize((size_t) jf[f].stream_bytes);
-                    EBCC_HIP_CHECK(hipMemcpyAsync(jobs[f].tail.data(), jb.stream + f * jb.stream_cap, jobs[f].tail.size(),
-                                                  hipMemcpyDeviceToHost, s));
-                }
-            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+                if (active[f]) jobs[f].tail.assign(ctx->h_stage + off[f], ctx->h_stage + off[f] + len[f]);
             return;
         }
         // every tile was written as a one-tile codestream into its slot: [main header 135][SOT 12][SOD 2][packets][EOC 2]
@@ -685,17 +684,16 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         //      longest host step, so the frames are compressed by a small thread pool while the GPU runs
         //      the fallback search; the results are only needed for the size comparison at :838
         if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-        std::vector<std::vector<uint8_t>> coeff_bytes(n);
+        // the kept SPIHT prefixes of the batch in one packed download; the workers read them where they land (the staging
+        // buffer of the residual engine is not touched again before they are done)
+        std::vector<size_t> coeff_len(n, 0), coeff_off(n, 0);
         for (size_t f = 0; f < n; f++) {
             Job &j = jobs[f];
             if (j.coeffs_size <= 16) j.coeffs_size = 0;
-            if (j.coeffs_size > 0) {
-                coeff_bytes[f].resize(j.coeffs_size);
-                EBCC_HIP_CHECK(hipMemcpyAsync(coeff_bytes[f].data(), rc->rb.stream + f * rc->rb.stream_words, j.coeffs_size,
-                                              hipMemcpyDeviceToHost, rs));
-            }
+            coeff_len[f] = j.coeffs_size;
         }
-        EBCC_HIP_CHECK(hipStreamSynchronize(rs));
+        stage_download(rc, (const uint8_t *) rc->rb.stream, rc->rb.stream_words * sizeof(uint32_t), coeff_len.data(), coeff_off.data(), n, rs);
+        const uint8_t *const coeff_base = rc->h_stage;
         // one job per frame on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so
         // the host is never oversubscribed however many slices run
         std::atomic<size_t> next_frame{0};
@@ -706,7 +704,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 Job &j = jobs[f];
                 if (j.coeffs_size == 0) continue;
                 j.zbytes.resize(zstd().bound(j.coeffs_size));
-                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_bytes[f].data(), j.coeffs_size, env.zstd_level);
+                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
                 j.zbytes.resize(z);
             }
         };

@@ -95,16 +95,20 @@ void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const 
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
 }
 
-void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n) { stage_layout(ctx, len, off, n); }
+void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m) { stage_layout(ctx, len, off, m); }
 
-void stage_upload(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, const size_t *len, const size_t *off, size_t n, hipStream_t s)
+void stage_send(ebcc_hip_ctx *ctx, size_t m, hipStream_t s)
 {
     size_t total = 0;
-    for (size_t f = 0; f < n; f++) if (len[f]) total = std::max(total, off[f] + ((len[f] + 15) & ~(size_t) 15));
-    if (!total) return;
-    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_pack, ctx->h_pack, 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, total, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_stage, dim3((unsigned) n, 4), dim3(256), 0, s, dst, stride, ctx->d_pack, ctx->d_stage, 0);
+    for (size_t k = 0; k < m; k++) total = std::max<size_t>(total, ctx->h_pack[2 * k] + ((ctx->h_pack[2 * k + 1] + 15) & ~15ull));
+    EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_pack, ctx->h_pack, 2 * m * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    if (total) EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_stage, ctx->h_stage, total, hipMemcpyHostToDevice, s));
+}
+
+void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first, size_t count, hipStream_t s)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_stage, dim3((unsigned) count, 4), dim3(256), 0, s, dst, stride, ctx->d_pack + 2 * first, ctx->d_stage, 0);
 }
 
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n)
@@ -246,14 +250,14 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     ok &= (ctx->d_u64b = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
-    ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 2 * max_frames)) != nullptr;
+    ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 4 * max_frames)) != nullptr;
     if (ok) {
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64a, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64b, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64c, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_active, max_frames * sizeof(int)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
-        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 2 * max_frames * sizeof(unsigned long long)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 4 * max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
     }

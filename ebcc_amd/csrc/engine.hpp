@@ -33,7 +33,7 @@ struct ebcc_hip_ctx {
     // into one device buffer and cross PCIe as one copy into / out of one pinned buffer (engine.hip: stage_*).
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
-    unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 * max_frames]: offset, length of every frame's piece
+    unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 pieces per frame][offset, length]
 };
 
 namespace ebcc {
@@ -47,10 +47,12 @@ T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count);
 // Device -> host: the first len[f] bytes of the slot src + f * stride of every frame with len[f] > 0, as ONE copy.
 // Fills off[f] (offsets into ctx->h_stage, 16-byte aligned) and returns after the data has arrived.
 void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s);
-// Host -> device: space for pieces of len[f] bytes in ctx->h_stage (off[f] filled in); after the caller has written
-// them, stage_upload sends them as one copy and scatters them to the slots dst + f * stride (asynchronous on s).
-void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n);
-void stage_upload(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, const size_t *len, const size_t *off, size_t n, hipStream_t s);
+// Host -> device: stage_reserve makes room for m <= 2 * max_frames pieces of len[k] bytes in ctx->h_stage (off[k] filled
+// in); after the caller has written them stage_send ships them as one copy (asynchronous on s), and stage_scatter
+// moves pieces first .. first + count - 1 to the slots dst, dst + stride, ... (on any stream ordered after the send).
+void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m);
+void stage_send(ebcc_hip_ctx *ctx, size_t m, hipStream_t s);
+void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first, size_t count, hipStream_t s);
 
 // synchronous copy of the frame states to ctx->h_fs
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n_frames);

@@ -847,7 +847,9 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     const size_t n_pix = ctx->n_pix;
     const J2kGeom &g = jb.geom;
     std::vector<int> table(n * (size_t) g.stride * 4, 0);
-    std::vector<std::vector<uint8_t>> coeffs(n);
+    // pieces to upload: codestream k = f, SPIHT bytes k = n + f - staged in pinned memory and sent as one copy
+    std::vector<size_t> piece(2 * n, 0), piece_off(2 * n, 0);
+    std::vector<ParsedFrame> heads(n);
     PhaseTimer pt;
     fetch_frame_states(ctx, n);
     bool any_resid = false;
@@ -855,7 +857,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         const uint8_t *d = streams[f];
         const size_t len = sizes[f];
         ctx->h_active[f] = 0;
-        ParsedFrame hd;
+        ParsedFrame &hd = heads[f];
         if (!parse_frame(d, len, hd)) return 1;
         FrameState &fs = ctx->h_fs[f];
         fs.minv = hd.minv; fs.maxv = hd.maxv;
@@ -869,17 +871,25 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         } else {
             if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return 1; }
             if (!j2k_parse_codestream(tail, hd.tail_size, g, table.data() + f * g.stride * 4)) return 1;
-            EBCC_HIP_CHECK(hipMemcpyAsync(jb.stream + f * jb.stream_cap, tail, hd.tail_size, hipMemcpyHostToDevice, s));
+            piece[f] = hd.tail_size;
             if (hd.compressed_size > 0 && hd.coeffs_size > 0) {                                                    // :1294-1304
                 if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
                 if (hd.coeffs_size > ctx->rb.stream_words * 4 - 64) { log_fatal("residual stream larger than the device slot"); return 1; }
-                coeffs[f].assign(hd.coeffs_size, 0);
-                zstd().decompress(coeffs[f].data(), hd.coeffs_size, z, hd.compressed_size);
+                piece[n + f] = hd.coeffs_size;
                 ctx->h_active[f] = 1;
                 any_resid = true;
             }
         }
+        (void) z;
     }
+    stage_reserve(ctx, piece.data(), piece_off.data(), 2 * n);
+    for (size_t f = 0; f < n; f++) {
+        const ParsedFrame &hd = heads[f];
+        if (piece[f]) memcpy(ctx->h_stage + piece_off[f], hd.tail, hd.tail_size);
+        if (piece[n + f]) zstd().decompress(ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.z, hd.compressed_size);
+    }
+    stage_send(ctx, 2 * n, s);
+    stage_scatter(ctx, jb.stream, jb.stream_cap, 0, n, s);
     pt.mark("decode: parse, zstd, uploads");
     push_frame_states(ctx, n);
     // The residual layer (SPIHT decode + synthesis: one wave per frame, latency-bound) does not depend on the
@@ -891,7 +901,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
             EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
             EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
         }
-        EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));                       // frame states are on the device
+        EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));                       // frame states and the staged pieces are on the device
         EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -900,12 +910,10 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     if (any_resid) {
         const size_t slot = ctx->rb.stream_words * 4;
         for (size_t f = 0; f < n; f++) {
-            ctx->h_u64a[f] = coeffs[f].size();
-            ctx->h_u64b[f] = coeffs[f].size() * 8;
-            if (ctx->h_active[f])
-                EBCC_HIP_CHECK(hipMemcpyAsync((uint8_t *) ctx->rb.stream + f * slot, coeffs[f].data(), coeffs[f].size(),
-                                              hipMemcpyHostToDevice, s2));
+            ctx->h_u64a[f] = piece[n + f];
+            ctx->h_u64b[f] = piece[n + f] * 8;
         }
+        stage_scatter(ctx, (uint8_t *) ctx->rb.stream, slot, n, n, s2);
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64a, ctx->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s2));
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_u64b, ctx->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s2));
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, n * sizeof(int), hipMemcpyHostToDevice, s2));

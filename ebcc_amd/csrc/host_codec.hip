@@ -1185,7 +1185,9 @@ int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, const float *h_f
             EBCC_HIP_CHECK(hipMemcpyAsync(const_cast<float *>(d_frames) + lo * n_pix, h_frames + lo * n_pix, cnt * n_pix * sizeof(float),
                                           hipMemcpyHostToDevice, c->stream));
         return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next);
-    }, "EBCC_HIP_SLICES", default_encode_slices());
+    }, "EBCC_HIP_SLICES", h_frames ? std::min<size_t>(2, default_encode_slices()) : default_encode_slices());
+    // (uploads from pageable memory hold up the other slices' launches while they run: with them in the slices two are
+    //  as fast as one and four are slower - tools/gpu/host_api_rate.py: 4.8 / 4.9 / 3.7 GB/s for 2 / 1 / 4 slices)
 }
 
 // the decode counterpart; h_out (optional): every slice downloads its frames when they are done

@@ -1079,9 +1079,8 @@ struct ChunkBox {
     }
 };
 
-int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, const float *h_frames, size_t n_frames, const codec_config_t *cfg,
-                      uint8_t **outs, size_t *sizes);
-int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out, float *h_out);
+int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes);
+int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out);
 
 // host-pointer convenience used by the reference-compatible entry points
 // n chunks of `tiles` frames of H x W each, contiguous in host memory
@@ -1099,13 +1098,11 @@ size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec
     while (done < n) {
         size_t k = std::min(cap, n - done);
         int rcode;
-        if (tiles == 1) {
-            // one-frame chunks: the batch runs as concurrent slices, each uploading its own frames on its own stream
-            rcode = run_encode_slices(ctx, d, data + done * n_pix, k, cfg, outs + done, sizes + done);
-        } else {
-            EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
-            rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
-        }
+        // (the whole batch in one copy: uploads issued from inside the slices slowed every slice down -
+        //  tools/gpu/host_api_rate.py: 5.6 GB/s encode this way, 3.7 with four uploading slices)
+        EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
+        if (tiles == 1) rcode = run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done);   // one-frame chunks: concurrent slices
+        else rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
         if (rcode == 2) { hipFree(d); exit(1); }                                               // check_nan_inf, :598-605
         if (rcode) { hipFree(d); return 0; }
         done += k;
@@ -1173,33 +1170,23 @@ static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env
 
 namespace {
 
-// n_frames one-frame chunks as concurrent slices.  h_frames (optional): the frames in host memory - every slice then
-// uploads its own part into d_frames on its own stream first, so the uploads of later slices run beside the kernels of
-// earlier ones.
-int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, const float *h_frames, size_t n_frames, const codec_config_t *cfg,
-                      uint8_t **outs, size_t *sizes)
+// n_frames one-frame chunks as concurrent slices
+int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
 {
     const size_t n_pix = ctx->n_pix;
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
-        if (h_frames)
-            EBCC_HIP_CHECK(hipMemcpyAsync(const_cast<float *>(d_frames) + lo * n_pix, h_frames + lo * n_pix, cnt * n_pix * sizeof(float),
-                                          hipMemcpyHostToDevice, c->stream));
         return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next);
-    }, "EBCC_HIP_SLICES", h_frames ? std::min<size_t>(2, default_encode_slices()) : default_encode_slices());
-    // (uploads from pageable memory hold up the other slices' launches while they run: with them in the slices two are
-    //  as fast as one and four are slower - tools/gpu/host_api_rate.py: 4.8 / 4.9 / 3.7 GB/s for 2 / 1 / 4 slices)
+    }, "EBCC_HIP_SLICES", default_encode_slices());
 }
 
-// the decode counterpart; h_out (optional): every slice downloads its frames when they are done
-int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out, float *h_out)
+// the decode counterpart (decode overlaps its two layers on the engine's two streams, decode_batch; a second slice hides
+// the host side - parsing, zstd, uploads - of one half behind the kernels of the other when there are hardware queues
+// for four streams)
+int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out)
 {
     const size_t n_pix = ctx->n_pix;
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
-        const int r = decode_batch(c, streams + lo, sizes + lo, cnt, d_out + lo * n_pix, next);
-        if (r || !h_out) return r;
-        EBCC_HIP_CHECK(hipMemcpyAsync(h_out + lo * n_pix, d_out + lo * n_pix, cnt * n_pix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        EBCC_HIP_CHECK(hipStreamSynchronize(c->stream));
-        return 0;
+        return decode_batch(c, streams + lo, sizes + lo, cnt, d_out + lo * n_pix, next);
     }, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);
 }
 
@@ -1257,7 +1244,7 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     log_set_level_from_env();
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }   // on error: free the non-null ones
-    return run_encode_slices(ctx, d_frames, nullptr, n_frames, config, out_streams, out_sizes);
+    return run_encode_slices(ctx, d_frames, n_frames, config, out_streams, out_sizes);
 }
 
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
@@ -1267,9 +1254,7 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     std::lock_guard<std::mutex> lock(g_mutex);
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-    // (decode overlaps its two layers on the engine's two streams, decode_batch; a second slice hides the host side -
-    //  parsing, zstd, uploads - of one half behind the kernels of the other when there are hardware queues for four streams)
-    return run_decode_slices(ctx, streams, sizes, n_frames, d_frames_out, nullptr);
+    return run_decode_slices(ctx, streams, sizes, n_frames, d_frames_out);
 }
 
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
@@ -1493,7 +1478,11 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
             } else {
                 EBCC_HIP_CHECK(hipSetDevice(ctx->device));
                 if (!zstd().ok) { log_fatal("libzstd not available"); rcode = 1; }
-                else rcode = run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d, h_chunks + done * csize);
+                else {
+                    rcode = run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d);      // (one download below: copies issued
+                                                                                                    //  from inside the slices slowed them down)
+                    if (!rcode) EBCC_HIP_CHECK(hipMemcpy(h_chunks + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
+                }
             }
             if (rcode) { hipFree(d); free(o); return 0; }
             done += k;

@@ -258,6 +258,7 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_active, max_frames * sizeof(int)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 4 * max_frames * sizeof(unsigned long long)));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_act, 2 * max_frames * sizeof(int)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
     }
@@ -286,6 +287,9 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_active) hipHostFree(ctx->h_active);
     if (ctx->h_fs) hipHostFree(ctx->h_fs);
     if (ctx->h_pack) hipHostFree(ctx->h_pack);
+    if (ctx->h_act) hipHostFree(ctx->h_act);
+    if (ctx->h_jf) hipHostFree(ctx->h_jf);
+    if (ctx->h_table) hipHostFree(ctx->h_table);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);

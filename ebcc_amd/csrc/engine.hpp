@@ -22,6 +22,11 @@ struct ebcc_hip_ctx {
     unsigned long long *h_u64a = nullptr, *h_u64b = nullptr, *h_u64c = nullptr;
     int *h_active = nullptr;
     ebcc::FrameState *h_fs = nullptr;      // pinned
+    // pinned mirrors of the small per-round transfers of the rate searches and of the decode tables: copies from / to
+    // pageable memory are synchronous inside the runtime and hold up the launches of the other slices
+    void *h_jf = nullptr;                  // [max_frames] J2kFrame (j2k.hpp)
+    int *h_act = nullptr;                  // [2 * max_frames]: probe mask, residual mask
+    int *h_table = nullptr;                // [max_frames * code-block slots * 4] decode tables (lazily sized by j2k_create)
     std::vector<void *> allocs;
     void *j2k = nullptr;                   // base-layer state (j2k.hpp)
     hipStream_t stream2 = nullptr;          // second stream of the engine (decode: residual layer beside the base layer)

@@ -305,21 +305,24 @@ struct Batch {
     const float *d_frames;
     size_t n, tiles, nt;           // chunks, tiles per chunk, n * tiles
     std::vector<J2kFrame> jf;      // per chunk
-    std::vector<J2kFrame> tjf;     // per tile (device image)
+    J2kFrame *tjf;                 // per tile (device image; pinned: ctx->h_jf)
     std::vector<int> active;       // per chunk
-    std::vector<int> tactive;
+    int *tactive, *ractive;        // pinned: ctx->h_act
     std::vector<float> state_cr;   // rate of the decode the engine holds for every chunk (-1: none)
     int *d_active;                 // per tile, on ctx
     hipStream_t s;
     ebcc_hip_ctx *rc;              // residual engine (chunk-sized frames)
     hipStream_t rs;
     Batch(ebcc_hip_ctx *c, const float *d, size_t n_, size_t tiles_ = 1, ebcc_hip_ctx *rc_ = nullptr)
-        : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), tiles(tiles_), nt(n_ * tiles_), jf(n_), tjf(n_ * tiles_),
-          active(n_, 0), tactive(n_ * tiles_, 0), state_cr(n_, -1.f), d_active(c->d_active), s(c->stream), rc(rc_ ? rc_ : c),
-          rs((rc_ ? rc_ : c)->stream) {}
+        : ctx(c), jb(*static_cast<J2kBuffers *>(c->j2k)), d_frames(d), n(n_), tiles(tiles_), nt(n_ * tiles_), jf(n_),
+          tjf(static_cast<J2kFrame *>(c->h_jf)), active(n_, 0), tactive(c->h_act), ractive(c->h_act + c->max_frames), state_cr(n_, -1.f),
+          d_active(c->d_active), s(c->stream), rc(rc_ ? rc_ : c), rs((rc_ ? rc_ : c)->stream)
+    {
+        memset(tjf, 0, sizeof(J2kFrame) * nt);
+    }
     void fetch_jf()
     {
-        EBCC_HIP_CHECK(hipMemcpyAsync(tjf.data(), jb.jf, sizeof(J2kFrame) * nt, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(tjf, jb.jf, sizeof(J2kFrame) * nt, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
         for (size_t c = 0; c < n; c++) {
             J2kFrame &o = jf[c];
@@ -337,16 +340,20 @@ struct Batch {
                 tjf[t].cr = jf[c].cr; tjf[t].target = jf[c].target;
                 tjf[t].hdr_share = tiles > 1 ? (float) kJ2kMainHeaderBytes / (float) tiles : 0.0f;
             }
-        EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, tjf.data(), sizeof(J2kFrame) * nt, hipMemcpyHostToDevice, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, tjf, sizeof(J2kFrame) * nt, hipMemcpyHostToDevice, s));
     }
     void push_active()
     {
         for (size_t c = 0; c < n; c++)
             for (size_t t = c * tiles; t < (c + 1) * tiles; t++) tactive[t] = active[c];
-        EBCC_HIP_CHECK(hipMemcpyAsync(d_active, tactive.data(), sizeof(int) * nt, hipMemcpyHostToDevice, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(d_active, tactive, sizeof(int) * nt, hipMemcpyHostToDevice, s));
     }
     // the chunk mask for the residual engine's kernels
-    void push_ractive() { EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_active, active.data(), sizeof(int) * n, hipMemcpyHostToDevice, rs)); }
+    void push_ractive()
+    {
+        for (size_t c = 0; c < n; c++) ractive[c] = active[c];
+        EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_active, ractive, sizeof(int) * n, hipMemcpyHostToDevice, rs));
+    }
     // one probe of the base layer for the active chunks: rate allocation at jf[c].cr (+ decode and statistics)
     // keep_field = false: only the statistics are wanted, jb.DEC stays what it was
     void launch_probe(bool decode, bool keep_field = true)
@@ -846,7 +853,9 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     hipStream_t s = ctx->stream;
     const size_t n_pix = ctx->n_pix;
     const J2kGeom &g = jb.geom;
-    std::vector<int> table(n * (size_t) g.stride * 4, 0);
+    int *const table = ctx->h_table;                                  // (pinned)
+    const size_t table_ints = n * (size_t) g.stride * 4;
+    memset(table, 0, table_ints * sizeof(int));
     // pieces to upload: codestream k = f, SPIHT bytes k = n + f - staged in pinned memory and sent as one copy
     std::vector<size_t> piece(2 * n, 0), piece_off(2 * n, 0);
     std::vector<ParsedFrame> heads(n);
@@ -870,7 +879,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
             if (cnt != n_pix) { log_fatal("const-field length %llu does not match the frame", (unsigned long long) cnt); return 1; }
         } else {
             if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return 1; }
-            if (!j2k_parse_codestream(tail, hd.tail_size, g, table.data() + f * g.stride * 4)) return 1;
+            if (!j2k_parse_codestream(tail, hd.tail_size, g, table + f * g.stride * 4)) return 1;
             piece[f] = hd.tail_size;
             if (hd.compressed_size > 0 && hd.coeffs_size > 0) {                                                    // :1294-1304
                 if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
@@ -904,7 +913,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));                       // frame states and the staged pieces are on the device
         EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
     }
-    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table, table_ints * sizeof(int), hipMemcpyHostToDevice, s));
     launch_j2k_decode(jb, (int) n, s);
     if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
     if (any_resid) {

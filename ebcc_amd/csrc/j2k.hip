@@ -87,6 +87,8 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_geom, jb->geoms.data(), sizeof(J2kGeom) * (size_t) period, hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blocks, blocks.data(), sizeof(J2kBlock) * blocks.size(), hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemcpyAsync(jb->d_blkmap, map.data(), map.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_jf, sizeof(J2kFrame) * F));
+    EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_table, sizeof(int) * 4 * total));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->rate_path_n, 0, sizeof(int) * F, s));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));

@@ -146,7 +146,7 @@ struct J2kBuffers {
 // smaller unions.  Defaults measured on MI355X (profiles/): decision pass 64 and MQ pass 64 (their lanes share one
 // instruction stream), probe restart 4, decode 4 (the per-sample decoder is branchy: fewer lanes, smaller unions); EBCC_T1_LPW="<n>" or "<a>,<b>,<c>,<d>" overrides them.
 enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
-int t1_lanes_per_wave(int kernel);
+int t1_lanes_per_wave(int kernel, int total_blocks = 0);   // (total_blocks: code-blocks in the launch, for the encoder kernels)
 
 J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks, int ty0 = 0);
 

@@ -28,7 +28,7 @@ static const double kNormsReal[4][10] = {
     {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0},
     {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2}};
 
-int t1_lanes_per_wave(int kernel)
+int t1_lanes_per_wave(int kernel, int total_blocks)
 {
     // EBCC_T1_LPW = "<n>" (all kernels) or "<decision pass>,<MQ pass>,<probe restart>,<decode>", each a power of two up to 64
     // (read at every launch: a tuning knob, results do not depend on it)
@@ -39,6 +39,16 @@ int t1_lanes_per_wave(int kernel)
             const int x = n == 1 ? v[0] : (i < n ? v[i] : 0);
             if (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32 || x == 64) t[i] = x;
         }
+        return t[kernel & 3];
+    }
+    // The encoder kernels step all lanes of a wave together, so a wave lasts as long as the sum over its steps of the
+    // slowest lane: with few code-blocks in the launch (a frame or two coded alone, e.g. from an HDF5 filter callback)
+    // there are SIMDs to spare and fewer lanes per wave finish sooner (one 721 x 1440 frame: 46.6 ms at 64 lanes,
+    // 36.3 ms at 4); large batches need the lanes (measured: 64 is best from 64 frames on).
+    if (kernel <= T1_MQ && total_blocks > 0 && total_blocks <= 8192) {
+        int lpw = 4;
+        while (lpw < 64 && total_blocks / lpw > 1024) lpw <<= 1;
+        return lpw;
     }
     return t[kernel & 3];
 }
@@ -965,13 +975,13 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
                            jb.d_blocks, fs, jb.jf, total, lpw);
     } else {                                                             // EBCC_T1_TWO_PHASE=1
         timing_begin("t1_symbols", s);
-        int lpw = t1_lanes_per_wave(T1_ENCODE);
+        int lpw = t1_lanes_per_wave(T1_ENCODE, total);
         hipLaunchKernelGGL(k_t1_symbols, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax,
                            jb.numbps, jb.totalpasses, jb.cblk_len, jb.SYM, jb.nsym, jb.VISP, jb.d_geom, jb.d_blocks, fs, jb.jf,
                            total, lpw);
         timing_end("t1_symbols", s);
         timing_begin("t1_mq", s);
-        lpw = t1_lanes_per_wave(T1_MQ);
+        lpw = t1_lanes_per_wave(T1_MQ, total);
         hipLaunchKernelGGL(k_t1_mq, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.SYM, jb.nsym, jb.numbps,
                            jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, lpw);
         timing_end("t1_mq", s);

@@ -1,0 +1,45 @@
+"""GPU box, under an interpreter with h5py (/opt/conda/bin/python3.9) and HDF5_PLUGIN_PATH=<repo>/ebcc_amd:
+HDF5 write / read rates of 721 x 1440 frames through (a) the filter callback, one chunk per call, and
+(b) the direct-chunk batch path (ebcc_amd/h5_batch.py).    python3.9 tools/gpu/h5_rate.py <dir> [frames]"""
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import h5py  # noqa: E402
+import numpy as np  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from ebcc_amd import EBCC_Filter, h5_batch  # noqa: E402
+
+out, N = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 64
+H, W = 721, 1440
+rng = np.random.default_rng(11)
+y, x = np.mgrid[0:H, 0:W]
+base = (275 + 12 * np.sin(x / 90.0) * np.cos(y / 70.0)).astype(np.float32)
+data = np.stack([base + rng.normal(0, 0.8, (H, W)).astype(np.float32).cumsum(axis=1) / 20 + 0.3 * k for k in range(N)]).astype(np.float32)
+opt = ("max_error_target", 0.5)
+gb = data.nbytes / 1e9
+
+ncb = min(N, 16)
+t0 = time.perf_counter()
+with h5py.File(os.path.join(out, "cb.h5"), "w") as f:
+    f.create_dataset("t", data=data[:ncb], **EBCC_Filter(base_cr=30, height=H, width=W, residual_opt=opt, data_dim=3))
+t1 = time.perf_counter()
+with h5py.File(os.path.join(out, "cb.h5"), "r") as f:
+    back = f["t"][...]
+t2 = time.perf_counter()
+print(f"filter callback ({ncb} frames): write {data[:ncb].nbytes / 1e9 / (t1 - t0):.3f} GB/s, read {data[:ncb].nbytes / 1e9 / (t2 - t1):.3f} GB/s, "
+      f"max error {float(np.abs(back - data[:ncb]).max()):.4f}", flush=True)
+
+for rep in range(2):
+    t0 = time.perf_counter()
+    with h5py.File(os.path.join(out, "dc.h5"), "w") as f:
+        d = h5_batch.create_dataset(f, "t", data.shape, base_cr=30, residual_opt=opt)
+        h5_batch.write_frames(d, data, 30, opt)
+    t1 = time.perf_counter()
+    with h5py.File(os.path.join(out, "dc.h5"), "r") as f:
+        back = h5_batch.read_frames(f["t"])
+    t2 = time.perf_counter()
+    print(f"direct-chunk batch ({N} frames), rep {rep}: write {gb / (t1 - t0):.3f} GB/s, read {gb / (t2 - t1):.3f} GB/s, "
+          f"max error {float(np.abs(back - data).max()):.4f}, file {os.path.getsize(os.path.join(out, 'dc.h5')) / 1e6:.1f} MB", flush=True)

@@ -221,6 +221,41 @@ def test_sliced_batches_equal_single_engine(monkeypatch):
         assert np.array_equal(res[k][1], res["1"][1]), k
 
 
+def test_tuning_knobs_do_not_change_results(monkeypatch):
+    """ebcc_hip_prepare (slice engines made ahead of time), EBCC_HOST_THREADS (entropy-stage threads) and
+    EBCC_T1_LPW leave streams and fields as they are; EBCC_ZSTD_LEVEL changes the bytes of the zstd payload only -
+    the decoded field stays the same and the reference's decoder (the oracle here) reads the stream."""
+    frames = np.stack([L.era5_like(96, 160, 500 + s, 1.2, 0.8) for s in range(17)])
+    cfg = L.make_config((1, 96, 160), base_cr=25.0, error=0.02, residual_type=L.MAX_ERROR)
+    monkeypatch.setenv("EBCC_INIT_BASE_ERROR_QUANTILE", "0.1")                 # a looser base layer and no fallback:
+    monkeypatch.setenv("EBCC_DISABLE_PURE_BASE_COMPRESSION_FALLBACK", "1")     # the residual layer stays, zstd has work
+    lib = L.product()
+    lib.ebcc_hip_prepare.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    with L.Context(len(frames), 96, 160) as ctx:
+        base = ctx.encode_frames(frames, cfg)
+        ref_dec = ctx.decode_frames(base)
+        assert any(int.from_bytes(s[16:24], "little") > 0 for s in base)      # some frames carry a residual layer
+    L.oracle().orc_set_j2k_backend(0)
+    assert base[0] == L.orc_encode(frames[0], cfg) and base[16] == L.orc_encode(frames[16], cfg)
+    for env in ({"EBCC_HOST_THREADS": "3"}, {"EBCC_T1_LPW": "8"}, {"EBCC_T1_LPW": "16,32,1,2"}, {"EBCC_HIP_SLICES": "3", "EBCC_HIP_DECODE_SLICES": "3"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with L.Context(len(frames), 96, 160) as ctx:
+            assert lib.ebcc_hip_prepare(ctypes.c_void_p(ctx.ptr), len(frames)) == 0
+            got = ctx.encode_frames(frames, cfg)
+            assert got == base, env
+            assert np.array_equal(ctx.decode_frames(got), ref_dec), env
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("EBCC_ZSTD_LEVEL", "3")
+    with L.Context(len(frames), 96, 160) as ctx:
+        fast = ctx.encode_frames(frames, cfg)
+        assert np.array_equal(ctx.decode_frames(fast), ref_dec)
+    assert fast != base                                                        # (other zstd bytes)
+    for f in (0, 7, 16):
+        assert np.array_equal(np.asarray(L.orc_decode(fast[f])).ravel(), ref_dec[f].ravel())
+
+
 @pytest.mark.parametrize("chunk", [(1, 96, 160), (1, 64, 96), (1, 96, 100)], ids=str)
 def test_chunking_entry_points_on_many_chunks(chunk):
     """ebcc_encode_chunking / ebcc_decode_chunking on an array of enough chunks for the sliced path (every slice

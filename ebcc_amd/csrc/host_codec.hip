@@ -525,6 +525,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     }
     fetch_frame_states(ctx, nt);
     b.fetch_jf();
+    if (j2k_tier1_retry(jb, (int) nt, b.tjf, s)) b.fetch_jf();        // (a group's decisions outgrew the segmented encoder's buffer)
     for (size_t f = 0; f < n; f++) {
         const FrameState &t0 = ctx->h_fs[f * tiles];                   // (all tiles of a chunk carry the chunk's statistics)
         if (t0.has_nonfinite) { log_fatal("NaN or Inf found in data of frame %zu", f); return 2; }

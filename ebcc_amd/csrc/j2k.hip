@@ -51,9 +51,12 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     jb->SYM = nullptr;
     {
         const char *e = getenv("EBCC_T1_TWO_PHASE");
-        if (!e || atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * 64 * (size_t) kJ2kSymCap + 256)) != nullptr;
+        jb->sym_rows = kJ2kSymRows;
+        if (const char *r = getenv("EBCC_HIP_SYM_ROWS")) jb->sym_rows = std::max(1, std::min(kJ2kSymRows, atoi(r)));
+        if (!e || atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * (size_t) jb->sym_rows * 1024 + 256)) != nullptr;
     }
-    ok &= (jb->nsym = ctx_alloc<uint32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->seglen = ctx_alloc<uint16_t>(ctx, groups * (size_t) kJ2kSegCount * 64)) != nullptr;
+    ok &= (jb->lanerows = ctx_alloc<uint32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->qplane = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->lastnp = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->T1S = ctx_alloc<unsigned long long>(ctx, groups * kT1StateWords * 64)) != nullptr;
@@ -334,7 +337,11 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx
     std::vector<J2kFrame> jf(n_frames);
     EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
-    for (size_t f = 0; f < n_frames; f++) { jf[f].cr = cr[f]; jf[f].target = 0; jf[f].overflow = 0; }
+    if (j2k_tier1_retry(jb, n, jf.data(), s)) {
+        EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    for (size_t f = 0; f < n_frames; f++) { jf[f].cr = cr[f]; jf[f].target = 0; }
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n_frames, hipMemcpyHostToDevice, s));
     launch_j2k_rate(jb, n, nullptr, s);
     launch_j2k_write(jb, n, nullptr, s);

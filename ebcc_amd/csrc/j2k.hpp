@@ -67,22 +67,23 @@ __host__ __device__ inline const std::uint16_t *j2k_frame_blkmap(const J2kGeom *
     return map + (size_t) j2k_geom_index(g, frame) * ((size_t) g->W * (size_t) g->H);
 }
 
-constexpr int kJ2kSymCap = 4096 * (kJ2kMaxPlanes + 1) + 2048;  // decision stream of one code-block: at most planes + 1 decisions per sample, plus stripe markers
+constexpr int kJ2kSymCap = 4096 * (kJ2kMaxPlanes + 1) + 2048;  // decision bytes budgeted per code-block (64 of them share a group's rows)
+constexpr int kJ2kSegCount = kJ2kMaxPlanes * 3 * 16;           // segments of a code-block: (bit-plane, pass type, stripe), t1_core.hpp
+constexpr int kJ2kSymRows = (4096 * (kJ2kMaxPlanes + 2)) / 16 + kJ2kSegCount;   // 16-decision rows of a code-block's stream: decisions (a zero-coding / refinement decision per sample and plane, a sign, at most 3 run-length decisions per column and stripe) + one partial row per segment
 constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
 
-// Checkpoint storage: one 36-byte record (a, c, ct, pos, then the 19 context states one byte each in five words)
-// per slot, the slots of a code-block contiguous: [code-block][slot = pass * 16 + stripe][9 words].  Writers
-// (the MQ pass, one code-block per lane, every lane at its own slot) and readers (the restart planner's binary
-// search, the restart itself, the finalising sweep) all walk one code-block's records, so a record is one or two
-// memory transactions instead of nine scattered ones.
+// Checkpoint storage: nine words per slot (a, c, ct, pos, then the 19 context states one byte each in five words),
+// lane-interleaved inside a group of 64 code-blocks like every other per-code-block array of tier-1:
+// [group][slot = pass * 16 + stripe][word][lane].  The MQ pass stores the checkpoints of all 64 code-blocks of a
+// wave at the same (uniform) point of its loop, so every store instruction writes one contiguous 256-byte line.
 constexpr int kJ2kCkptFields = 9;
 __host__ __device__ inline size_t j2k_ckpt_block_bytes() { return (size_t) kJ2kCkptFields * kJ2kCkptPerBlock * 4; }
 struct J2kCkptView {
-    std::uint32_t *rec;            // first record of this code-block
-    __host__ __device__ std::uint32_t &at(int field, std::uint32_t slot) const { return rec[slot * kJ2kCkptFields + (std::uint32_t) field]; }
+    std::uint32_t *rec;            // word 0 of slot 0 of this code-block (its lane's column of the group)
+    __host__ __device__ std::uint32_t &at(int field, std::uint32_t slot) const { return rec[(slot * kJ2kCkptFields + (std::uint32_t) field) * 64u]; }
     __host__ __device__ static J2kCkptView of(void *all, size_t gid)
     {
-        return J2kCkptView{(std::uint32_t *) ((unsigned char *) all + gid * j2k_ckpt_block_bytes())};
+        return J2kCkptView{(std::uint32_t *) ((unsigned char *) all + (gid >> 6) * 64 * j2k_ckpt_block_bytes()) + (gid & 63)};
     }
 };
 
@@ -94,7 +95,7 @@ struct J2kFrame {                 // per-frame scalars (device)
     int stream_bytes;             // whole codestream
     unsigned long long nbad;      // count(|x - d| > target) of the last decode
     double err_sum;               // sum(x - d)
-    int overflow;                 // a code-block outgrew its byte slot
+    int overflow;                 // bit 0: a code-block outgrew its byte slot; bit 1: a group's decisions outgrew its rows of SYM (retry: launch_j2k_tier1)
     float hdr_share;              // this tile's share of the main header in the byte budget (opj_j2k_update_rates:
                                   // main header bytes / number of tiles); 0 = a single tile = all 135 bytes
 };
@@ -115,8 +116,10 @@ struct J2kBuffers {
     unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
     unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
     void *ckpt;                   // [frames*nblocks][passes * 16 stripes][9 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
-    uint8_t *SYM;                 // [frames*nblocks][kJ2kSymCap] decision streams of the two-phase encoder (t1_core.hpp)
-    std::uint32_t *nsym;          // [frames*nblocks] bytes in the stream
+    uint8_t *SYM;                 // [groups][sym_rows][64 lanes][16] decision rows of the segmented two-phase encoder (t1_core.hpp: row format); null: single-kernel encoder
+    int sym_rows;                 // 1-KB rows of SYM per group (kJ2kSymRows; EBCC_HIP_SYM_ROWS overrides, for tests of the retry)
+    std::uint16_t *seglen;        // [groups][kJ2kSegCount][64] decisions of every segment of every code-block, then its first row in the block's stream
+    std::uint32_t *lanerows;      // [frames*nblocks] rows in the block's stream
     int *qplane;                  // [frames*nblocks] where the current probe's decode restarts: pass | stripe << 8 (-1: nothing, -2: V is up to date)
     int *lastnp;                  // [frames*nblocks] passes the code-block had in the frame's previous probe decode (-1: none yet; reset by the analysis)
     unsigned long long *T1S;      // [groups][kT1StateWords][64] tier-1 state
@@ -156,6 +159,12 @@ void launch_input_stats(const float *data, int n_frames, size_t n_pix, FrameStat
 // scale to u16 (:686-689), DC level shift, forward 9/7, quantisation, tier-1 of every code-block,
 // distortion tables: everything of opj_encode that does not depend on the rate
 void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, hipStream_t s);
+// the tier-1 stage of the analysis again with the single-kernel encoder (after J2kFrame::overflow bit 1: the decisions of
+// a group of code-blocks outgrew their rows of the segmented encoder's buffer); also called by the analysis itself
+void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool single_kernel);
+// to be called with the per-frame scalars fetched after the analysis: runs that retry if any frame asks for it (the
+// caller then fetches them again)
+bool j2k_tier1_retry(const J2kBuffers &jb, int n_frames, const J2kFrame *host_jf, hipStream_t s);
 // rate allocation for jf[f].cr (opj_tcd_rateallocate) -> npass, jf.body_bytes/stream_bytes
 void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
 // write the codestream of the current layer assignment into jb.stream

@@ -687,163 +687,238 @@ __global__ __launch_bounds__(64) void k_t1_encode(unsigned long long *T1S, const
     t1::finalize_checkpoints(obs, r.totalpasses, (blk.h + 3) >> 2, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
 }
 
-// ---- phase 1: the coding passes, emitting decisions instead of coding them (t1::emit_block)
-struct SymPutDev {
-    unsigned char *base;           // this code-block's slot in SYM
-    int *overflow;
-    unsigned long long win = 0;
-    __device__ void operator()(uint32_t i, uint32_t sym)
-    {
-        win |= (unsigned long long) sym << (8 * (i & 7u));
-        if ((i & 7u) == 7u) {
-            if (i < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (i & ~7u)) = win; else *overflow = 1;
-            win = 0;
-        }
-    }
-    __device__ void put_if(bool on, uint32_t i, uint32_t sym)           // branch-free unless a word completes
-    {
-        win |= (unsigned long long) (on ? sym : 0u) << (8 * (i & 7u));
-        if (on && (i & 7u) == 7u) {
-            if (i < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (i & ~7u)) = win; else *overflow = 1;
-            win = 0;
-        }
-    }
-    __device__ void flush(uint32_t n)
-    {
-        if ((n & 7u) && n < (uint32_t) kJ2kSymCap) *(unsigned long long *) (base + (n & ~7u)) = win;
-    }
-};
-struct EmitObserver {
-    unsigned char *visp;           // group base of the per-plane visited masks
+// ================================================================================================
+// segmented two-phase encoder (t1_core.hpp): masks + counts, segment offsets, decisions, arithmetic coding
+// ================================================================================================
+// the encoder's row masks of one code-block (lane-interleaved inside its group)
+struct DevMasks {
+    const unsigned char *bp, *suf, *sg;    // group bases
+    unsigned char *visp;
     uint32_t lane8;
-    template <class Em>
-    __device__ void pass_start(int, const Em &) {}
-    template <class Store>
-    __device__ void sigprop_done(int bp, Store &st)
-    {
-        for (int y = 0; y < 64; y++) *(unsigned long long *) (visp + ((uint32_t) (bp * 64 + y) * 512u + lane8)) = st.VIS(y);
-    }
+    __device__ unsigned long long ld(const unsigned char *b, int row) const { return *(const unsigned long long *) (b + ((uint32_t) row * 512u + lane8)); }
+    __device__ unsigned long long BP(int p, int y) const { return ld(bp, p * 64 + y); }
+    __device__ unsigned long long SUF(int p, int y) const { return ld(suf, p * 64 + y); }
+    __device__ unsigned long long SGN(int y) const { return ld(sg, y); }
+    __device__ unsigned long long VISP(int p, int y) const { return ld(visp, p * 64 + y); }
 };
-
-__global__ __launch_bounds__(64) void k_t1_symbols(unsigned long long *T1S, const unsigned long long *BP,
-                                                    const unsigned long long *SGN, unsigned long long *SPS, const int *blkmax,
-                                                    int *numbps, int *totalpasses, int *cblk_len, uint8_t *SYM,
-                                                    uint32_t *nsym, unsigned long long *VISP, const J2kGeom *geom,
-                                                    const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, int lpw)
+struct Tier1Lane {                 // what every tier-1 kernel derives for its lane's code-block
+    int gid, frame, P, w, h, orient;
+    bool live;
+};
+__device__ inline Tier1Lane tier1_lane(int gid, int total, const int *blkmax, const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs)
 {
-    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
-    const int gid = gid0 + threadIdx.x;
-    if (gid >= total) return;
+    Tier1Lane l{gid, 0, 0, 0, 0, 0, false};
+    if (gid >= total) return l;
     const int nb = geom->stride;
-    const int frame = gid / nb, bi = gid - frame * nb;
-    if (fs[frame].const_field) return;
-    blocks = j2k_frame_blocks(geom, blocks, frame);
-    geom = &j2k_frame_geom(geom, frame);
-    const J2kBlock blk = blocks[bi];
-    const int orient = geom->bands[blk.band].orient;
+    l.frame = gid / nb;
+    if (fs[l.frame].const_field) return l;
+    const J2kBlock blk = j2k_frame_blocks(geom, blocks, l.frame)[gid - l.frame * nb];
     const int m = blkmax[gid];
-    int P = m ? (31 - __clz(m)) + 1 - 6 : 0;                         // opj_t1_encode_cblk: numbps
-    numbps[gid] = P;
-    if (P <= 0) { totalpasses[gid] = 0; cblk_len[gid] = 0; nsym[gid] = 0; return; }
-    const size_t grp = (size_t) (gid0 >> 6);
-    const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
-    DevStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64),
-                (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (SPS + grp * 64 * 64), lane8};
-    EmitObserver obs{(unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
-    t1::SymbolEmitter<SymPutDev> em{0, SymPutDev{SYM + (size_t) gid * kJ2kSymCap, &jf[frame].overflow}};
-    totalpasses[gid] = t1::emit_block(st, em, blk.w, blk.h, orient, P, obs);
-    em.put.flush(em.n);
-    nsym[gid] = em.n;
-#ifdef EBCC_T1_PROFILE
-    if (gid == 64 * 40) printf("k_t1_symbols lane profile: propagation %lld us, refinement %lld us, cleanup %lld us\n",
-                               t1::t1_profile[0] / 100, t1::t1_profile[1] / 100, t1::t1_profile[2] / 100);
-#endif
+    l.P = m ? (31 - __clz(m)) + 1 - 6 : 0;                             // opj_t1_encode_cblk: numbps
+    l.w = blk.w; l.h = blk.h;
+    l.orient = j2k_frame_geom(geom, l.frame).bands[blk.band].orient;
+    l.live = l.P > 0;
+    return l;
 }
 
-// ---- phase 2: arithmetic coding of the decision streams, one code-block per lane, every lane the same loop.
-// All lanes are at the same stream index, so the stream is staged through LDS 64 bytes per lane at a time:
-// one wave-wide refill every 64 symbols (with the next chunk's loads already in flight) instead of a global
-// load - and a wave-wide wait for it - whenever any single lane runs dry.
-struct SymSrcDev {
-    const unsigned char *base;     // this code-block's stream
-    uint32_t *ring;                // LDS, [16 words][64 lanes] of this wave
-    uint32_t lane;
-    uint4 n0, n1, n2, n3;          // the chunk after the one in LDS
-    __device__ void prefetch(uint32_t at)
-    {
-        const uint4 *p = (const uint4 *) (base + at);
-        n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3];
-    }
-    __device__ uint32_t get(uint32_t i)
-    {
-        if ((i & 63u) == 0u) {
-            uint32_t *r = ring + lane;
-            r[0 * 64] = n0.x; r[1 * 64] = n0.y; r[2 * 64] = n0.z; r[3 * 64] = n0.w;
-            r[4 * 64] = n1.x; r[5 * 64] = n1.y; r[6 * 64] = n1.z; r[7 * 64] = n1.w;
-            r[8 * 64] = n2.x; r[9 * 64] = n2.y; r[10 * 64] = n2.z; r[11 * 64] = n2.w;
-            r[12 * 64] = n3.x; r[13 * 64] = n3.y; r[14 * 64] = n3.z; r[15 * 64] = n3.w;
-            prefetch(i + 64u);
+// ---- masks and counts: one code-block per lane, planes from the top; mask arithmetic only
+struct ScanOutDev {
+    unsigned char *vp, *sp;        // group bases of VISP and SPS
+    std::uint16_t *lens;           // this lane's column of the group's segment lengths
+    uint32_t lane8;
+    __device__ void visp_row(unsigned char *b, int row, unsigned long long v) const { *(unsigned long long *) (b + ((uint32_t) row * 512u + lane8)) = v; }
+    __device__ void visp(int p, int y, unsigned long long m) const { visp_row(vp, p * 64 + y, m); }
+    __device__ void sps_or(int y, unsigned long long n) const { *(unsigned long long *) (sp + ((uint32_t) y * 512u + lane8)) |= n; }
+    __device__ void len(int seg, uint32_t n) const { lens[(uint32_t) seg * 64u] = (std::uint16_t) n; }
+};
+__global__ __launch_bounds__(64) void k_t1_scan(const unsigned long long *BP, const unsigned long long *SUF, const unsigned long long *SGN,
+                                                 unsigned long long *SPS, unsigned long long *VISP, const int *blkmax, int *numbps,
+                                                 int *totalpasses, int *cblk_len, std::uint16_t *seglen, const J2kGeom *geom,
+                                                 const J2kBlock *blocks, const FrameState *fs, int total)
+{
+    const size_t grp = blockIdx.x;
+    const int gid = (int) (grp * 64) + (int) threadIdx.x;
+    const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
+    if (gid < total) { numbps[gid] = l.P; totalpasses[gid] = l.live ? 3 * l.P - 2 : 0; cblk_len[gid] = 0; }
+    if (!l.live) return;
+    const uint32_t lane8 = threadIdx.x * 8u;
+    DevMasks M{(const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64), (const unsigned char *) (SUF + grp * (kJ2kMaxPlanes + 2) * 64 * 64),
+               (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
+    ScanOutDev out{M.visp, (unsigned char *) (SPS + grp * 64 * 64), seglen + grp * kJ2kSegCount * 64 + threadIdx.x, lane8};
+    t1::scan_block(M, out, l.P, l.w, l.h, l.orient);
+}
+
+// ---- row offsets: every segment of a code-block takes seg_rows(decisions) 16-byte rows of the block's stream, in coding
+// order; the counts k_t1_scan left become the segments' first rows (in place), the total goes to lanerows
+__global__ __launch_bounds__(64) void k_t1_rowoffs(std::uint16_t *seglen, uint32_t *lanerows, const int *blkmax, J2kFrame *jf,
+                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total,
+                                                    uint32_t sym_rows)
+{
+    const size_t grp = blockIdx.x;
+    const int gid = (int) (grp * 64) + (int) threadIdx.x;
+    const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
+    std::uint16_t *L = seglen + grp * kJ2kSegCount * 64 + threadIdx.x;
+    uint32_t off = 0;
+    if (l.live) {
+        const int nstr = (l.h + 3) >> 2;
+        for (int seg = t1::seg_index(l.P - 1, 2, 0); seg < kJ2kSegCount; seg++) {
+            if (!t1::seg_valid(l.P, nstr, t1::seg_plane(seg), t1::seg_type(seg), seg & 15)) continue;
+            const uint32_t n = L[(uint32_t) seg * 64u];
+            L[(uint32_t) seg * 64u] = (std::uint16_t) off;
+            off += t1::seg_rows(n);
         }
-        return ((const unsigned char *) (ring + ((i & 63u) >> 2) * 64u + lane))[i & 3u];
+    }
+    if (gid < total) lanerows[gid] = off;
+    if (off > sym_rows) atomicOr(&jf[l.frame].overflow, 2);             // (cannot happen for sym_rows = kJ2kSymRows: the host would re-run tier-1 with the single-kernel encoder)
+}
+
+// ---- decisions: one wave per (group of 64 code-blocks, bit-plane), a code-block per lane; the decisions of a segment
+// go through a per-lane byte ring in LDS and leave as the 16-byte rows of the block's stream: row r of lane l of a
+// group at ((r * 64) + l) * 16, so that the MQ pass reads one contiguous KB per step
+struct SegEmDev {
+    unsigned char *ring;           // LDS: this lane's 64 bytes (lane stride 68 bytes = 17 banks: lanes at the same offset never conflict)
+    uint8_t *sym;                  // the group's rows + lane * 16
+    const std::uint16_t *rowoff;   // this lane's column of the segments' first rows
+    uint32_t cap;                  // rows the lane may write
+    uint32_t cnt = 0, fl = 0;      // decisions of the segment so far, rows written
+    uint32_t row0 = 0;
+    __device__ void begin(int seg) { cnt = 0; fl = 0; row0 = rowoff[(uint32_t) seg * 64u]; }
+    __device__ void emit_if(bool on, uint32_t ctx, uint32_t d)
+    {
+        ring[cnt & 63u] = (unsigned char) (ctx | (d << 5));             // (overwritten by the next decision unless `on`)
+        cnt += on ? 1u : 0u;
+    }
+    __device__ void piece(uint32_t keep)                                 // keep: decisions in this row (the rest is padding)
+    {
+        const uint32_t *q = (const uint32_t *) (ring + ((fl & 3u) << 4));
+        uint32_t w[4] = {q[0], q[1], q[2], q[3]};
+        if (keep < 16u) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int nv = min(max((int) keep - 4 * d, 0), 4);
+                const uint32_t m = nv ? 0xFFFFFFFFu >> (32 - 8 * nv) : 0u;
+                w[d] = (w[d] & m) | (0x80808080u & ~m);
+            }
+        }
+        if (fl == 0) w[0] |= t1::kRowStart;
+        if (row0 + fl < cap) *(uint4 *) (sym + (size_t) (row0 + fl) * 1024) = make_uint4(w[0], w[1], w[2], w[3]);
+        fl++;
+    }
+    __device__ void column_end() { if ((cnt >> 4) != fl) piece(16u); }  // (a column adds at most 11 decisions)
+    __device__ void end()
+    {
+        if ((cnt >> 4) != fl) piece(16u);
+        if ((cnt & 15u) || cnt == 0) piece(cnt & 15u);
     }
 };
 
-struct CtxLds {
-    // the 19 context states of every lane, one byte each: word j of lane l at (j * 64 + l) * 4 (bank = lane)
-    unsigned char *base;           // LDS, already offset by lane * 4
-    __device__ uint32_t ld(int c) const { return base[(uint32_t) (c >> 2) * 256u + (uint32_t) (c & 3)]; }
-    __device__ void st(int c, uint32_t v) { base[(uint32_t) (c >> 2) * 256u + (uint32_t) (c & 3)] = (unsigned char) v; }
-    __device__ void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = *(const uint32_t *) (base + j * 256); }
+__global__ __launch_bounds__(64) void k_t1_emit(const unsigned long long *BP, const unsigned long long *SUF, const unsigned long long *SGN,
+                                                 unsigned long long *VISP, const int *blkmax, uint8_t *SYM, const std::uint16_t *seglen,
+                                                 const uint32_t *lanerows, const J2kGeom *geom, const J2kBlock *blocks,
+                                                 const FrameState *fs, int total, uint32_t sym_rows)
+{
+    __shared__ uint32_t ring[17 * 64];
+    const size_t grp = blockIdx.x;
+    const int p = (int) blockIdx.y;
+    const int gid = (int) (grp * 64) + (int) threadIdx.x;
+    const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
+    if (!l.live || p >= l.P || lanerows[gid] > sym_rows) return;
+    const uint32_t lane8 = threadIdx.x * 8u;
+    DevMasks M{(const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64), (const unsigned char *) (SUF + grp * (kJ2kMaxPlanes + 2) * 64 * 64),
+               (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
+    SegEmDev em{(unsigned char *) ring + threadIdx.x * 68u, SYM + grp * (size_t) sym_rows * 1024 + threadIdx.x * 16u,
+                seglen + grp * kJ2kSegCount * 64 + threadIdx.x, sym_rows};
+    const int nstr = (l.h + 3) >> 2;
+    for (int s = 0; s < nstr; s++) t1::emit_stripe_segments(M, em, l.P, p, s, l.w, l.h, l.orient);
+}
+
+// ---- arithmetic coding of the row streams: one wave per group, a code-block per lane (t1::mq_encode_rows)
+struct LdsTable2 {
+    const __attribute__((address_space(3))) uint32_t *t;
+    __device__ uint32_t operator()(uint32_t st7) const { return t[st7]; }
 };
-struct MqSink {
-    // coded bytes leave in aligned 8-byte words (a byte store per BYTEOUT costs a whole memory transaction each)
-    uint8_t *p; int *overflow;
-    unsigned long long win = 0;
-    int base = 0;                  // index of the first byte held in win
+struct RowSrcDev {
+    const uint8_t *sym;            // the group's rows + lane * 16
+    uint32_t n, wn;                // rows of this lane, of the longest lane of the wave
+    __device__ uint32_t rows() const { return n; }
+    __device__ uint32_t wave_rows() const { return wn; }
+    __device__ void load(uint32_t row, uint32_t w[4]) const
+    {
+        const uint4 v = *(const uint4 *) (sym + (size_t) row * 1024);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    }
+};
+struct CtxLds2 {
+    // the context states of every lane, a dword each (state in its low byte): context c of lane l at (c * 64 + l) * 4,
+    // so a handle - the byte address - is one shift-add away from the decision byte and the bank is the lane
+    uint32_t base;                 // LDS byte address of this lane's context 0
+    __device__ uint32_t handle(uint32_t c) const { return base + (c << 8); }
+    __device__ uint32_t ld(uint32_t h) const { return *(const __attribute__((address_space(3))) unsigned char *) (uintptr_t) h; }
+    __device__ void st(uint32_t h, uint32_t v) { *(__attribute__((address_space(3))) unsigned char *) (uintptr_t) h = (unsigned char) v; }
+    __device__ void words(uint32_t x[5]) const
+    {
+        for (int j = 0; j < 5; j++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) if (4 * j + k < t1::NCTX) v |= ld(handle((uint32_t) (4 * j + k))) << (8 * k);
+            x[j] = v;
+        }
+    }
+};
+struct MqSinkLds {
+    // coded bytes go into a 64-byte ring per lane in LDS (lane stride 68 bytes: lanes at the same offset never
+    // conflict) and leave as aligned 8-byte words at the uniform points of the loop (every 16 decisions)
+    unsigned char *ring;           // LDS, this lane's 64 bytes
+    uint8_t *out; int *overflow;
+    int top = 0, fl = 0;           // bytes put so far, bytes written out (multiple of 8)
     __device__ void put(int i, uint32_t b)
     {
-        if (i < 0) return;
-        if (i >= kJ2kCblkBytes) { *overflow = 1; return; }
-        const int w = i & ~7;
-        if (w != base) { *(unsigned long long *) (p + base) = win; win = 0; base = w; }
-        const int sh = 8 * (i & 7);
-        win = (win & ~(0xFFull << sh)) | ((unsigned long long) (b & 0xFFu) << sh);
+        ring[(uint32_t) i & 63u] = (unsigned char) b;                    // (i == -1 lands in byte 63 and is overwritten later)
+        top = i + 1;
     }
-    __device__ void finish() { *(unsigned long long *) (p + base) = win; }
+    __device__ void word()
+    {
+        const uint32_t *q = (const uint32_t *) (ring + ((uint32_t) fl & 63u));
+        if (fl + 8 <= kJ2kCblkBytes) *(uint2 *) (out + fl) = make_uint2(q[0], q[1]); else *overflow = 1;
+        fl += 8;
+    }
+    __device__ void row_end() { while (fl + 8 <= top) word(); }
+    __device__ void finish() { row_end(); if (fl < top) word(); }
 };
 
-__global__ __launch_bounds__(64) void k_t1_mq(const uint8_t *SYM, const uint32_t *nsym, const int *numbps,
-                                               const int *totalpasses, int *cblk_len, int *rates, uint8_t *cblk_bytes, void *ckpt,
-                                               const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf,
-                                               int total, int lpw)
+__global__ __launch_bounds__(64) void k_t1_mqrows(const uint8_t *SYM, const uint32_t *lanerows, const int *blkmax, int *cblk_len,
+                                                   int *rates, uint8_t *cblk_bytes, void *ckpt, const J2kGeom *geom,
+                                                   const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows)
 {
-    EBCC_LDS_MQ_TABLE(tab);
-    __shared__ uint32_t ring[16 * 64];
-    __shared__ uint32_t ctxw[5 * 64];
-    if ((int) threadIdx.x >= lpw) return;
-    const int gid0 = blockIdx.x * lpw;
-    const int gid = gid0 + threadIdx.x;
-    if (gid >= total) return;
-    const int nb = geom->stride;
-    const int frame = gid / nb, bi = gid - frame * nb;
-    if (fs[frame].const_field) return;
-    blocks = j2k_frame_blocks(geom, blocks, frame);
-    geom = &j2k_frame_geom(geom, frame);
-    const int np = totalpasses[gid];
-    if (numbps[gid] <= 0 || np <= 0) return;
-    const J2kBlock blk = blocks[bi];
-    const uint32_t lane8 = (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u;
-    uint8_t *out = cblk_bytes + (size_t) gid * kJ2kCblkBytes;
-    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, lane8};
-    SymSrcDev src{SYM + (size_t) gid * kJ2kSymCap, ring, threadIdx.x};
-    src.prefetch(0);
-    t1::EncodeResult r = t1::mq_encode_stream(src, CtxLds{(unsigned char *) (ctxw + threadIdx.x)}, nsym[gid], np,
-                                              MqSink{out, &jf[frame].overflow}, DevAt{out, kJ2kCblkBytes},
-                                              rates + (size_t) gid * kJ2kMaxPasses, ck, tab);
+    __shared__ uint32_t tab_store[128];
+    __shared__ uint32_t ctxw[32 * 64];
+    __shared__ uint32_t bring[17 * 64];
+    tab_store[threadIdx.x] = t1::mq_entry2((int) threadIdx.x);
+    tab_store[threadIdx.x + 64] = t1::mq_entry2((int) threadIdx.x + 64);
+    __syncthreads();
+    const LdsTable2 tab{(const __attribute__((address_space(3))) uint32_t *) tab_store};
+    const size_t grp = blockIdx.x;
+    const int gid = (int) (grp * 64) + (int) threadIdx.x;
+    const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
+    uint32_t nrows = l.live ? lanerows[gid] : 0u;
+    if (nrows > sym_rows) nrows = 0;                                     // (overflow: the host retries, see k_t1_rowoffs)
+    uint32_t wrows = nrows;
+    for (int d = 32; d >= 1; d >>= 1) wrows = max(wrows, (uint32_t) __shfl_xor((int) wrows, d));
+    wrows = (uint32_t) __builtin_amdgcn_readfirstlane((int) wrows);
+    if (wrows == 0) return;
+    // (lanes without a code-block run along with no rows: nothing is coded or stored for them)
+    const bool on = nrows > 0;
+    uint8_t *out = cblk_bytes + (size_t) (on ? gid : 0) * kJ2kCblkBytes;
+    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, threadIdx.x * 8u};
+    RowSrcDev src{SYM + grp * (size_t) sym_rows * 1024 + threadIdx.x * 16u, nrows, wrows};
+    const int P = on ? l.P : 0, nstr = (l.h + 3) >> 2;
+    const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + threadIdx.x * 4u;
+    t1::EncodeResult r = t1::mq_encode_rows(src, CtxLds2{ctx_base}, P, nstr,
+                                            MqSinkLds{(unsigned char *) bring + threadIdx.x * 68u, out, &jf[l.frame].overflow},
+                                            DevAt{out, kJ2kCblkBytes}, rates + (size_t) (on ? gid : 0) * kJ2kMaxPasses, ck, tab);
+    if (P <= 0) return;
     cblk_len[gid] = r.length;
     __threadfence();                                                    // the sweep below re-reads this lane's own bytes
-    t1::finalize_checkpoints(ck, np, (blk.h + 3) >> 2, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
+    t1::finalize_checkpoints(ck, r.totalpasses, nstr, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
 }
 
 // ================================================================================================
@@ -946,13 +1021,80 @@ static const short *nmsedec_luts(hipStream_t s)
     return g_luts;
 }
 
+__global__ void k_jf_reset(J2kFrame *jf, int n)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) jf[f].overflow = 0;
+}
+
+// tier-1 of every code-block of the batch from the masks k_quantize left.  Default: the segmented two-phase encoder;
+// `single_kernel` (EBCC_T1_TWO_PHASE=0, or the retry after a group's decisions outgrew its rows of SYM - jf.overflow
+// bit 1) runs passes and MQ coder in one kernel instead.  Same bytes, rates, checkpoints and masks either way.
+void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool single_kernel)
+{
+    const J2kGeom &g = jb.geom;
+    const FrameState *fs = jb.fs;
+    const int total = n_frames * g.stride;
+    const size_t groups = ((size_t) total + 63) / 64;
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.SPS, 0, groups * 64 * 64 * sizeof(unsigned long long), s));
+    timing_begin("t1_encode", s);
+    if (!jb.SYM || single_kernel) {
+        EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
+        int lpw = getenv("EBCC_T1_LPW") ? t1_lanes_per_wave(T1_ENCODE) : 32;    // (the single-kernel encoder is at its best with 32)
+        unsigned t1_grid = (unsigned) ceil_div(total, lpw);
+        hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
+                           jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.VISP, jb.d_geom,
+                           jb.d_blocks, fs, jb.jf, total, lpw);
+    } else {
+        EBCC_HIP_CHECK(hipMemsetAsync(jb.seglen, 0, groups * (size_t) kJ2kSegCount * 64 * sizeof(std::uint16_t), s));
+        timing_begin("t1_symbols", s);
+        hipLaunchKernelGGL(k_t1_scan, dim3((unsigned) groups), dim3(64), 0, s, jb.BP, jb.SUF, jb.SGN, jb.SPS, jb.VISP, jb.blkmax, jb.numbps,
+                           jb.totalpasses, jb.cblk_len, jb.seglen, jb.d_geom, jb.d_blocks, fs, total);
+        hipLaunchKernelGGL(k_t1_rowoffs, dim3((unsigned) groups), dim3(64), 0, s, jb.seglen, jb.lanerows, jb.blkmax, jb.jf, jb.d_geom, jb.d_blocks,
+                           fs, total, (uint32_t) jb.sym_rows);
+        hipLaunchKernelGGL(k_t1_emit, dim3((unsigned) groups, kJ2kMaxPlanes), dim3(64), 0, s, jb.BP, jb.SUF, jb.SGN, jb.VISP, jb.blkmax, jb.SYM,
+                           jb.seglen, jb.lanerows, jb.d_geom, jb.d_blocks, fs, total, (uint32_t) jb.sym_rows);
+        timing_end("t1_symbols", s);
+        if (getenv("EBCC_HIP_T1_STATS")) {                               // diagnostics: rows of 16 decisions per code-block (a wave of the MQ pass walks its longest lane's)
+            std::vector<uint32_t> tot((size_t) total);
+            EBCC_HIP_CHECK(hipMemcpyAsync(tot.data(), jb.lanerows, sizeof(uint32_t) * (size_t) total, hipMemcpyDeviceToHost, s));
+            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+            uint32_t mx = 0; double sum = 0, wsum = 0;
+            for (size_t g0 = 0; g0 < (size_t) total; g0 += 64) {
+                uint32_t wm = 0;
+                for (size_t i = g0; i < std::min((size_t) total, g0 + 64); i++) { wm = std::max(wm, tot[i]); sum += tot[i]; }
+                wsum += wm; mx = std::max(mx, wm);
+            }
+            fprintf(stderr, "ebcc-mi355x tier-1: %zu groups, rows of 16 decisions: per code-block mean %.0f, per wave mean %.0f max %u (cap %d)\n", groups,
+                    sum / (double) total, wsum / (double) groups, mx, jb.sym_rows);
+        }
+        timing_begin("t1_mq", s);
+        hipLaunchKernelGGL(k_t1_mqrows, dim3((unsigned) groups), dim3(64), 0, s, jb.SYM, jb.lanerows, jb.blkmax, jb.cblk_len, jb.rates,
+                           jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, (uint32_t) jb.sym_rows);
+        timing_end("t1_mq", s);
+    }
+    timing_end("t1_encode", s);
+    hipLaunchKernelGGL(k_distortion, dim3(g.stride, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
+                       jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
+}
+
+bool j2k_tier1_retry(const J2kBuffers &jb, int n_frames, const J2kFrame *host_jf, hipStream_t s)
+{
+    bool need = false;
+    for (int f = 0; f < n_frames; f++) need |= (host_jf[f].overflow & 2) != 0;
+    if (!need) return false;
+    hipLaunchKernelGGL(k_jf_reset, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.jf, n_frames);
+    launch_j2k_tier1(jb, n_frames, s, true);
+    return true;
+}
+
 void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, hipStream_t s)
 {
     const FrameState *fs = jb.fs;
     const J2kGeom &g = jb.geom;
     const size_t n_pix = (size_t) g.W * g.H;
     const int total = n_frames * g.stride;
-    const size_t groups = ((size_t) total + 63) / 64;
+    hipLaunchKernelGGL(k_jf_reset, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.jf, n_frames);
     hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.rate_path_n, 0, sizeof(int) * (size_t) n_frames, s));   // new pass tables: k_rate's record starts over
     EBCC_HIP_CHECK(hipMemsetAsync(jb.lastnp, 0xFF, sizeof(int) * (size_t) total, s));         // and so does the probe decode's
@@ -964,31 +1106,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     timing_end("j2k_dwt_fwd", s);
     hipLaunchKernelGGL(k_quantize, dim3(g.stride, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
                        jb.d_geom, jb.d_blocks, fs);
-    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
-    EBCC_HIP_CHECK(hipMemsetAsync(jb.SPS, 0, groups * 64 * 64 * sizeof(unsigned long long), s));
-    timing_begin("t1_encode", s);
-    if (!jb.SYM) {
-        int lpw = getenv("EBCC_T1_LPW") ? t1_lanes_per_wave(T1_ENCODE) : 32;    // (the single-kernel encoder is at its best with 32)
-        unsigned t1_grid = (unsigned) ceil_div(total, lpw);
-        hipLaunchKernelGGL(k_t1_encode, dim3(t1_grid), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax, jb.numbps,
-                           jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.VISP, jb.d_geom,
-                           jb.d_blocks, fs, jb.jf, total, lpw);
-    } else {                                                             // EBCC_T1_TWO_PHASE=1
-        timing_begin("t1_symbols", s);
-        int lpw = t1_lanes_per_wave(T1_ENCODE, total);
-        hipLaunchKernelGGL(k_t1_symbols, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.BP, jb.SGN, jb.SPS, jb.blkmax,
-                           jb.numbps, jb.totalpasses, jb.cblk_len, jb.SYM, jb.nsym, jb.VISP, jb.d_geom, jb.d_blocks, fs, jb.jf,
-                           total, lpw);
-        timing_end("t1_symbols", s);
-        timing_begin("t1_mq", s);
-        lpw = t1_lanes_per_wave(T1_MQ, total);
-        hipLaunchKernelGGL(k_t1_mq, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.SYM, jb.nsym, jb.numbps,
-                           jb.totalpasses, jb.cblk_len, jb.rates, jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, lpw);
-        timing_end("t1_mq", s);
-    }
-    timing_end("t1_encode", s);
-    hipLaunchKernelGGL(k_distortion, dim3(g.stride, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
-                       jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
+    launch_j2k_tier1(jb, n_frames, s, false);
 }
 
 // dequantisation + inverse transform of the tier-1 decoder's output V through the tile buffers B to the decoded

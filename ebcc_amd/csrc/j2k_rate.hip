@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     // see are needed when no further pass follows, but all 64 are cheap next to the decode.
     const unsigned long long *sg = SGN + grp * 64 * 64 + gl;
     const unsigned long long *sps = SPS + grp * 64 * 64 + gl;
+    st.S(-1) = 0; st.S(64) = 0;                                         // (the guard rows: nothing else writes them on this path)
     for (int y = 0; y < 64; y++) {
         unsigned long long S = 0, R = 0, Vv = 0;
         const int q = r + (y < 4 * stripe ? 1 : 0);

@@ -354,11 +354,7 @@ T1_HD int ctx_sc(uint32_t sup, uint32_t smid, uint32_t sdn, uint32_t nup, uint32
 // renormalisation shift count of the interval register: a in [1, 0x7FFF] -> shifts until bit 15 is set
 T1_HD int renorm_shifts(uint32_t a)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __clz((int) a) - 16;
-#else
-    return __builtin_clz(a) - 16;
-#endif
+    return __builtin_clz(a) - 16;                                        // (a is never 0)
 }
 
 T1_HD int ctz64(u64 v)
@@ -695,6 +691,204 @@ struct Passes {
         }
     }
 
+    // ---- per-stripe pieces of the bit-parallel passes: membership masks, decision counts, column emission.
+    // The column loops work on 32-bit halves of the row masks (a 64-bit variable shift is a quarter-rate
+    // instruction on gfx950; v_bfe_u32 on a half is full rate).
+    struct Lo { T1_HD static uint32_t of(u64 v) { return (uint32_t) v; } };
+    struct Hi { T1_HD static uint32_t of(u64 v) { return (uint32_t) (v >> 32); } };
+    T1_HD static uint32_t bit32(uint32_t m, int x) { return (m >> x) & 1u; }
+    T1_HD static int ctz32(uint32_t v)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __ffs((int) v) - 1;
+#else
+        return __builtin_ctz(v);
+#endif
+    }
+    T1_HD static int popc64(u64 v)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __popcll(v);
+#else
+        return __builtin_popcountll(v);
+#endif
+    }
+
+    // propagation pass over one stripe: m = samples coded, n = samples that become significant
+    T1_HD void sigprop_members(const Stripe &sp, const u64 b[4], u64 m[4], u64 n[4]) const
+    {
+        u64 cand[4], p[4], nbo[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            cand[r] = ~sp.s[r + 1] & (r < sp.nrows ? sp.wmask : 0ull);
+            p[r] = cand[r] & b[r];
+            nbo[r] = neighbours(sp.s[r], sp.s[r + 1], sp.s[r + 2]);
+            n[r] = 0;
+        }
+        bool changed;
+        do {
+            changed = false;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const u64 ext = (r > 0 ? n[r - 1] | (n[r - 1] << 1) : 0ull) | (r < 3 ? n[r + 1] << 1 : 0ull);
+                const u64 v = flood(p[r], p[r] & (nbo[r] | ext));
+                changed |= v != n[r];
+                n[r] = v;
+            }
+        } while (changed);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const u64 ext = (r > 0 ? n[r - 1] | (n[r - 1] << 1) : 0ull) | (r < 3 ? n[r + 1] << 1 : 0ull);
+            m[r] = cand[r] & (nbo[r] | ext | (n[r] << 1));
+        }
+    }
+    T1_HD static uint32_t sigprop_count(const u64 m[4], const u64 n[4])
+    {
+        return (uint32_t) (popc64(m[0]) + popc64(m[1]) + popc64(m[2]) + popc64(m[3]) + popc64(n[0]) + popc64(n[1]) + popc64(n[2]) + popc64(n[3]));
+    }
+    template <class H, class Em>
+    T1_HD static void sigprop_cols(Em &em, const u64 m[4], const u64 b[4], const RowCtx zc[4], const RowSgn sc[4])
+    {
+        uint32_t m_[4], b_[4], z0[4], z1[4], z2[4], z3[4], c0[4], c1[4], c2[4], sb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            m_[r] = H::of(m[r]); b_[r] = H::of(b[r]);
+            z0[r] = H::of(zc[r].n0); z1[r] = H::of(zc[r].n1); z2[r] = H::of(zc[r].n2); z3[r] = H::of(zc[r].n3);
+            c0[r] = H::of(sc[r].c0); c1[r] = H::of(sc[r].c1); c2[r] = H::of(sc[r].c2); sb[r] = H::of(sc[r].sb);
+        }
+        uint32_t pending = m_[0] | m_[1] | m_[2] | m_[3];
+        while (pending) {
+            T1_STAT(0);
+            const int x = ctz32(pending);
+            pending &= pending - 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t on = bit32(m_[r], x), d = bit32(b_[r], x);
+                em.emit_if(on != 0, bit32(z0[r], x) | (bit32(z1[r], x) << 1) | (bit32(z2[r], x) << 2) | (bit32(z3[r], x) << 3), d);
+                em.emit_if((on & d) != 0, (uint32_t) CTX_SC0 + (bit32(c0[r], x) | (bit32(c1[r], x) << 1) | (bit32(c2[r], x) << 2)), bit32(sb[r], x));
+            }
+            em.column_end();
+        }
+    }
+    template <class Em>
+    T1_HD void sigprop_emit(Em &em, const Stripe &sp, const u64 b[4], const u64 m[4], const u64 n[4]) const
+    {
+        if ((m[0] | m[1] | m[2] | m[3]) == 0) return;
+        RowCtx zc[4];
+        RowSgn sc[4];
+        row_contexts(sp, n, zc, sc);
+        sigprop_cols<Lo>(em, m, b, zc, sc);
+        sigprop_cols<Hi>(em, m, b, zc, sc);
+    }
+
+    // cleanup pass over one stripe: m = samples coded here, n = those that become significant, agg = columns in
+    // run-length mode (all four samples coded here, nothing significant in the 3 x 6 neighbourhood on entry)
+    T1_HD void cleanup_members(const Stripe &sp, const u64 b[4], bool full, u64 m[4], u64 n[4], u64 &agg) const
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            m[r] = ~(sp.s[r + 1] | sp.vis[r]) & (r < sp.nrows ? sp.wmask : 0ull);
+            n[r] = m[r] & b[r];
+        }
+        agg = 0;
+        if (full) {
+            u64 any = (n[0] | n[1] | n[2] | n[3]) << 1;
+#pragma unroll
+            for (int r = 0; r < 6; r++) any |= sp.s[r] | (sp.s[r] << 1) | (sp.s[r] >> 1);
+            agg = m[0] & m[1] & m[2] & m[3] & ~any;
+        }
+    }
+    // decisions of the stripe: AGG per run-length column, two UNIFORM bits when the run ends inside it, a zero-coding
+    // decision for every coded sample that is not covered by the run, a sign for every newly significant one
+    T1_HD static uint32_t cleanup_count(const u64 m[4], const u64 n[4], const u64 b[4], u64 agg)
+    {
+        const u64 hit = agg & (b[0] | b[1] | b[2] | b[3]);
+        uint32_t c = (uint32_t) (popc64(agg) + 2 * popc64(hit));
+        u64 prior = 0;                                                   // a row above in this column has its bit set
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            c += (uint32_t) (popc64(m[r] & ~(agg & ~prior)) + popc64(n[r]));
+            prior |= b[r];
+        }
+        return c;
+    }
+    template <class H, class Em>
+    T1_HD static void cleanup_cols(Em &em, const u64 m[4], const u64 b[4], u64 agg, const RowCtx zc[4], const RowSgn sc[4])
+    {
+        uint32_t m_[4], b_[4], z0[4], z1[4], z2[4], z3[4], c0[4], c1[4], c2[4], sb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            m_[r] = H::of(m[r]); b_[r] = H::of(b[r]);
+            z0[r] = H::of(zc[r].n0); z1[r] = H::of(zc[r].n1); z2[r] = H::of(zc[r].n2); z3[r] = H::of(zc[r].n3);
+            c0[r] = H::of(sc[r].c0); c1[r] = H::of(sc[r].c1); c2[r] = H::of(sc[r].c2); sb[r] = H::of(sc[r].sb);
+        }
+        const uint32_t agg_ = H::of(agg);
+        uint32_t pending = m_[0] | m_[1] | m_[2] | m_[3];
+        while (pending) {
+            T1_STAT(2);
+            const int x = ctz32(pending);
+            pending &= pending - 1;
+            const uint32_t a = bit32(agg_, x);
+            const uint32_t d0 = bit32(b_[0], x), d1 = bit32(b_[1], x), d2 = bit32(b_[2], x), d3 = bit32(b_[3], x);
+            const uint32_t run = d0 ? 0u : (d1 ? 1u : (d2 ? 2u : (d3 ? 3u : 4u)));
+            const bool hit = a && run != 4u;
+            em.emit_if(a != 0, (uint32_t) CTX_AGG, run != 4u ? 1u : 0u);
+            em.emit_if(hit, (uint32_t) CTX_UNI, run >> 1);
+            em.emit_if(hit, (uint32_t) CTX_UNI, run & 1u);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t on = bit32(m_[r], x), d = bit32(b_[r], x);
+                const bool zc_on = on && !(a && (uint32_t) r <= run);          // rows up to the run's end carry no own decision
+                em.emit_if(zc_on, bit32(z0[r], x) | (bit32(z1[r], x) << 1) | (bit32(z2[r], x) << 2) | (bit32(z3[r], x) << 3), d);
+                em.emit_if((on & d) != 0, (uint32_t) CTX_SC0 + (bit32(c0[r], x) | (bit32(c1[r], x) << 1) | (bit32(c2[r], x) << 2)), bit32(sb[r], x));
+            }
+            em.column_end();
+        }
+    }
+    template <class Em>
+    T1_HD void cleanup_emit(Em &em, const Stripe &sp, const u64 b[4], const u64 m[4], const u64 n[4], u64 agg) const
+    {
+        if ((m[0] | m[1] | m[2] | m[3]) == 0) return;
+        RowCtx zc[4];
+        RowSgn sc[4];
+        row_contexts(sp, n, zc, sc);
+        cleanup_cols<Lo>(em, m, b, agg, zc, sc);
+        cleanup_cols<Hi>(em, m, b, agg, zc, sc);
+    }
+
+    // refinement pass over one stripe: m = samples significant before this plane, ref = refined before, nb = "has a
+    // significant neighbour"
+    template <class H, class Em>
+    T1_HD static void refine_cols(Em &em, const u64 m[4], const u64 b[4], const u64 ref[4], const u64 nb[4])
+    {
+        uint32_t m_[4], b_[4], r_[4], n_[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { m_[r] = H::of(m[r]); b_[r] = H::of(b[r]); r_[r] = H::of(ref[r]); n_[r] = H::of(nb[r]); }
+        uint32_t pending = m_[0] | m_[1] | m_[2] | m_[3];
+        while (pending) {
+            T1_STAT(1);
+            const int x = ctz32(pending);
+            pending &= pending - 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                em.emit_if(bit32(m_[r], x) != 0, (uint32_t) CTX_MAG0 + (bit32(r_[r], x) ? 2u : bit32(n_[r], x)), bit32(b_[r], x));
+            em.column_end();
+        }
+    }
+    template <class Em>
+    T1_HD void refine_emit(Em &em, const Stripe &sp, const u64 b[4], const u64 ref[4], u64 m[4]) const
+    {
+        u64 nb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            m[r] = sp.s[r + 1] & ~sp.vis[r];                              // significant before this plane
+            nb[r] = neighbours(sp.s[r], sp.s[r + 1], sp.s[r + 2]);
+        }
+        if ((m[0] | m[1] | m[2] | m[3]) == 0) return;
+        refine_cols<Lo>(em, m, b, ref, nb);
+        refine_cols<Hi>(em, m, b, ref, nb);
+    }
+
     T1_HD void sigprop_bits(int plane, int ystart = 0)
     {
         for (int y0 = ystart; y0 < h; y0 += 4) {
@@ -702,48 +896,9 @@ struct Passes {
             Stripe sp;
             load(sp, y0);
             const u64 b[4] = {st.BP(plane, y0), st.BP(plane, y0 + 1), st.BP(plane, y0 + 2), st.BP(plane, y0 + 3)};
-            u64 cand[4], p[4], nbo[4], n[4] = {0, 0, 0, 0}, m[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                cand[r] = ~sp.s[r + 1] & (r < sp.nrows ? sp.wmask : 0ull);
-                p[r] = cand[r] & b[r];
-                nbo[r] = neighbours(sp.s[r], sp.s[r + 1], sp.s[r + 2]);
-            }
-            bool changed;
-            do {
-                changed = false;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const u64 ext = (r > 0 ? n[r - 1] | (n[r - 1] << 1) : 0ull) | (r < 3 ? n[r + 1] << 1 : 0ull);
-                    const u64 v = flood(p[r], p[r] & (nbo[r] | ext));
-                    changed |= v != n[r];
-                    n[r] = v;
-                }
-            } while (changed);
-            u64 pending = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const u64 ext = (r > 0 ? n[r - 1] | (n[r - 1] << 1) : 0ull) | (r < 3 ? n[r + 1] << 1 : 0ull);
-                m[r] = cand[r] & (nbo[r] | ext | (n[r] << 1));
-                pending |= m[r];
-            }
-            if (pending) {
-                RowCtx zc[4];
-                RowSgn sc[4];
-                row_contexts(sp, n, zc, sc);
-                while (pending) {
-                    T1_STAT(0);
-                    const int x = ctz64(pending);
-                    pending &= pending - 1;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t on = bit_at(m[r], x), d = bit_at(b[r], x);
-                        mq.emit_if(on != 0, bit_at(zc[r].n0, x) | (bit_at(zc[r].n1, x) << 1) | (bit_at(zc[r].n2, x) << 2) | (bit_at(zc[r].n3, x) << 3), d);
-                        mq.emit_if((on & d) != 0, (uint32_t) CTX_SC0 + (bit_at(sc[r].c0, x) | (bit_at(sc[r].c1, x) << 1) | (bit_at(sc[r].c2, x) << 2)),
-                                   bit_at(sc[r].sb, x));
-                    }
-                }
-            }
+            u64 n[4], m[4];
+            sigprop_members(sp, b, m, n);
+            sigprop_emit(mq, sp, b, m, n);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 sp.s[r + 1] |= n[r];
@@ -762,47 +917,9 @@ struct Passes {
             Stripe sp;
             load(sp, y0);
             const u64 b[4] = {st.BP(plane, y0), st.BP(plane, y0 + 1), st.BP(plane, y0 + 2), st.BP(plane, y0 + 3)};
-            u64 m[4], n[4], pending = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                m[r] = ~(sp.s[r + 1] | sp.vis[r]) & (r < sp.nrows ? sp.wmask : 0ull);
-                n[r] = m[r] & b[r];
-                pending |= m[r];
-            }
-            if (pending) {
-                // run-length mode: all four samples of the column are coded here and nothing in the 3 x 6
-                // neighbourhood is significant when the column is entered (previous column's news included)
-                u64 agg = 0;
-                if (y0 + 3 < h) {
-                    u64 any = (n[0] | n[1] | n[2] | n[3]) << 1;
-#pragma unroll
-                    for (int r = 0; r < 6; r++) any |= sp.s[r] | (sp.s[r] << 1) | (sp.s[r] >> 1);
-                    agg = m[0] & m[1] & m[2] & m[3] & ~any;
-                }
-                RowCtx zc[4];
-                RowSgn sc[4];
-                row_contexts(sp, n, zc, sc);
-                while (pending) {
-                    T1_STAT(2);
-                    const int x = ctz64(pending);
-                    pending &= pending - 1;
-                    const uint32_t a = bit_at(agg, x);
-                    const uint32_t d0 = bit_at(b[0], x), d1 = bit_at(b[1], x), d2 = bit_at(b[2], x), d3 = bit_at(b[3], x);
-                    const uint32_t run = d0 ? 0u : (d1 ? 1u : (d2 ? 2u : (d3 ? 3u : 4u)));
-                    const bool hit = a && run != 4u;
-                    mq.emit_if(a != 0, (uint32_t) CTX_AGG, run != 4u ? 1u : 0u);
-                    mq.emit_if(hit, (uint32_t) CTX_UNI, run >> 1);
-                    mq.emit_if(hit, (uint32_t) CTX_UNI, run & 1u);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t on = bit_at(m[r], x), d = bit_at(b[r], x);
-                        const bool zc_on = on && !(a && (uint32_t) r <= run);          // rows up to the run's end carry no own decision
-                        mq.emit_if(zc_on, bit_at(zc[r].n0, x) | (bit_at(zc[r].n1, x) << 1) | (bit_at(zc[r].n2, x) << 2) | (bit_at(zc[r].n3, x) << 3), d);
-                        mq.emit_if((on & d) != 0, (uint32_t) CTX_SC0 + (bit_at(sc[r].c0, x) | (bit_at(sc[r].c1, x) << 1) | (bit_at(sc[r].c2, x) << 2)),
-                                   bit_at(sc[r].sb, x));
-                    }
-                }
-            }
+            u64 m[4], n[4], agg;
+            cleanup_members(sp, b, y0 + 3 < h, m, n, agg);
+            cleanup_emit(mq, sp, b, m, n, agg);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 sp.s[r + 1] |= n[r];
@@ -820,22 +937,9 @@ struct Passes {
             Stripe sp;
             load(sp, y0);
             const u64 b[4] = {st.BP(plane, y0), st.BP(plane, y0 + 1), st.BP(plane, y0 + 2), st.BP(plane, y0 + 3)};
-            u64 m[4], ref[4], nb[4], pending = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                m[r] = sp.s[r + 1] & ~sp.vis[r];                          // significant before this plane
-                ref[r] = st.REF(y0 + r);
-                nb[r] = neighbours(sp.s[r], sp.s[r + 1], sp.s[r + 2]);
-                pending |= m[r];
-            }
-            while (pending) {
-                T1_STAT(1);
-                const int x = ctz64(pending);
-                pending &= pending - 1;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    mq.emit_if(bit_at(m[r], x) != 0, (uint32_t) CTX_MAG0 + (bit_at(ref[r], x) ? 2u : bit_at(nb[r], x)), bit_at(b[r], x));
-            }
+            const u64 ref[4] = {st.REF(y0), st.REF(y0 + 1), st.REF(y0 + 2), st.REF(y0 + 3)};
+            u64 m[4];
+            refine_emit(mq, sp, b, ref, m);
 #pragma unroll
             for (int r = 0; r < 4; r++) st.REF(y0 + r) = ref[r] | m[r];
         }
@@ -973,6 +1077,7 @@ struct SymbolEmitter {
     T1_HD void emit(int ctx, int d) { put(n, (uint32_t) ctx | ((uint32_t) d << 5)); n++; }
     // the same when `on`, nothing otherwise - without a branch around it (bit-parallel passes below)
     T1_HD void emit_if(bool on, uint32_t ctx, uint32_t d) { put.put_if(on, n, ctx | (d << 5)); n += on ? 1u : 0u; }
+    T1_HD void column_end() {}
     T1_HD void mark(bool new_pass) { put(n, kSymStripe | (new_pass ? kSymPass : 0u)); n++; }
     T1_HD void encode_zc(int ctx, int d) { emit(ctx, d); }
     T1_HD void encode_sc(int ctx, int d) { emit(ctx, d); }
@@ -1104,6 +1209,280 @@ T1_HD EncodeResult mq_encode_stream(SymSrc sym, CtxMem cx, uint32_t nsym, int np
     EncodeResult r;
     r.totalpasses = npasses;
     r.length = n;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented two-phase encoder: the decision stream of a code-block cut into SEGMENTS, one per (bit-plane,
+// pass type, stripe).  Everything a segment needs follows from the encoder's masks alone:
+//     significant before plane p          SUF[p + 1]          (OR of the bit-plane masks above p)
+//     coded by plane p's propagation pass VISP[p]             (scan_block below: mask arithmetic, no decisions)
+//     significant after it                SUF[p + 1] | (VISP[p] & BP[p])
+//     refined before plane p              SUF[p + 2]
+// so the segments of a code-block can be produced in any order - one wave per (64 code-blocks, plane) on the
+// device.  A segment is padded to whole rows of 16 decisions and flagged in-band, so the MQ pass is a loop over
+// rows in which stripe checkpoints and pass boundaries are handled once per row, not per decision; the inner loop
+// is the arithmetic coder and nothing else, the same instruction stream for all 64 code-blocks of a wave.
+//   scan_block            -> VISP, SPS and the number of decisions of every segment
+//   emit_stripe_segments  -> the decisions of the three segments of one (plane, stripe)
+//   mq_encode_rows        -> bytes, pass rates and checkpoints (identical to encode_block_observed)
+// ------------------------------------------------------------------------------------------------
+constexpr int kSegPlanes = 26;                                            // == kJ2kMaxPlanes (j2k.hpp)
+constexpr int kSegCount = kSegPlanes * 3 * 16;
+T1_HD int seg_index(int p, int t, int s) { return ((kSegPlanes - 1 - p) * 3 + t) * 16 + s; }
+T1_HD int seg_plane(int seg) { return kSegPlanes - 1 - seg / 48; }
+T1_HD int seg_type(int seg) { return (seg >> 4) % 3; }
+// does code-block (P planes, nstr stripes) have segment (p, t, s)?  (its top plane has a cleanup pass only)
+T1_HD bool seg_valid(int P, int nstr, int p, int t, int s) { return p < P && (p < P - 1 || t == 2) && s < nstr; }
+
+// Masks: u64 BP(int plane, int y), SUF(int plane, int y), SGN(int y), VISP(int plane, int y) for y in [0, 64) and
+// planes in [0, kSegPlanes + 1]; rows at or beyond the block height are never asked for.
+template <class Masks>
+struct MaskRows {
+    Masks &M;
+    int h;
+    T1_HD u64 bp(int p, int y) const { return (y >= 0 && y < h) ? M.BP(p, y) : 0ull; }
+    T1_HD u64 suf(int p, int y) const { return (y >= 0 && y < h) ? M.SUF(p, y) : 0ull; }
+    T1_HD u64 sgn(int y) const { return (y >= 0 && y < h) ? M.SGN(y) : 0ull; }
+    T1_HD u64 visp(int p, int y) const { return (y >= 0 && y < h) ? M.VISP(p, y) : 0ull; }
+};
+struct NullCoder {};
+
+// Out: void visp(int plane, int y, u64 m), void sps_or(int y, u64 n), void len(int seg, uint32_t decisions)
+template <class Masks, class Out>
+T1_HD void scan_block(Masks &M, Out &out, int P, int w, int h, int orient)
+{
+    NullCoder nc;
+    Passes<true, Masks, NullCoder> ps(M, nc, w, h, orient);
+    const MaskRows<Masks> R{M, h};
+    const int nstr = (h + 3) >> 2;
+    for (int p = P - 1; p >= 0; p--) {
+        const bool top = p == P - 1;
+        Stripe sp;
+        sp.wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+        if (!top) {
+            u64 carry = 0;                                                // new significance of the row above the stripe
+            for (int s = 0; s < nstr; s++) {
+                const int y0 = 4 * s;
+                sp.nrows = h - y0 < 4 ? h - y0 : 4;
+#pragma unroll
+                for (int r = 0; r < 6; r++) sp.s[r] = R.suf(p + 1, y0 - 1 + r);
+                const u64 b[4] = {R.bp(p, y0), R.bp(p, y0 + 1), R.bp(p, y0 + 2), R.bp(p, y0 + 3)};
+                const uint32_t nref = (uint32_t) (ps.popc64(sp.s[1]) + ps.popc64(sp.s[2]) + ps.popc64(sp.s[3]) + ps.popc64(sp.s[4]));
+                sp.s[0] |= carry;
+                u64 m[4], n[4];
+                ps.sigprop_members(sp, b, m, n);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (r < sp.nrows) { out.visp(p, y0 + r, m[r]); if (n[r]) out.sps_or(y0 + r, n[r]); }
+                out.len(seg_index(p, 0, s), ps.sigprop_count(m, n));
+                out.len(seg_index(p, 1, s), nref);
+                carry = n[3];
+            }
+        }
+        for (int s = 0; s < nstr; s++) {
+            const int y0 = 4 * s;
+            sp.nrows = h - y0 < 4 ? h - y0 : 4;
+            sp.s[0] = R.suf(p, y0 - 1);                                   // the row above has been through this pass
+#pragma unroll
+            for (int r = 1; r < 6; r++) {
+                const int y = y0 - 1 + r;
+                sp.s[r] = R.suf(p + 1, y) | (top ? 0ull : (R.visp(p, y) & R.bp(p, y)));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) sp.vis[r] = top ? 0ull : R.visp(p, y0 + r);
+            const u64 b[4] = {R.bp(p, y0), R.bp(p, y0 + 1), R.bp(p, y0 + 2), R.bp(p, y0 + 3)};
+            u64 m[4], n[4], agg;
+            ps.cleanup_members(sp, b, y0 + 3 < h, m, n, agg);
+            out.len(seg_index(p, 2, s), ps.cleanup_count(m, n, b, agg));
+        }
+    }
+}
+
+// Em: void begin(int seg), void emit_if(bool on, uint32_t ctx, uint32_t d), void column_end(), void end()
+template <class Masks, class Em>
+T1_HD void emit_stripe_segments(Masks &M, Em &em, int P, int p, int s, int w, int h, int orient)
+{
+    Passes<true, Masks, Em> ps(M, em, w, h, orient);
+    const MaskRows<Masks> R{M, h};
+    const bool top = p == P - 1;
+    const int y0 = 4 * s;
+    u64 s1[6], A[6], sg[6], vp[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int y = y0 - 1 + r;
+        s1[r] = R.suf(p + 1, y);
+        sg[r] = R.sgn(y);
+        vp[r] = top ? 0ull : R.visp(p, y);
+        A[r] = s1[r] | (vp[r] & R.bp(p, y));
+    }
+    const u64 b[4] = {R.bp(p, y0), R.bp(p, y0 + 1), R.bp(p, y0 + 2), R.bp(p, y0 + 3)};
+    Stripe sp;
+    sp.wmask = w >= 64 ? ~0ull : ((1ull << w) - 1);
+    sp.nrows = h - y0 < 4 ? h - y0 : 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { sp.sgn[r] = sg[r + 1]; sp.sps[r] = 0; }
+    u64 m[4], n[4];
+    if (!top) {
+        // propagation pass: the row above is through it, the rest as before the plane; nothing visited yet
+        sp.s[0] = A[0];
+#pragma unroll
+        for (int r = 1; r < 6; r++) sp.s[r] = s1[r];
+#pragma unroll
+        for (int r = 0; r < 6; r++) sp.neg[r] = sp.s[r] & sg[r];
+#pragma unroll
+        for (int r = 0; r < 4; r++) sp.vis[r] = 0;
+        em.begin(seg_index(p, 0, s));
+        ps.sigprop_members(sp, b, m, n);
+        ps.sigprop_emit(em, sp, b, m, n);
+        em.end();
+        // refinement pass: everything as after the propagation pass
+#pragma unroll
+        for (int r = 0; r < 6; r++) { sp.s[r] = A[r]; sp.neg[r] = A[r] & sg[r]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) sp.vis[r] = vp[r + 1];
+        const u64 ref[4] = {R.suf(p + 2, y0), R.suf(p + 2, y0 + 1), R.suf(p + 2, y0 + 2), R.suf(p + 2, y0 + 3)};
+        em.begin(seg_index(p, 1, s));
+        ps.refine_emit(em, sp, b, ref, m);
+        em.end();
+    }
+    // cleanup pass: the row above is through it (significant at or above this plane)
+    sp.s[0] = R.suf(p, y0 - 1);
+#pragma unroll
+    for (int r = 1; r < 6; r++) sp.s[r] = A[r];
+#pragma unroll
+    for (int r = 0; r < 6; r++) sp.neg[r] = sp.s[r] & sg[r];
+#pragma unroll
+    for (int r = 0; r < 4; r++) sp.vis[r] = vp[r + 1];
+    u64 agg;
+    em.begin(seg_index(p, 2, s));
+    ps.cleanup_members(sp, b, y0 + 3 < h, m, n, agg);
+    ps.cleanup_emit(em, sp, b, m, n, agg);
+    em.end();
+}
+
+// MQ state table of the segment coder: indexed by the whole context byte (6-bit state | mps << 6), an entry
+// holds Qe and BOTH successor bytes, so a symbol costs one table read and no sense/switch arithmetic:
+//     qe | (nmps | mps << 6) << 16 | (nlps | (mps ^ switch) << 6) << 24
+T1_HD uint32_t mq_entry2(int st7)
+{
+    const int i = st7 & 63, mps = st7 >> 6;
+    const uint32_t e = mq_entry(i < 47 ? i : 46);
+    const uint32_t nm = ((e >> 16) & 0x3Fu) | ((uint32_t) mps << 6), nl = ((e >> 22) & 0x3Fu) | (((uint32_t) mps ^ (e >> 28)) << 6);
+    return (e & 0xFFFFu) | (nm << 16) | (nl << 24);
+}
+struct ConstTable2 {
+    T1_HD uint32_t operator()(uint32_t st7) const { return mq_entry2((int) st7); }
+};
+
+// Row format of the decision streams: a code-block's decisions, segment after segment in coding order, in ROWS of
+// 16 bytes; every segment starts a new row (at least one, even when it has no decision), so a row never straddles
+// two segments.  Byte = context | bit << 5; bit 7 set = padding (no decision); bit 6 of byte 0 set = first row of a
+// segment (the coder checkpoints there and, at the first stripe of a pass, closes the previous pass).
+constexpr uint32_t kRowPad = 0x80u, kRowStart = 0x40u;
+T1_HD uint32_t seg_rows(uint32_t decisions) { return decisions ? (decisions + 15u) >> 4 : 1u; }
+
+// RowSrc: uint32_t rows()                      rows of this lane's code-block
+//         uint32_t wave_rows()                 the most rows any lane of the wave has (uniform)
+//         void load(uint32_t row, uint32_t w[4])
+// CtxMem: uint32_t ld(uint32_t h), void st(uint32_t h, uint32_t state) with a handle h = handle(ctx) (an address on the
+//         device), void words(uint32_t out[5]) - the 19 context states packed four per word
+// Sink:   void put(int index, uint32_t byte) (index -1 ignored; indices increase), void row_end() (a uniform point:
+//         buffered bytes may leave), void finish()
+// CkArray: store(p, s, a, c16, shifts, cx[5]) as for mq_encode_stream
+// Every lane of a wave runs this loop in lock-step over wave_rows() rows; lanes differ in what their rows hold, and
+// the only per-decision divergence left is the renormalisation's byte output.
+template <class RowSrc, class CtxMem, class Sink, class ByteAt, class CkArray, class Table = ConstTable2>
+T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink sink, ByteAt bytes, int *rates, CkArray &ck,
+                                  Table tab = Table())
+{
+    uint32_t a = 0x8000, c = 0, cur = 0, shifts = 0;
+    int ct = 12, n = -1;
+    for (int i = 0; i < NCTX; i++) cx.st(cx.handle((uint32_t) i), i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u)));
+    auto byteout = [&]() {
+        // C.2.7 without branches: a carry goes into the byte being held unless that byte is 0xFF; a byte that is
+        // (or becomes) 0xFF is followed by a 7-bit byte
+        const uint32_t carry = cur != 0xFFu ? (c >> 27) & 1u : 0u;
+        cur += carry;
+        c -= carry << 27;
+        const bool stuff = cur == 0xFFu;
+        sink.put(n, cur);
+        n++;
+        const int sh = stuff ? 20 : 19;
+        cur = (c >> sh) & 0xFFu;
+        c &= (1u << sh) - 1u;
+        ct = stuff ? 7 : 8;
+    };
+    const int npasses = P > 0 ? 3 * P - 2 : 0;
+    const uint32_t nrows = P > 0 ? src.rows() : 0u, wrows = src.wave_rows();
+    int pass = 0, stripe = 0;
+    uint32_t w[4] = {0, 0, 0, 0}, wn[4] = {0, 0, 0, 0};
+    if (wrows) src.load(0, w);
+    for (uint32_t row = 0; row < wrows; row++) {
+        if (row + 1 < wrows) src.load(row + 1, wn);                       // (in flight while this row is coded)
+        if (row < nrows) {
+            if (w[0] & kRowStart) {
+                if (stripe == 0 && pass > 0) rates[pass - 1] = (int) ((uint32_t) n + 3u);
+                uint32_t x[5];
+                cx.words(x);
+                ck.store(pass, stripe, a, c & 0xFFFFu, shifts, x);
+                if (++stripe == nstr) { stripe = 0; pass++; }
+            }
+            uint32_t v = w[0] & 0xFFu;
+            uint32_t h = cx.handle(v & 31u);
+            uint32_t st = cx.ld(h);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t vn = j < 15 ? (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : 0u;
+                const uint32_t hn = cx.handle(vn & 31u);
+                uint32_t stn = 0;
+                if (j < 15) stn = cx.ld(hn);                              // (issued before this decision's state store)
+                if (!(v & kRowPad)) {
+                    const uint32_t e = tab(st), qe = e & 0xFFFFu;
+                    const uint32_t lps = ((v >> 5) ^ (st >> 6)) & 1u;
+                    a -= qe;
+                    const bool small = (a & 0x8000u) == 0;
+                    const bool lower = (a < qe) != (lps != 0);            // which sub-interval the symbol is coded in
+                    if (lower) a = qe; else c += qe;
+                    const uint32_t ns = lps ? e >> 24 : (small ? (e >> 16) & 0xFFu : st);
+                    cx.st(h, ns);
+                    if (j < 15 && hn == h) stn = ns;                      // the next decision uses the same context
+                    int k = renorm_shifts(a);                             // 0 when bit 15 is set
+                    shifts += (uint32_t) k;
+                    if (k >= ct) {
+                        a <<= ct; c <<= ct; k -= ct; byteout();
+                        if (k >= ct) { a <<= ct; c <<= ct; k -= ct; byteout(); }       // (k <= 15: at most two bytes)
+                    }
+                    a <<= k; c <<= k; ct -= k;
+                }
+                v = vn; st = stn; h = hn;
+            }
+        }
+        sink.row_end();
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = wn[i];
+    }
+    if (npasses > 0) {                                                    // FLUSH (C.2.9)
+        const uint32_t tempc = c + a;
+        c |= 0xFFFFu;
+        if (c >= tempc) c -= 0x8000u;
+        c <<= ct; byteout();
+        c <<= ct; byteout();
+        sink.put(n, cur);
+        if (cur != 0xFFu) n++;
+        sink.finish();                                                    // (a buffering sink writes out its tail)
+        rates[npasses - 1] = n;
+        int last = n;
+        for (int q = npasses; q > 0;) {
+            --q;
+            if (rates[q] > last) rates[q] = last; else last = rates[q];
+        }
+        for (int q = 0; q < npasses; q++)
+            if (rates[q] > 0 && bytes(rates[q] - 1) == 0xFF) rates[q]--;
+    }
+    EncodeResult r;
+    r.totalpasses = npasses;
+    r.length = npasses > 0 ? n : 0;
     return r;
 }
 

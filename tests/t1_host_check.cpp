@@ -80,6 +80,39 @@ struct CkView {                   // CkArray over a plain [pass * nstr + stripe]
         ck[p * nstr + s] = MqCheckpoint{a, c16, 0, (int) shifts, c.w0, c.w1, c.w2};
     }
 };
+
+// ---- segmented encoder (scan_block / emit_stripe_segments / mq_encode_segments) ----
+struct HostMasks {                 // the encoder's masks of one code-block
+    std::vector<u64> bp, suf, visp;    // [plane][64], suf/visp with two spare planes
+    u64 sgn[64], sps[64];
+    int P;
+    u64 BP(int p, int y) { return p < P ? bp[(size_t) p * 64 + y] : 0; }
+    u64 SUF(int p, int y) { return suf[(size_t) p * 64 + y]; }
+    u64 SGN(int y) { return sgn[y]; }
+    u64 VISP(int p, int y) { return visp[(size_t) p * 64 + y]; }
+};
+struct ScanOut {
+    HostMasks *m; std::vector<uint32_t> *lens;
+    void visp(int p, int y, u64 v) { m->visp[(size_t) p * 64 + y] = v; }
+    void sps_or(int y, u64 v) { m->sps[y] |= v; }
+    void len(int seg, uint32_t n) { (*lens)[seg] = n; }
+};
+struct SegEm {
+    std::vector<std::vector<uint8_t>> *segs; int cur = -1;
+    void begin(int seg) { cur = seg; (*segs)[seg].clear(); }
+    void emit_if(bool on, uint32_t ctx, uint32_t d) { if (on) (*segs)[cur].push_back((uint8_t) (ctx | (d << 5))); }
+    void column_end() {}
+    void end() {}
+};
+struct RowSrcHost {               // one code-block's row stream (t1_core.hpp: row format)
+    const std::vector<uint32_t> *w;
+    uint32_t rows() const { return (uint32_t) (w->size() / 4); }
+    uint32_t wave_rows() const { return rows() + 3; }                     // (a wave runs as long as its longest lane: extra rows must be ignored)
+    void load(uint32_t row, uint32_t o[4]) const { for (int k = 0; k < 4; k++) o[k] = row < rows() ? (*w)[(size_t) row * 4 + k] : 0x12345678u; }
+};
+struct CtxBytes2 { uint8_t *b; uint32_t handle(uint32_t c) const { return c; } uint32_t ld(uint32_t h) const { return b[h]; } void st(uint32_t h, uint32_t v) { b[h] = (uint8_t) v; }
+                   void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= (uint32_t) b[i] << (8 * (i & 3)); } };
+struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end() {} void finish() {} };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
 int main(int argc, char **argv)
@@ -158,6 +191,75 @@ int main(int argc, char **argv)
                            k < em.n ? syms[k] : 0, k < em3.n ? syms3[k] : 0);
                     bad++; continue;
                 }
+            }
+            // ---- the segmented encoder: scan (masks + counts), per-stripe emission, uniform-segment MQ pass
+            {
+                HostMasks hm;
+                hm.P = numbps;
+                hm.bp = st.bp;
+                hm.suf.assign((size_t) (kSegPlanes + 2) * 64, 0);
+                hm.visp.assign((size_t) (kSegPlanes + 2) * 64, 0xDEADBEEFDEADBEEFull);      // (unwritten rows must never matter)
+                memcpy(hm.sgn, st.sgn, sizeof hm.sgn);
+                memset(hm.sps, 0, sizeof hm.sps);
+                for (int y = 0; y < 64; y++) { u64 acc = 0; for (int pl = numbps - 1; pl >= 0; pl--) { acc |= st.bp[(size_t) pl * 64 + y]; hm.suf[(size_t) pl * 64 + y] = acc; } }
+                std::vector<uint32_t> lens(kSegCount, 0xFFFFFFFFu);
+                ScanOut so{&hm, &lens};
+                scan_block(hm, so, numbps, w, h, orient);
+                bool okm = memcmp(hm.sps, st.sps, sizeof st.sps) == 0;
+                for (int pl = 0; okm && pl < numbps - 1; pl++)
+                    for (int yy = 0; yy < h; yy++) if (hm.visp[(size_t) pl * 64 + yy] != mobs.visp[pl][yy]) { okm = false; printf("trial %d scan visp plane %d row %d\n", t, pl, yy); break; }
+                // segments of the marker stream
+                std::vector<std::vector<uint8_t>> want(kSegCount);
+                {
+                    int pass = -1, stripe = 0, segi = -1;
+                    for (uint32_t i = 0; i < em.n; i++) {
+                        const uint8_t v = syms[i];
+                        if (v & kSymStripe) {
+                            if (v & kSymPass) { pass++; stripe = 0; } else stripe++;
+                            segi = seg_index(plane_of_pass(numbps, pass), type_of_pass(pass), stripe);
+                        } else want[segi].push_back(v);
+                    }
+                }
+                std::vector<std::vector<uint8_t>> got(kSegCount);
+                SegEm sem{&got};
+                for (int pl = numbps - 1; pl >= 0; pl--)
+                    for (int s_ = 0; s_ < nstr; s_++) emit_stripe_segments(hm, sem, numbps, pl, s_, w, h, orient);
+                for (int sg = 0; okm && sg < kSegCount; sg++) {
+                    const bool valid = seg_valid(numbps, nstr, seg_plane(sg), seg_type(sg), sg & 15);
+                    if (!valid) { if (!want[sg].empty() || !got[sg].empty()) { okm = false; printf("trial %d decisions in invalid segment %d\n", t, sg); } continue; }
+                    if (got[sg] != want[sg]) { okm = false; printf("trial %d segment %d (plane %d type %d stripe %d) differs: %zu vs %zu decisions\n", t, sg, seg_plane(sg), seg_type(sg), sg & 15, got[sg].size(), want[sg].size()); }
+                    else if (lens[sg] != want[sg].size()) { okm = false; printf("trial %d segment %d count %u vs %zu\n", t, sg, lens[sg], want[sg].size()); }
+                }
+                if (!okm) { printf("trial %d SEGMENTED EMISSION mismatch (w %d h %d orient %d P %d)\n", t, w, h, orient, numbps); bad++; continue; }
+                static MqCheckpoint ck3[120 * 16];
+                memset(ck3, 0, sizeof ck3);
+                CkView ckv3{ck3, nstr};
+                int rates3[kMaxPasses];
+                uint8_t ctxb3[32] = {0};
+                std::vector<uint8_t> bytes3;
+                std::vector<uint32_t> rowsw;                                // the segments as rows, in coding order
+                for (int sg = 0; sg < kSegCount; sg++) {
+                    if (!seg_valid(numbps, nstr, seg_plane(sg), seg_type(sg), sg & 15)) continue;
+                    const std::vector<uint8_t> &v = got[sg];
+                    const uint32_t nr = seg_rows((uint32_t) v.size());
+                    for (uint32_t rr = 0; rr < nr; rr++)
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t word = 0;
+                            for (int bb = 0; bb < 4; bb++) {
+                                const size_t i = (size_t) rr * 16 + k * 4 + bb;
+                                uint32_t byte = i < v.size() ? v[i] : kRowPad | (rng() & 0x3Fu);    // (padding carries arbitrary low bits)
+                                if (rr == 0 && k == 0 && bb == 0) byte |= kRowStart;
+                                word |= byte << (8 * bb);
+                            }
+                            rowsw.push_back(word);
+                        }
+                }
+                EncodeResult r3 = mq_encode_rows(RowSrcHost{&rowsw}, CtxBytes2{ctxb3}, numbps, nstr, VecSink3{&bytes3}, VecAt{&bytes3}, rates3, ckv3);
+                finalize_checkpoints(ckv3, r3.totalpasses, nstr, BufSrc{bytes3.data(), r3.length});
+                bool same = r3.totalpasses == r.totalpasses && r3.length == r.length && memcmp(bytes3.data(), bytes.data(), (size_t) r.length) == 0;
+                for (int p_ = 0; same && p_ < r.totalpasses; p_++) same = rates3[p_] == rates[p_];
+                for (int i = 0; same && i < r.totalpasses * nstr; i++) same = memcmp(&ck3[i], &eobs.ck[i], sizeof(MqCheckpoint)) == 0;
+                if (!same) { printf("trial %d SEGMENTED MQ mismatch (passes %d/%d len %d/%d)\n", t, r3.totalpasses, r.totalpasses, r3.length, r.length); bad++; continue; }
             }
             static MqCheckpoint ck2[120 * 16];
             CkView ckv2{ck2, nstr};

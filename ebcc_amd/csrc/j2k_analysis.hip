@@ -797,7 +797,7 @@ struct SegEmDev {
             for (int d = 0; d < 4; d++) {
                 const int nv = min(max((int) keep - 4 * d, 0), 4);
                 const uint32_t m = nv ? 0xFFFFFFFFu >> (32 - 8 * nv) : 0u;
-                w[d] = (w[d] & m) | (0x80808080u & ~m);
+                w[d] = (w[d] & m) | ((t1::kRowPad * 0x01010101u) & ~m);
             }
         }
         if (fl == 0) w[0] |= t1::kRowStart;
@@ -834,32 +834,46 @@ __global__ __launch_bounds__(64) void k_t1_emit(const unsigned long long *BP, co
 
 // ---- arithmetic coding of the row streams: one wave per group, a code-block per lane (t1::mq_encode_rows)
 struct LdsTable2 {
-    const __attribute__((address_space(3))) uint32_t *t;
-    __device__ uint32_t operator()(uint32_t st7) const { return t[st7]; }
+    // t1::mq_entry2 for every state code, 8 bytes per entry; the code IS the entry's byte offset
+    uint32_t base;                 // LDS byte address of the table
+    __device__ void operator()(uint32_t code, uint32_t &qe, uint32_t &next) const
+    {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 e = *(const __attribute__((address_space(3))) u32x2 *) (uintptr_t) (base + code);
+        qe = e.x; next = e.y;
+    }
 };
+// The rows come through LDS: the workgroup's second wave (the loader) copies them from HBM kRowChunk rows at a time
+// into one half of a double buffer while the coder wave works on the other, with a workgroup barrier per chunk.  The
+// coder wave therefore never waits for vector memory: its own global accesses are stores only (checkpoints, bytes,
+// rates), and on gfx9 a load's data would wait for every older store of the wave (one counter, in issue order).
+constexpr int kRowChunk = 8;
 struct RowSrcDev {
-    const uint8_t *sym;            // the group's rows + lane * 16
+    uint32_t buf;                  // LDS byte address of this lane's 16 bytes of row 0 of buffer 0 (row stride 1 KB, buffers kRowChunk KB apart)
     uint32_t n, wn;                // rows of this lane, of the longest lane of the wave
     __device__ uint32_t rows() const { return n; }
     __device__ uint32_t wave_rows() const { return wn; }
+    __device__ void sync(uint32_t row) const { if (row % kRowChunk == 0) __syncthreads(); }
     __device__ void load(uint32_t row, uint32_t w[4]) const
     {
-        const uint4 v = *(const uint4 *) (sym + (size_t) row * 1024);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *) (uintptr_t) (buf + (row % (2 * kRowChunk)) * 1024u);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     }
+    __device__ bool any(bool b) const { return __any(b) != 0; }
 };
 struct CtxLds2 {
-    // the context states of every lane, a dword each (state in its low byte): context c of lane l at (c * 64 + l) * 4,
+    // the state codes of every lane, a dword slot each (code in its low half): context c of lane l at (c * 64 + l) * 4,
     // so a handle - the byte address - is one shift-add away from the decision byte and the bank is the lane
     uint32_t base;                 // LDS byte address of this lane's context 0
     __device__ uint32_t handle(uint32_t c) const { return base + (c << 8); }
-    __device__ uint32_t ld(uint32_t h) const { return *(const __attribute__((address_space(3))) unsigned char *) (uintptr_t) h; }
-    __device__ void st(uint32_t h, uint32_t v) { *(__attribute__((address_space(3))) unsigned char *) (uintptr_t) h = (unsigned char) v; }
+    __device__ uint32_t ld(uint32_t h) const { return *(const __attribute__((address_space(3))) unsigned short *) (uintptr_t) h; }
+    __device__ void st(uint32_t h, uint32_t v) { *(__attribute__((address_space(3))) unsigned short *) (uintptr_t) h = (unsigned short) v; }
     __device__ void words(uint32_t x[5]) const
     {
         for (int j = 0; j < 5; j++) {
             uint32_t v = 0;
-            for (int k = 0; k < 4; k++) if (4 * j + k < t1::NCTX) v |= ld(handle((uint32_t) (4 * j + k))) << (8 * k);
+            for (int k = 0; k < 4; k++) if (4 * j + k < t1::NCTX) v |= t1::mq_code_state(ld(handle((uint32_t) (4 * j + k)))) << (8 * k);
             x[j] = v;
         }
     }
@@ -869,51 +883,65 @@ struct MqSinkLds {
     // conflict) and leave as aligned 8-byte words at the uniform points of the loop (every 16 decisions)
     unsigned char *ring;           // LDS, this lane's 64 bytes
     uint8_t *out; int *overflow;
-    int top = 0, fl = 0;           // bytes put so far, bytes written out (multiple of 8)
-    __device__ void put(int i, uint32_t b)
-    {
-        ring[(uint32_t) i & 63u] = (unsigned char) b;                    // (i == -1 lands in byte 63 and is overwritten later)
-        top = i + 1;
-    }
+    int fl = 0;                    // bytes written out (multiple of 8)
+    __device__ void put(int i, uint32_t b) { ring[(uint32_t) i & 63u] = (unsigned char) b; }    // (i == -1 lands in byte 63 and is overwritten later)
     __device__ void word()
     {
         const uint32_t *q = (const uint32_t *) (ring + ((uint32_t) fl & 63u));
         if (fl + 8 <= kJ2kCblkBytes) *(uint2 *) (out + fl) = make_uint2(q[0], q[1]); else *overflow = 1;
         fl += 8;
     }
-    __device__ void row_end() { while (fl + 8 <= top) word(); }
-    __device__ void finish() { row_end(); if (fl < top) word(); }
+    __device__ void row_end(int n) { while (fl + 8 <= n) word(); }
+    __device__ void finish(int n) { row_end(n); if (fl < n) word(); }
 };
 
-__global__ __launch_bounds__(64) void k_t1_mqrows(const uint8_t *SYM, const uint32_t *lanerows, const int *blkmax, int *cblk_len,
-                                                   int *rates, uint8_t *cblk_bytes, void *ckpt, const J2kGeom *geom,
-                                                   const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows)
+__global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uint32_t *lanerows, const int *blkmax, int *cblk_len,
+                                                    int *rates, uint8_t *cblk_bytes, void *ckpt, const J2kGeom *geom,
+                                                    const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows)
 {
-    __shared__ uint32_t tab_store[128];
+    __shared__ uint2 tab_store[128];
     __shared__ uint32_t ctxw[32 * 64];
     __shared__ uint32_t bring[17 * 64];
-    tab_store[threadIdx.x] = t1::mq_entry2((int) threadIdx.x);
-    tab_store[threadIdx.x + 64] = t1::mq_entry2((int) threadIdx.x + 64);
-    __syncthreads();
-    const LdsTable2 tab{(const __attribute__((address_space(3))) uint32_t *) tab_store};
+    __shared__ uint4 rowbuf[2 * kRowChunk * 64];
+    const int lane = (int) threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
+    for (int i = (int) threadIdx.x; i < 128; i += 128) { uint32_t qe, nx; t1::mq_entry2(i, qe, nx); tab_store[i] = make_uint2(qe, nx); }
+    const LdsTable2 tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
     const size_t grp = blockIdx.x;
-    const int gid = (int) (grp * 64) + (int) threadIdx.x;
+    const int gid = (int) (grp * 64) + lane;
     const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
     uint32_t nrows = l.live ? lanerows[gid] : 0u;
     if (nrows > sym_rows) nrows = 0;                                     // (overflow: the host retries, see k_t1_rowoffs)
     uint32_t wrows = nrows;
     for (int d = 32; d >= 1; d >>= 1) wrows = max(wrows, (uint32_t) __shfl_xor((int) wrows, d));
-    wrows = (uint32_t) __builtin_amdgcn_readfirstlane((int) wrows);
+    wrows = (uint32_t) __builtin_amdgcn_readfirstlane((int) wrows);      // (both waves of the workgroup compute the same value)
     if (wrows == 0) return;
+    const uint8_t *sym = SYM + grp * (size_t) sym_rows * 1024 + (size_t) lane * 16u;
+    if (loader) {
+        // chunk q of the rows goes to buffer q & 1 and is handed over at barrier number q (RowSrcDev::sync at row q * kRowChunk)
+        const uint32_t nchunks = (wrows + kRowChunk - 1) / kRowChunk;
+        for (uint32_t q = 0; q < nchunks; q++) {
+            uint4 v[kRowChunk];
+#pragma unroll
+            for (int i = 0; i < kRowChunk; i++) {
+                const uint32_t row = q * kRowChunk + (uint32_t) i;
+                v[i] = row < wrows ? *(const uint4 *) (sym + (size_t) row * 1024) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < kRowChunk; i++) rowbuf[((q & 1u) * kRowChunk + (uint32_t) i) * 64 + (uint32_t) lane] = v[i];
+            __syncthreads();
+        }
+        return;
+    }
     // (lanes without a code-block run along with no rows: nothing is coded or stored for them)
     const bool on = nrows > 0;
     uint8_t *out = cblk_bytes + (size_t) (on ? gid : 0) * kJ2kCblkBytes;
-    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, threadIdx.x * 8u};
-    RowSrcDev src{SYM + grp * (size_t) sym_rows * 1024 + threadIdx.x * 16u, nrows, wrows};
+    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, (uint32_t) lane * 8u};
+    RowSrcDev src{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint4 *) rowbuf + (uint32_t) lane * 16u, nrows, wrows};
     const int P = on ? l.P : 0, nstr = (l.h + 3) >> 2;
-    const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + threadIdx.x * 4u;
+    const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + (uint32_t) lane * 4u;
     t1::EncodeResult r = t1::mq_encode_rows(src, CtxLds2{ctx_base}, P, nstr,
-                                            MqSinkLds{(unsigned char *) bring + threadIdx.x * 68u, out, &jf[l.frame].overflow},
+                                            MqSinkLds{(unsigned char *) bring + lane * 68, out, &jf[l.frame].overflow},
                                             DevAt{out, kJ2kCblkBytes}, rates + (size_t) (on ? gid : 0) * kJ2kMaxPasses, ck, tab);
     if (P <= 0) return;
     cblk_len[gid] = r.length;
@@ -1069,7 +1097,7 @@ void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool si
                     sum / (double) total, wsum / (double) groups, mx, jb.sym_rows);
         }
         timing_begin("t1_mq", s);
-        hipLaunchKernelGGL(k_t1_mqrows, dim3((unsigned) groups), dim3(64), 0, s, jb.SYM, jb.lanerows, jb.blkmax, jb.cblk_len, jb.rates,
+        hipLaunchKernelGGL(k_t1_mqrows, dim3((unsigned) groups), dim3(128), 0, s, jb.SYM, jb.lanerows, jb.blkmax, jb.cblk_len, jb.rates,
                            jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, (uint32_t) jb.sym_rows);
         timing_end("t1_mq", s);
     }

@@ -1361,44 +1361,60 @@ T1_HD void emit_stripe_segments(Masks &M, Em &em, int P, int p, int s, int w, in
     em.end();
 }
 
-// MQ state table of the segment coder: indexed by the whole context byte (6-bit state | mps << 6), an entry
-// holds Qe and BOTH successor bytes, so a symbol costs one table read and no sense/switch arithmetic:
-//     qe | (nmps | mps << 6) << 16 | (nlps | (mps ^ switch) << 6) << 24
-T1_HD uint32_t mq_entry2(int st7)
+// MQ state table of the row coder.  A context's state is kept as the CODE 8 * (6-bit state | mps << 6) - the byte
+// offset of its entry in a table of 8-byte entries - and an entry holds Qe and BOTH successor codes, so a decision
+// costs one table read, no sense/switch arithmetic and no address arithmetic:
+//     word 0: qe     word 1: code(nmps, mps) | code(nlps, mps ^ switch) << 16
+// Code kNullCode (state 47, unused by T.800) has Qe = 0 and itself as successor: coding its more probable symbol
+// leaves every register of the coder unchanged.  Padding bytes of a row are decisions "0 in context kCtxNull",
+// whose state is kNullCode for ever - so the coder needs no test for padding at all.
+constexpr uint32_t kNullCode = 8u * 47u;
+constexpr uint32_t kCtxNull = 19;
+T1_HD uint32_t mq_code(uint32_t st7) { return st7 << 3; }
+T1_HD uint32_t mq_code_state(uint32_t code) { return code >> 3; }
+T1_HD void mq_entry2(int st7, uint32_t &qe, uint32_t &next)
 {
     const int i = st7 & 63, mps = st7 >> 6;
-    const uint32_t e = mq_entry(i < 47 ? i : 46);
+    if (i >= 47) { qe = 0; next = kNullCode | (kNullCode << 16); return; }
+    const uint32_t e = mq_entry(i);
     const uint32_t nm = ((e >> 16) & 0x3Fu) | ((uint32_t) mps << 6), nl = ((e >> 22) & 0x3Fu) | (((uint32_t) mps ^ (e >> 28)) << 6);
-    return (e & 0xFFFFu) | (nm << 16) | (nl << 24);
+    qe = e & 0xFFFFu;
+    next = mq_code(nm) | (mq_code(nl) << 16);
 }
 struct ConstTable2 {
-    T1_HD uint32_t operator()(uint32_t st7) const { return mq_entry2((int) st7); }
+    T1_HD void operator()(uint32_t code, uint32_t &qe, uint32_t &next) const { mq_entry2((int) mq_code_state(code), qe, next); }
 };
 
 // Row format of the decision streams: a code-block's decisions, segment after segment in coding order, in ROWS of
 // 16 bytes; every segment starts a new row (at least one, even when it has no decision), so a row never straddles
-// two segments.  Byte = context | bit << 5; bit 7 set = padding (no decision); bit 6 of byte 0 set = first row of a
-// segment (the coder checkpoints there and, at the first stripe of a pass, closes the previous pass).
-constexpr uint32_t kRowPad = 0x80u, kRowStart = 0x40u;
+// two segments.  Byte = context | bit << 5; padding = kRowPad (context kCtxNull, bit 0: a no-op for the coder, see
+// above); bit 6 of byte 0 set = first row of a segment (the coder checkpoints there and, at the first stripe of a
+// pass, closes the previous pass).
+constexpr uint32_t kRowPad = 0x80u | kCtxNull, kRowStart = 0x40u;
 T1_HD uint32_t seg_rows(uint32_t decisions) { return decisions ? (decisions + 15u) >> 4 : 1u; }
 
 // RowSrc: uint32_t rows()                      rows of this lane's code-block
 //         uint32_t wave_rows()                 the most rows any lane of the wave has (uniform)
+//         void sync(uint32_t row)              called by every lane before row `row` is loaded (a uniform point)
 //         void load(uint32_t row, uint32_t w[4])
-// CtxMem: uint32_t ld(uint32_t h), void st(uint32_t h, uint32_t state) with a handle h = handle(ctx) (an address on the
-//         device), void words(uint32_t out[5]) - the 19 context states packed four per word
-// Sink:   void put(int index, uint32_t byte) (index -1 ignored; indices increase), void row_end() (a uniform point:
-//         buffered bytes may leave), void finish()
+//         bool any(bool)                       true if the argument is true for any lane of the wave
+// CtxMem: uint32_t handle(uint32_t ctx) (an address on the device), uint32_t ld(handle) / void st(handle, code): the state
+//         codes (contexts 0 .. 31; 19 is the null context), void words(uint32_t out[5]): the 19 context states as
+//         bytes (state | mps << 6), four per word - the checkpoint format
+// Sink:   void put(int index, uint32_t byte) (index -1 ignored; an index may be written again until a higher one
+//         has been), void row_end(int n) (a uniform point: bytes below n are final and may leave), void finish(int n)
 // CkArray: store(p, s, a, c16, shifts, cx[5]) as for mq_encode_stream
-// Every lane of a wave runs this loop in lock-step over wave_rows() rows; lanes differ in what their rows hold, and
-// the only per-decision divergence left is the renormalisation's byte output.
+// Every lane of a wave runs this loop in lock-step over wave_rows() rows; lanes differ in what their rows hold.  A
+// row is straight-line code: MPS/LPS, renormalisation and the first output byte of a decision are selects, only a
+// second output byte (a renormalisation of 8+ bits across a byte boundary) takes a branch.
 template <class RowSrc, class CtxMem, class Sink, class ByteAt, class CkArray, class Table = ConstTable2>
 T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink sink, ByteAt bytes, int *rates, CkArray &ck,
                                   Table tab = Table())
 {
     uint32_t a = 0x8000, c = 0, cur = 0, shifts = 0;
     int ct = 12, n = -1;
-    for (int i = 0; i < NCTX; i++) cx.st(cx.handle((uint32_t) i), i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u)));
+    for (uint32_t i = 0; i < 32; i++)
+        cx.st(cx.handle(i), i >= (uint32_t) NCTX ? kNullCode : mq_code(i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u))));
     auto byteout = [&]() {
         // C.2.7 without branches: a carry goes into the byte being held unless that byte is 0xFF; a byte that is
         // (or becomes) 0xFF is followed by a 7-bit byte
@@ -1416,11 +1432,11 @@ T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink s
     const int npasses = P > 0 ? 3 * P - 2 : 0;
     const uint32_t nrows = P > 0 ? src.rows() : 0u, wrows = src.wave_rows();
     int pass = 0, stripe = 0;
-    uint32_t w[4] = {0, 0, 0, 0}, wn[4] = {0, 0, 0, 0};
-    if (wrows) src.load(0, w);
     for (uint32_t row = 0; row < wrows; row++) {
-        if (row + 1 < wrows) src.load(row + 1, wn);                       // (in flight while this row is coded)
+        src.sync(row);                                                    // (uniform: the device source swaps its staging buffers here)
         if (row < nrows) {
+            uint32_t w[4];
+            src.load(row, w);
             if (w[0] & kRowStart) {
                 if (stripe == 0 && pass > 0) rates[pass - 1] = (int) ((uint32_t) n + 3u);
                 uint32_t x[5];
@@ -1428,39 +1444,63 @@ T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink s
                 ck.store(pass, stripe, a, c & 0xFFFFu, shifts, x);
                 if (++stripe == nstr) { stripe = 0; pass++; }
             }
-            uint32_t v = w[0] & 0xFFu;
-            uint32_t h = cx.handle(v & 31u);
-            uint32_t st = cx.ld(h);
+            // Two dependency chains per decision: the INTERVAL chain (context state -> table entry -> A -> shift count;
+            // one table read long) and the CODE chain (C register, down-counter, output bytes; needs only the addend
+            // and the shift count of its decision).  The code chain of decision j - 1 is placed between the table
+            // read of decision j and its first use, so a lone wave has work while the read is in flight.
+            uint32_t h = cx.handle(w[0] & 31u);
+            uint32_t code = cx.ld(h);
+            uint32_t add = 0;                                             // addend and shift count of the decision whose code chain is due
+            int k = 0;
+            auto code_chain = [&]() {
+                c += add;
+                const bool need = k >= ct;                                // a byte leaves when the down-counter runs out (selects, no branch)
+                const int sh1 = need ? ct : k;
+                int k2 = k - sh1;
+                c <<= sh1;
+                const uint32_t carry = (need && cur != 0xFFu) ? (c >> 27) & 1u : 0u;
+                const uint32_t curc = cur + carry;
+                c -= carry << 27;
+                const bool stuff = curc == 0xFFu;
+                sink.put(n, curc);                                        // (written again later unless `need`)
+                n += need ? 1 : 0;
+                const int shn = stuff ? 20 : 19;
+                cur = need ? (c >> shn) & 0xFFu : cur;
+                c = need ? c & ((1u << shn) - 1u) : c;
+                ct = need ? (stuff ? 7 : 8) : ct - sh1;
+                if (src.any(k2 >= ct)) {                                  // rare: a second byte (k <= 15: never a third)
+                    if (k2 >= ct) { c <<= ct; k2 -= ct; byteout(); }
+                }
+                c <<= k2; ct -= k2;
+            };
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const uint32_t vn = j < 15 ? (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : 0u;
-                const uint32_t hn = cx.handle(vn & 31u);
-                uint32_t stn = 0;
-                if (j < 15) stn = cx.ld(hn);                              // (issued before this decision's state store)
-                if (!(v & kRowPad)) {
-                    const uint32_t e = tab(st), qe = e & 0xFFFFu;
-                    const uint32_t lps = ((v >> 5) ^ (st >> 6)) & 1u;
-                    a -= qe;
-                    const bool small = (a & 0x8000u) == 0;
-                    const bool lower = (a < qe) != (lps != 0);            // which sub-interval the symbol is coded in
-                    if (lower) a = qe; else c += qe;
-                    const uint32_t ns = lps ? e >> 24 : (small ? (e >> 16) & 0xFFu : st);
-                    cx.st(h, ns);
-                    if (j < 15 && hn == h) stn = ns;                      // the next decision uses the same context
-                    int k = renorm_shifts(a);                             // 0 when bit 15 is set
-                    shifts += (uint32_t) k;
-                    if (k >= ct) {
-                        a <<= ct; c <<= ct; k -= ct; byteout();
-                        if (k >= ct) { a <<= ct; c <<= ct; k -= ct; byteout(); }       // (k <= 15: at most two bytes)
-                    }
-                    a <<= k; c <<= k; ct -= k;
+                const uint32_t wj = w[j >> 2] >> (8 * (j & 3));           // this decision's byte in bits 0..7
+                uint32_t qe, nxt;
+                tab(code, qe, nxt);
+                uint32_t hn = 0, coden = 0;
+                if (j < 15) {
+                    hn = cx.handle((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31u);
+                    coden = cx.ld(hn);                                    // (issued before this decision's state store)
                 }
-                v = vn; st = stn; h = hn;
+                if (j > 0) code_chain();                                  // decision j - 1
+                const bool lps = (((wj << 4) ^ code) & 0x200u) != 0;      // decision bit (bit 5) against the mps (bit 9 of the code)
+                a -= qe;
+                const bool small = a < 0x8000u;
+                const bool lower = (a < qe) != lps;                       // which sub-interval the symbol is coded in
+                add = lower ? 0u : qe;
+                a = lower ? qe : a;
+                const uint32_t ncode = lps ? nxt >> 16 : (small ? nxt & 0xFFFFu : code);
+                cx.st(h, ncode);
+                if (j < 15 && hn == h) coden = ncode;                     // the next decision uses the same context
+                k = renorm_shifts(a);                                     // 0 when bit 15 is set
+                shifts += (uint32_t) k;
+                a <<= k;
+                h = hn; code = coden;
             }
+            code_chain();                                                 // decision 15
         }
-        sink.row_end();
-#pragma unroll
-        for (int i = 0; i < 4; i++) w[i] = wn[i];
+        sink.row_end(n);
     }
     if (npasses > 0) {                                                    // FLUSH (C.2.9)
         const uint32_t tempc = c + a;
@@ -1470,7 +1510,7 @@ T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink s
         c <<= ct; byteout();
         sink.put(n, cur);
         if (cur != 0xFFu) n++;
-        sink.finish();                                                    // (a buffering sink writes out its tail)
+        sink.finish(n);                                                   // (a buffering sink writes out its tail)
         rates[npasses - 1] = n;
         int last = n;
         for (int q = npasses; q > 0;) {

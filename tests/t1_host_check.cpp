@@ -109,10 +109,12 @@ struct RowSrcHost {               // one code-block's row stream (t1_core.hpp: r
     uint32_t rows() const { return (uint32_t) (w->size() / 4); }
     uint32_t wave_rows() const { return rows() + 3; }                     // (a wave runs as long as its longest lane: extra rows must be ignored)
     void load(uint32_t row, uint32_t o[4]) const { for (int k = 0; k < 4; k++) o[k] = row < rows() ? (*w)[(size_t) row * 4 + k] : 0x12345678u; }
+    bool any(bool b) const { return b; }
+    void sync(uint32_t) const {}
 };
-struct CtxBytes2 { uint8_t *b; uint32_t handle(uint32_t c) const { return c; } uint32_t ld(uint32_t h) const { return b[h]; } void st(uint32_t h, uint32_t v) { b[h] = (uint8_t) v; }
-                   void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= (uint32_t) b[i] << (8 * (i & 3)); } };
-struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end() {} void finish() {} };
+struct CtxCodes { uint16_t *b; uint32_t handle(uint32_t c) const { return c; } uint32_t ld(uint32_t h) const { return b[h]; } void st(uint32_t h, uint32_t v) { b[h] = (uint16_t) v; }
+                  void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= mq_code_state(b[i]) << (8 * (i & 3)); } };
+struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end(int) {} void finish(int n) { v->resize((size_t) n); } };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 
 int main(int argc, char **argv)
@@ -235,7 +237,7 @@ int main(int argc, char **argv)
                 memset(ck3, 0, sizeof ck3);
                 CkView ckv3{ck3, nstr};
                 int rates3[kMaxPasses];
-                uint8_t ctxb3[32] = {0};
+                uint16_t ctxb3[32] = {0};
                 std::vector<uint8_t> bytes3;
                 std::vector<uint32_t> rowsw;                                // the segments as rows, in coding order
                 for (int sg = 0; sg < kSegCount; sg++) {
@@ -247,14 +249,14 @@ int main(int argc, char **argv)
                             uint32_t word = 0;
                             for (int bb = 0; bb < 4; bb++) {
                                 const size_t i = (size_t) rr * 16 + k * 4 + bb;
-                                uint32_t byte = i < v.size() ? v[i] : kRowPad | (rng() & 0x3Fu);    // (padding carries arbitrary low bits)
+                                uint32_t byte = i < v.size() ? v[i] : kRowPad;
                                 if (rr == 0 && k == 0 && bb == 0) byte |= kRowStart;
                                 word |= byte << (8 * bb);
                             }
                             rowsw.push_back(word);
                         }
                 }
-                EncodeResult r3 = mq_encode_rows(RowSrcHost{&rowsw}, CtxBytes2{ctxb3}, numbps, nstr, VecSink3{&bytes3}, VecAt{&bytes3}, rates3, ckv3);
+                EncodeResult r3 = mq_encode_rows(RowSrcHost{&rowsw}, CtxCodes{ctxb3}, numbps, nstr, VecSink3{&bytes3}, VecAt{&bytes3}, rates3, ckv3);
                 finalize_checkpoints(ckv3, r3.totalpasses, nstr, BufSrc{bytes3.data(), r3.length});
                 bool same = r3.totalpasses == r.totalpasses && r3.length == r.length && memcmp(bytes3.data(), bytes.data(), (size_t) r.length) == 0;
                 for (int p_ = 0; same && p_ < r.totalpasses; p_++) same = rates3[p_] == rates[p_];

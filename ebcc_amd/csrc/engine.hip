@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/ebcc_hip.h"
+#include "search.hpp"
 
 namespace ebcc {
 
@@ -251,6 +252,8 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 4 * max_frames)) != nullptr;
+    ok &= (ctx->d_search = ctx_alloc<uint8_t>(ctx, sizeof(DevChunk) * max_frames)) != nullptr;
+    ok &= (ctx->d_counter = (int *) ctx_alloc<uint32_t>(ctx, 4)) != nullptr;
     if (ok) {
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64a, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64b, max_frames * sizeof(unsigned long long)));
@@ -259,6 +262,8 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 4 * max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_act, 2 * max_frames * sizeof(int)));
+        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, sizeof(DevChunk) * max_frames));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_counter, 4 * sizeof(int)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
     }
@@ -288,6 +293,8 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_fs) hipHostFree(ctx->h_fs);
     if (ctx->h_pack) hipHostFree(ctx->h_pack);
     if (ctx->h_act) hipHostFree(ctx->h_act);
+    if (ctx->h_search) hipHostFree(ctx->h_search);
+    if (ctx->h_counter) hipHostFree(ctx->h_counter);
     if (ctx->h_jf) hipHostFree(ctx->h_jf);
     if (ctx->h_table) hipHostFree(ctx->h_table);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);

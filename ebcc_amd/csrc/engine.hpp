@@ -27,6 +27,8 @@ struct ebcc_hip_ctx {
     void *h_jf = nullptr;                  // [max_frames] J2kFrame (j2k.hpp)
     int *h_act = nullptr;                  // [2 * max_frames]: probe mask, residual mask
     int *h_table = nullptr;                // [max_frames * code-block slots * 4] decode tables (lazily sized by j2k_create)
+    void *d_search = nullptr, *h_search = nullptr;   // [max_frames] DevChunk: state of the device-driven searches (search.hpp), pinned mirror
+    int *d_counter = nullptr, *h_counter = nullptr;  // [4] small device counters and their pinned mirror
     std::vector<void *> allocs;
     void *j2k = nullptr;                   // base-layer state (j2k.hpp)
     hipStream_t stream2 = nullptr;          // second stream of the engine (decode: residual layer beside the base layer)

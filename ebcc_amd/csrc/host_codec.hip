@@ -27,6 +27,7 @@
 #include "../../include/ebcc_hip.h"
 #include "engine.hpp"
 #include "j2k.hpp"
+#include "search.hpp"
 
 namespace ebcc {
 bool j2k_parse_codestream(const uint8_t *cs, size_t n, const J2kGeom &g, int *table);
@@ -479,6 +480,77 @@ void run_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
     }
 }
 
+// The same search with its state machine on the device (search.hpp): the rounds are enqueued back to back - advance,
+// rate allocation, probe decode - without a host synchronisation in between; the host looks at the states once after
+// `rounds` of them (EBCC_HIP_SEARCH_ROUNDS, default 16: more than the usual search needs) and only enqueues more if a
+// chunk is still searching.  Same probes, same decisions, same result as run_search (EBCC_HIP_HOST_SEARCH=1 selects that).
+int search_rounds()
+{
+    if (const char *e = getenv("EBCC_HIP_SEARCH_ROUNDS")) return std::max(1, atoi(e));
+    return 16;
+}
+template <class Jobs>
+void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
+{
+    ebcc_hip_ctx *ctx = b.ctx;
+    const size_t n = b.n;
+    DevChunk *h = static_cast<DevChunk *>(ctx->h_search), *d = static_cast<DevChunk *>(ctx->d_search);
+    hipStream_t s = b.s;
+    for (size_t f = 0; f < n; f++) {
+        const Job &j = jobs[f];
+        DevChunk &c = h[f];
+        c.const_field = j.const_field ? 1 : 0;
+        c.state_cr = b.state_cr[f];
+        c.q = j.q;
+        c.n_probes = (int) std::min<size_t>(j.probes.size(), kMaxProbes);
+        for (int i = 0; i < c.n_probes; i++) c.probes[i] = DevProbe{j.probes[i].cr, j.probes[i].stream_bytes, j.probes[i].nbad, j.probes[i].err_sum};
+        const RateSearch &r = j.rs[k];
+        DevRateSearch &o = c.rs[k];
+        o.lo = r.lo; o.hi = r.hi; o.cr = r.cr; o.result = r.result; o.pending = r.pending; o.phase = j.const_field ? 6 : r.phase;
+        o.q = r.q; o.q0 = r.q0; o.qt = r.qt; o.want = 0; o.want_cr = 0;
+        o.last = DevProbe{j.last[k].cr, j.last[k].stream_bytes, j.last[k].nbad, j.last[k].err_sum};
+    }
+    EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, s));
+    EBCC_HIP_CHECK(hipMemsetAsync(ctx->d_counter, 0, sizeof(int) * 4, s));
+    int rounds = search_rounds();
+    for (;;) {
+        for (int r = 0; r < rounds; r++) {
+            launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
+            launch_j2k_rate(b.jb, (int) b.nt, b.d_active, s);
+            launch_j2k_probe_decode(b.d_frames, b.jb, (int) b.nt, b.d_active, s, k == 0);     // (search 1 uses the statistics only: the field of search 0 stays)
+        }
+        launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
+        EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        bool done = true;
+        for (size_t f = 0; f < n; f++) done &= h[f].rs[k].phase == 6;
+        if (done) break;
+        rounds = 6;
+    }
+    log_trace("rate search %d: %d probes of chunks over the rounds", k, ctx->h_counter[0]);
+    for (size_t f = 0; f < n; f++) {
+        Job &j = jobs[f];
+        if (j.const_field) continue;
+        const DevChunk &c = h[f];
+        const DevRateSearch &o = c.rs[k];
+        RateSearch &r = j.rs[k];
+        r.lo = o.lo; r.hi = o.hi; r.cr = o.cr; r.result = o.result; r.pending = o.pending; r.phase = 4; r.q = o.q; r.q0 = o.q0; r.qt = o.qt;
+        j.last[k] = ProbeRec{o.last.cr, o.last.nbad, o.last.stream_bytes, o.last.err_sum};
+        if (k == 0) j.q = c.q;
+        j.probes.clear();
+        for (int i = 0; i < c.n_probes; i++) j.probes.push_back(ProbeRec{c.probes[i].cr, c.probes[i].nbad, c.probes[i].stream_bytes, c.probes[i].err_sum});
+        b.state_cr[f] = c.state_cr;
+    }
+    b.fetch_jf();                                                         // (the host mirror of the per-frame scalars follows the device again)
+}
+template <class Jobs>
+void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
+{
+    static const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
+    if (host_loop) run_search(b, k, jobs, n_pix); else device_rate_search(b, k, jobs, n_pix);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ebcc_encode for a batch of device-resident single-frame chunks.  Returns 0, 1 (error) or 2 (NaN/Inf).
 // ------------------------------------------------------------------------------------------------
@@ -584,7 +656,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         const bool want_pure = !pure_done && !env.no_fallback;
         for (size_t f = 0; f < n; f++)
             if (!jobs[f].const_field) jobs[f].rs[0].start(cfg->base_cr, jobs[f].q, q_target);
-        run_search(b, 0, jobs, n_pix);
+        rate_search(b, 0, jobs, n_pix);
         for (size_t f = 0; f < n; f++) {
             b.active[f] = jobs[f].const_field ? 0 : 1;
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
@@ -649,7 +721,43 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                     j.trunc_active = true;
                 }
             }
-            // ---- truncation bisection (:777-795): all frames advance one probe per round
+            // ---- truncation bisection (:777-795): all frames advance one cut per round
+            static const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
+            if (!host_loop) {
+                // state machine on the device (search.hpp): advance, reconstruct the decoder state at the cut, synthesis +
+                // statistics - enqueued back to back, one look at the states after `rounds` of them
+                DevChunk *h = static_cast<DevChunk *>(rc->h_search), *d = static_cast<DevChunk *>(rc->d_search);
+                for (size_t f = 0; f < n; f++) {
+                    const Job &j = jobs[f];
+                    DevChunk &c = h[f];
+                    c.t_hi = j.t_hi; c.t_lo = j.t_lo; c.t_best = j.t_best; c.mean_err = j.mean_err; c.best_err = j.best_err;
+                    c.target = j.target; c.trunc_active = j.trunc_active ? 1 : 0; c.trunc_pending = 0;
+                }
+                EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, rs));
+                EBCC_HIP_CHECK(hipMemsetAsync(rc->d_counter, 0, sizeof(int) * 4, rs));
+                int rounds = std::max(search_rounds(), 18);
+                for (;;) {
+                    for (int r = 0; r < rounds; r++) {
+                        launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
+                        launch_reconstruct(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
+                        launch_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+                    }
+                    launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
+                    EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
+                    EBCC_HIP_CHECK(hipStreamSynchronize(rs));
+                    bool done = true;
+                    for (size_t f = 0; f < n; f++) done &= !h[f].trunc_active;
+                    if (done) break;
+                    rounds = 6;
+                }
+                for (size_t f = 0; f < n; f++) {
+                    Job &j = jobs[f];
+                    if (!j.trunc_active) continue;
+                    const DevChunk &c = h[f];
+                    j.t_hi = c.t_hi; j.t_lo = c.t_lo; j.t_best = c.t_best; j.mean_err = c.mean_err; j.best_err = c.best_err;
+                    j.trunc_active = false;
+                }
+            } else
             for (;;) {
                 const double eps = 1e-8;
                 bool any = false;
@@ -730,7 +838,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 if (env.no_consistency) jobs[f].rs[1].start(jobs[f].cr, jobs[f].q, 1.0);      // from search #1's state
                 else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);                 // :829-833 == the first probe
             }
-            run_search(b, 1, jobs, n_pix);                                                    // :836
+            rate_search(b, 1, jobs, n_pix);                                                   // :836
             zjoin();
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {

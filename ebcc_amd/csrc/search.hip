@@ -1,0 +1,142 @@
+// search.hip - device-side state machines of the rate search and the truncation bisection (search.hpp).
+#include "search.hpp"
+
+namespace ebcc {
+namespace {
+
+constexpr int kMainHeaderBytes = 135;      // SOC, SIZ, COD, QCD, COM of every codestream the codec writes
+
+// ---- /root/reference/src/ebcc_codec.c:545-596, one probe per call --------------------------------------
+// returns true and sets `out` if a probe at rate `out` is needed next
+__device__ bool rs_next(DevRateSearch &r, float &out)
+{
+    for (;;) {
+        if (r.phase == 0) {
+            if (r.q < r.qt && r.lo >= 1. / 2) { r.lo /= 2; out = r.pending = r.lo; return true; }          // :559-563
+            r.q = r.q0; r.phase = 1;
+        } else if (r.phase == 1) {
+            if (r.q >= r.qt && r.hi <= 1000) { r.hi *= 2; out = r.pending = r.hi; return true; }           // :565-569
+            if (r.q >= r.qt) { r.result = r.hi; r.phase = 4; return false; }                             // :571-574
+            r.q = r.q0; r.phase = 2;
+        } else if (r.phase == 2) {
+            const double eps = 1e-8;
+            if ((fabs(r.q - r.qt) > eps || r.q == 1.0) && r.hi - r.lo > 1.) {                             // :579-588
+                r.cr = (r.lo + r.hi) / 2; out = r.pending = r.cr; return true;
+            }
+            r.phase = 3; out = r.pending = r.lo; return true;                                             // :590
+        } else {
+            return false;
+        }
+    }
+}
+__device__ void rs_feed(DevRateSearch &r, double quantile)
+{
+    r.q = quantile;
+    if (r.phase == 2) { if (r.q < r.qt) r.hi = r.cr; else r.lo = r.cr; }
+    else if (r.phase == 3) { r.result = r.lo; r.phase = 4; }
+}
+__device__ const DevProbe *find_probe(const DevChunk &c, float cr)
+{
+    for (int i = 0; i < c.n_probes; i++) if (c.probes[i].cr == cr) return &c.probes[i];
+    return nullptr;
+}
+
+__global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, int n_chunks, int tiles, int k, double n_pix,
+                                 int *unfinished)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= n_chunks) return;
+    DevChunk &C = chunks[ci];
+    DevRateSearch &R = C.rs[k];
+    const int t0 = ci * tiles;
+    auto set_active = [&](int v) { for (int t = 0; t < tiles; t++) active[t0 + t] = v; };
+    if (C.const_field || R.phase == 6) { set_active(0); return; }
+    auto feed = [&](const DevProbe &rec) {
+        if (R.phase == 3) R.last = rec;
+        const double q = 1. - ((double) rec.nbad / n_pix);                                                // :512
+        if (k == 0) C.q = q;
+        rs_feed(R, q);
+    };
+    if (R.want) {                                                        // the probe asked for in the previous round
+        DevProbe rec{jf[t0].cr, 0, 0ull, 0.0};
+        int body = 0;
+        for (int t = 0; t < tiles; t++) { rec.nbad += jf[t0 + t].nbad; rec.err_sum += jf[t0 + t].err_sum; body += jf[t0 + t].body_bytes; }
+        rec.stream_bytes = kMainHeaderBytes + tiles * 14 + body + 2;     // main header, SOT + SOD per tile, EOC
+        if (k == 0) C.state_cr = rec.cr;                                 // (search 0's probes leave their decode in the engine)
+        if (!find_probe(C, rec.cr) && C.n_probes < kMaxProbes) C.probes[C.n_probes++] = rec;
+        R.want = 0;
+        if (R.phase == 5) { R.last = rec; R.phase = 6; set_active(0); return; }
+        feed(rec);
+    }
+    // walk through the probes already on record (the other search, or the first encode, usually made them).  The
+    // final probe of search 0 (:590) must leave its decode in the engine - the residual layer is computed from it -
+    // so it is made again unless the engine's last decode of the chunk was at exactly that rate.
+    while (!R.want && R.phase < 4) {
+        float cr;
+        if (!rs_next(R, cr)) break;
+        const DevProbe *rec = find_probe(C, cr);
+        const bool needs_state = k == 0 && R.phase == 3 && C.state_cr != cr;
+        if (rec && !needs_state) feed(*rec);
+        else { R.want = 1; R.want_cr = cr; }
+    }
+    if (!R.want && R.phase == 4) {
+        // a search that leaves through the rate > 1000 exit (:571-574) makes no final probe: its result is the last
+        // doubling step; for search 0 that step's decode has to be in the engine
+        if (R.last.cr != R.result) { const DevProbe *rec = find_probe(C, R.result); if (rec) R.last = *rec; }
+        if (k == 0 && C.state_cr != R.result) { R.want = 1; R.want_cr = R.result; R.phase = 5; }
+        else R.phase = 6;
+    }
+    set_active(R.want);
+    if (R.want) {
+        for (int t = 0; t < tiles; t++) jf[t0 + t].cr = R.want_cr;
+        atomicAdd(unfinished, 1);
+    }
+}
+
+// ---- :765-796 ------------------------------------------------------------------------------------------
+__global__ void k_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *active, int n_chunks,
+                                double n_pix, int *unfinished)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_chunks) return;
+    DevChunk &C = chunks[f];
+    if (!C.trunc_active) { active[f] = 0; return; }
+    if (C.trunc_pending) {
+        const double tb = (double) trunc_bits[f];
+        const float cur = __uint_as_float(fs[f].maxerr_bits);
+        if (cur > C.target) C.t_lo = tb;
+        else {
+            C.t_hi = tb;
+            if (cur >= C.best_err) { C.best_err = cur; C.t_best = tb; C.mean_err = fs[f].err_sum / n_pix; }
+        }
+        C.trunc_pending = 0;
+    }
+    const double eps = 1e-8;
+    if (((C.target - C.best_err) / C.target > eps) && (C.t_hi - C.t_lo > 8 * 4)) {
+        trunc_bits[f] = (unsigned long long) ceil((C.t_hi + C.t_lo) / 2 / 8) * 8ull;
+        C.trunc_pending = 1;
+        active[f] = 1;
+        atomicAdd(unfinished, 1);
+    } else {
+        C.trunc_active = 0;
+        active[f] = 0;
+    }
+}
+
+}  // namespace
+
+void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_chunks, int tiles, int k, double n_pix,
+                           int *unfinished, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_search_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, jf, d_active, n_chunks, tiles, k, n_pix,
+                       unfinished);
+}
+
+void launch_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
+                          double n_pix, int *unfinished, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trunc_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, fs, trunc_bits, d_active, n_chunks, n_pix,
+                       unfinished);
+}
+
+}  // namespace ebcc

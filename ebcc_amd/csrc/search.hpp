@@ -1,0 +1,61 @@
+// search.hpp - the reference's two search loops with their state on the device.
+//   * rate search (/root/reference/src/ebcc_codec.c:545-596, called at :728 and :836): halve / double / bisect the
+//     JPEG 2000 rate until the fraction of samples within the error target crosses the wanted quantile;
+//   * truncation bisection of the SPIHT stream (:765-796).
+// The decision sequence is the reference's, evaluated unchanged (same float / double expressions in the same
+// order); what moves is where it runs: a one-thread-per-chunk kernel reads the statistics the previous probe left on
+// the device, advances the state machine and writes the next rate (or cut point) and the active mask, so a whole
+// search is enqueued as a fixed number of rounds without the host in the loop (host_codec.hip: device_rate_search,
+// device_truncation).  Rounds in which no chunk is active cost their launches only - every probe kernel returns at
+// once for inactive frames.
+#pragma once
+
+#include "j2k.hpp"
+
+namespace ebcc {
+
+struct DevProbe {                  // outcome of the base layer coded at one rate (a function of (chunk, rate) only)
+    float cr;
+    int stream_bytes;
+    unsigned long long nbad;       // count(|x - d| > target)
+    double err_sum;                // sum(x - d)
+};
+
+// :545-596 as a resumable state machine (phases 0-4 as in the reference's three loops and final encode)
+struct DevRateSearch {
+    float lo, hi, cr, result, pending;
+    int phase;                     // 0 halving, 1 doubling, 2 bisect, 3 final probe, 4 search done, 5 its decode is being restored, 6 finished
+    double q, q0, qt;
+    int want;                      // waits for the probe at want_cr
+    float want_cr;
+    DevProbe last;                 // the probe the result rests on
+};
+
+constexpr int kMaxProbes = 64;     // probes on record per chunk (both searches share them); further ones are simply made again
+
+struct DevChunk {                  // per chunk (= frame, or the frames coded as the tiles of one image)
+    DevRateSearch rs[2];           // [0] error-bounded search (:728), [1] pure base layer (:836)
+    float state_cr;                // rate of the decode the engine holds for this chunk (-1: none)
+    int n_probes;
+    int const_field;
+    int pad0;
+    double q;                      // quantile of the last probe search 0 looked at
+    DevProbe probes[kMaxProbes];
+    // truncation bisection (:765-796)
+    double t_hi, t_lo, t_best, mean_err;
+    float best_err, target;
+    int trunc_active, trunc_pending;
+};
+
+// One round of rate search k for every chunk: take in the probe made for it in the previous round (if any), walk the
+// state machine through probes already on record, and either ask for the next probe (jf[tile].cr, active[tile] = 1)
+// or finish.  `unfinished` (device int) is incremented by every chunk that still wants a probe.
+void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_chunks, int tiles, int k, double n_pix,
+                           int *unfinished, hipStream_t s);
+
+// One round of the truncation bisection: take in the statistics of the cut made in the previous round, choose the next
+// cut (trunc_bits[f], active[f] = 1) or finish.
+void launch_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
+                          double n_pix, int *unfinished, hipStream_t s);
+
+}  // namespace ebcc

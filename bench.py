@@ -32,31 +32,39 @@ FRAME_BYTES = H * W * 4
 BASE_CR, MAX_ERR = 30.0, 0.5
 
 
-def synth_frames(torch, n, device, seed):
-    """SURVEY.md section 8(d) generator on the device: k^-1.5 spectrum noise on a zonal profile."""
+def synth_frames(torch, n, device, seed, slope=1.5, amp=2.5, ramp=None):
+    """SURVEY.md section 8(d) generator on the device: k^-slope spectrum noise (amplitude amp) on a zonal profile;
+    ramp = (a, b): frame i's noise amplitude and profile swing are scaled by a + (b - a) * i / (n - 1), so that the
+    frames' ranges differ (config 3: RELATIVE_ERROR targets follow the per-frame range)."""
     g = torch.Generator(device=device)
     g.manual_seed(1234 + seed)
     ky = torch.fft.fftfreq(H, device=device)[:, None]
     kx = torch.fft.rfftfreq(W, device=device)[None, :]
     k = torch.sqrt(ky * ky + kx * kx)
     k[0, 0] = 1
-    filt = k ** (-1.5)
+    filt = k ** (-slope)
     filt[0, 0] = 0
     lat = torch.linspace(-1, 1, H, device=device)[:, None]
-    prof = 235 + 50 * torch.cos(lat * torch.pi / 2)
+    swing = 50 * torch.cos(lat * torch.pi / 2)
+    prof = 235 + swing
     out = torch.empty((n, H, W), dtype=torch.float32, device=device)
     for i in range(0, n, 32):
         m = min(32, n - i)
         noise = torch.randn((m, H, W), generator=g, device=device, dtype=torch.float32)
         f = torch.fft.irfft2(torch.fft.rfft2(noise) * filt, s=(H, W))
         f = f / f.std(dim=(1, 2), keepdim=True)
-        out[i:i + m] = (prof + 2.5 * f).to(torch.float32)
+        if ramp is None:
+            out[i:i + m] = (prof + amp * f).to(torch.float32)
+        else:
+            idx = torch.arange(i, i + m, device=device, dtype=torch.float32) / max(1, n - 1)
+            scale = (ramp[0] + (ramp[1] - ramp[0]) * idx)[:, None, None]
+            out[i:i + m] = (235 + scale * (swing + amp * f)).to(torch.float32)
     return out.contiguous()
 
 
 def cpu_baseline(sample, cores):
     """Reference CPU codec (oracle/_ref = reference sources + OpenJPEG 2.4.0/zstd) or, if that build cannot
-    be loaded, the oracle port; one process per core, one frame each."""
+    be loaded, the oracle port; one process per core, two frames each, median per-frame times."""
     import multiprocessing as mp
     from tests import _lib as L
     kind = "reference" if os.path.exists(L.REF_SO) else "port"
@@ -65,15 +73,16 @@ def cpu_baseline(sample, cores):
             ctypes.CDLL(L.REF_SO)
     except OSError:
         kind = "port"
-    frames = [np.ascontiguousarray(sample[i % len(sample)]) for i in range(cores)]
+    frames = [np.ascontiguousarray(sample[i % len(sample)]) for i in range(2 * cores)]
     t0 = time.time()
     with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_one, [(kind, f) for f in frames])
+        res = pool.map(_cpu_one, [(kind, f) for f in frames], chunksize=2)
     wall = time.time() - t0
-    enc = float(np.mean([r[0] for r in res]))
-    dec = float(np.mean([r[1] for r in res]))
+    enc = float(np.median([r[0] for r in res]))
+    dec = float(np.median([r[1] for r in res]))
     return {"value": round(len(frames) * FRAME_BYTES / wall / 1e9, 6), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": f"{len(frames)} frames 721x1440, one per process, encode+decode; mean {enc:.2f}s enc / {dec:.3f}s dec per frame",
+            "sample": f"{len(frames)} frames 721x1440 (base_cr 30, MAX_ERROR 0.5), two per process on {cores} processes, encode+decode; "
+                      f"median {enc:.2f}s enc / {dec:.3f}s dec per frame, {wall:.1f}s wall",
             "encode_MBps_per_core": round(FRAME_BYTES / enc / 1e6, 3), "decode_MBps_per_core": round(FRAME_BYTES / dec / 1e6, 2)}
 
 
@@ -112,6 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (config3, residual population, host API)")
     args = ap.parse_args()
 
     import torch
@@ -186,32 +196,133 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    def run_batches(data, cfg_, reps=1):
+        """encode + decode of `data` ((m, H, W) on the device) through the engine in batches of n frames; returns
+        (encode s, decode s, compressed bytes, frames that keep a residual layer, max abs error)."""
+        m = data.shape[0]
+        dec = torch.empty_like(data[:n])
+        te = td = 0.0
+        nbytes = resid = 0
+        worst = 0.0
+        for _ in range(reps):
+            nbytes = resid = 0
+            for lo in range(0, m, n):
+                k = min(n, m - lo)
+                part = data[lo:lo + k]
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                assert lib.ebcc_hip_encode_frames(ctx, part.data_ptr(), k, ctypes.byref(cfg_), outs, sizes) == 0, lib.ebcc_hip_last_error()
+                t1_ = time.perf_counter()
+                assert lib.ebcc_hip_decode_frames(ctx, outs, sizes, k, dec.data_ptr()) == 0, lib.ebcc_hip_last_error()
+                torch.cuda.synchronize()
+                t2_ = time.perf_counter()
+                te += t1_ - t0_
+                td += t2_ - t1_
+                for i in range(k):
+                    nbytes += sizes[i]
+                    resid += int.from_bytes(ctypes.string_at(outs[i] + 16, 8), "little") > 0        # header: coeffs_size
+                    lib.free_buffer(outs[i])
+                worst = max(worst, float((dec[:k] - part).abs().amax()))
+        return te / reps, td / reps, nbytes, resid, worst
+
+    def extra_workloads():
+        """Measured in the same run (N = 1 only): the other single-GPU populations of SURVEY section 8(d) and the
+        reference's own host-pointer entry points."""
+        ex = {}
+        # ---- BASELINE configs[2] on a bounded sample: RELATIVE_ERROR 1e-3, per-frame amplitude ramp, 512 frames in
+        #      batches of the engine's capacity (what EBCC_HIP_MAX_BATCH does behind the host-pointer API)
+        m3 = 512 if n >= 256 else 2 * n
+        data = synth_frames(torch, m3, device, seed=77, ramp=(0.25, 1.75))
+        cfg3 = L.make_config((1, H, W), base_cr=BASE_CR, error=1e-3, residual_type=L.RELATIVE_ERROR)
+        run_batches(data[:n], cfg3)                                               # (warm-up)
+        te, td, nb, resid, worst = run_batches(data, cfg3)
+        rng_ = (data.amax(dim=(1, 2)) - data.amin(dim=(1, 2)))
+        ex["config3"] = {"workload": f"{m3} frames 721x1440, base_cr=30 RELATIVE_ERROR=1e-3, amplitude ramp 0.25..1.75, batches of {n}",
+                         "value": round(m3 * FRAME_BYTES / (te + td) / 1e9, 4), "unit": "GB/s",
+                         "encode_GBps": round(m3 * FRAME_BYTES / te / 1e9, 4), "decode_GBps": round(m3 * FRAME_BYTES / td / 1e9, 4),
+                         "compressed_bytes_per_frame": int(nb / m3), "frames_with_residual_layer": round(resid / m3, 4),
+                         "max_error_over_range": round(float(worst / rng_.amin()), 6)}
+        del data
+        # ---- the population that keeps the residual layer (slope 1.0, amp 0.7)
+        mr = min(n, 128)
+        data = synth_frames(torch, mr, device, seed=99, slope=1.0, amp=0.7)
+        run_batches(data[:min(mr, 32)], cfg)
+        te, td, nb, resid, worst = run_batches(data, cfg)
+        ex["residual_population"] = {"workload": f"{mr} frames 721x1440 (spectrum slope 1.0, amplitude 0.7), base_cr=30 MAX_ERROR=0.5",
+                                     "value": round(mr * FRAME_BYTES / (te + td) / 1e9, 4), "unit": "GB/s",
+                                     "encode_GBps": round(mr * FRAME_BYTES / te / 1e9, 4), "decode_GBps": round(mr * FRAME_BYTES / td / 1e9, 4),
+                                     "compressed_bytes_per_frame": int(nb / mr), "frames_with_residual_layer": round(resid / mr, 4),
+                                     "max_abs_error": round(worst, 5)}
+        del data
+        # ---- the reference's host-pointer API: pageable host array in, EBCK container in host memory out (PCIe inclusive)
+        host = frames.cpu().numpy()
+        ccfg = L.make_config((n, H, W), (1, H, W), base_cr=BASE_CR, error=MAX_ERR, residual_type=L.MAX_ERROR)
+        lib.ebcc_encode_chunking.restype = ctypes.c_size_t
+        lib.ebcc_encode_chunking.argtypes = [ctypes.c_void_p, ctypes.POINTER(L.CodecConfig), L.c_void_pp]
+        lib.ebcc_decode_chunking.restype = ctypes.c_size_t
+        lib.ebcc_decode_chunking.argtypes = [ctypes.c_void_p, ctypes.c_size_t, L.c_void_pp]
+        best = None
+        for rep in range(2):                                                      # (the first pass creates the API's own engines)
+            o = ctypes.c_void_p()
+            t0_ = time.perf_counter()
+            nb = lib.ebcc_encode_chunking(host.ctypes.data, ctypes.byref(ccfg), ctypes.byref(o))
+            t1_ = time.perf_counter()
+            assert nb > 0
+            d = ctypes.c_void_p()
+            m = lib.ebcc_decode_chunking(o, nb, ctypes.byref(d))
+            t2_ = time.perf_counter()
+            assert m == n * H * W
+            back = np.ctypeslib.as_array(ctypes.cast(d, ctypes.POINTER(ctypes.c_float)), shape=(n, H, W))
+            err = float(np.abs(back[::17] - host[::17]).max())
+            lib.free_buffer(o)
+            lib.free_buffer(d)
+            best = (t1_ - t0_, t2_ - t1_, nb, err)
+        te, td, nb, err = best
+        ex["host_api"] = {"workload": f"ebcc_encode_chunking / ebcc_decode_chunking on a pageable host array of {n}x721x1440 fp32, one frame per chunk",
+                          "encode_GBps": round(n * FRAME_BYTES / te / 1e9, 4), "decode_GBps": round(n * FRAME_BYTES / td / 1e9, 4),
+                          "round_trip_GBps": round(n * FRAME_BYTES / (te + td) / 1e9, 4), "container_bytes": int(nb), "max_abs_error": round(err, 5)}
+        return ex
+
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = extra_workloads()
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         total_frames = n * world
         value = total_frames * FRAME_BYTES / (elapsed / args.steps) / 1e9
         # dominant kernel by total time: tier-1 coding of every code-block (HIP events recorded on the launching
-        # stream of each slice engine around both of its phases)
+        # stream of each slice engine around its kernels)
         tms, launches = ctypes.c_double(), ctypes.c_long()
         lib.ebcc_hip_timing_read(ctx, b"t1_encode", ctypes.byref(tms), ctypes.byref(launches))
         kern = {}
-        for name in (b"t1_encode", b"t1_symbols", b"t1_mq", b"t1_probe_decode", b"rate_alloc", b"j2k_dwt_fwd", b"spiht_encode", b"t1_decode"):
+        for name in (b"t1_encode", b"t1_symbols", b"t1_mq", b"t1_probe_decode", b"rate_alloc", b"j2k_dwt_fwd", b"spiht_encode", b"t1_decode", b"spiht_decode"):
             a, c = ctypes.c_double(), ctypes.c_long()
             lib.ebcc_hip_timing_read(ctx, name, ctypes.byref(a), ctypes.byref(c))
             if c.value:
                 kern[name.decode()] = {"ms_avg": round(a.value / c.value, 4), "launches": c.value}
+
+        def kernel_sources_sha():
+            import hashlib
+            hsh = hashlib.sha256()
+            for f in ("j2k_analysis.hip", "t1_core.hpp"):
+                hsh.update(open(os.path.join(ROOT, "ebcc_amd", "csrc", f), "rb").read())
+            return hsh.hexdigest()[:16]
+
         def pmc_traffic(frames_per_launch):
-            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r01_pmc_*.json,
+            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r02_pmc_tier1.json,
             tools/gpu/profile.sh: separate FETCH_SIZE and WRITE_SIZE runs of `--frames 64` on one slice = 64 frames per
-            dispatch).  gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB."""
+            dispatch; gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB).  The file names
+            the kernel sources it was taken with; a file that predates the last change to them gives no figure."""
             try:
-                fj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
-                wj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write_size.json")))
-                f, w, per = fj["kernels"], wj["kernels"], float(fj.get("frames_per_dispatch") or 32)
-                per_frame = sum(2.0 * f[k]["per_dispatch"] + w[k]["per_dispatch"] for k in ("k_t1_symbols", "k_t1_mq")) * 1024.0 / per
-                return int(per_frame * frames_per_launch)
-            except Exception:
-                return None
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_tier1.json")))
+                if pj.get("kernel_sources_sha") != kernel_sources_sha():
+                    return None, "profiles/r02_pmc_tier1.json predates the current tier-1 kernel sources"
+                per = float(pj["frames_per_dispatch"])
+                per_frame = sum(2.0 * pj["fetch_kb"][k] + pj["write_kb"][k] for k in pj["kernels"]) * 1024.0 / per
+                return int(per_frame * frames_per_launch), "profiles/r02_pmc_tier1.json@" + pj["kernel_sources_sha"]
+            except Exception as e:
+                return None, "no usable PMC file: " + repr(e)
 
         roof = None
         if launches.value:
@@ -220,9 +331,12 @@ def main():
             # each with its own launch)
             algo = (n * FRAME_BYTES + comp) * args.steps / launches.value
             ach = algo / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "tier-1 encoder (k_t1_symbols + k_t1_mq)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 6), "traffic": pmc_traffic(n * args.steps / launches.value), "avg_launch_ms": round(avg_s * 1e3, 4),
-                    "algorithmic_bytes_per_launch": algo}
+            traffic, tsrc = pmc_traffic(n * args.steps / launches.value)
+            roof = {"bound": "hbm", "kernel": "tier-1 encoder (k_t1_scan + k_t1_rowoffs + k_t1_emit + k_t1_mqrows)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "algorithmic_bytes_per_launch": algo, "frames_per_launch": n * args.steps / launches.value}
+        slices = int(os.environ.get("EBCC_HIP_SLICES", "4" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "2"))
+        lib.ebcc_hip_host_threads.restype = ctypes.c_int
         line = {
             "metric": "fp32 GB/s encode+decode, 721x1440 ERA5 frames MAX_ERROR=0.5",
             "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,15 +345,26 @@ def main():
             "config": {"workload": f"{n}-frame batch 721x1440 fp32 per GPU, base_cr=30 MAX_ERROR=0.5 (BASELINE configs[1])",
                        "frames_per_gpu": n, "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "encode_slices": int(os.environ.get("EBCC_HIP_SLICES", "4" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "2"))},
+                       "encode_slices": slices, "host_zstd_threads_per_slice": lib.ebcc_hip_host_threads(slices),
+                       "host_cpus": len(os.sched_getaffinity(0))},
             "encode_GBps": round(total_frames * FRAME_BYTES * args.steps / enc_t / 1e9, 4),
             "decode_GBps": round(total_frames * FRAME_BYTES * args.steps / dec_t / 1e9, 4),
             "compressed_bytes_per_frame": int(comp / n), "max_abs_error": round(max_err, 5),
             "kernels": kern, "roofline": roof,
         }
+        try:                                                    # HBM-bound kernels, measured alone (tools/gpu/hbm_table.sh): best and worst of the table
+            hk = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_kernels.json")))
+            rows = [r for r in hk["kernels"] if r.get("frac_of_6290") is not None]
+            if rows:
+                line["hbm_kernels"] = {"source": "profiles/r02_hbm_kernels.json@" + hk.get("kernel_sources_sha", "?"),
+                                       "best": max(rows, key=lambda r: r["frac_of_6290"]), "worst": min(rows, key=lambda r: r["frac_of_6290"])}
+        except Exception:
+            pass
+        if extras:
+            line.update(extras)
         if not args.no_cpu_baseline:
             try:
-                cores = min(16, os.cpu_count() or 1)
+                cores = min(16, len(os.sched_getaffinity(0)))
                 line["cpu_baseline"] = cpu_baseline(frames[:4].cpu().numpy(), cores)
             except Exception as e:                              # the baseline is a report, never a gate
                 line["cpu_baseline"] = {"error": repr(e)}

@@ -7,18 +7,41 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 
 namespace ebcc {
 
+// A failed HIP call on the host side throws; every extern "C" entry point catches at the boundary, reports through
+// set_error / the reference's log_fatal and returns its error value (0 bytes / 0 floats / non-zero status) - the
+// library never takes the host application down for a failed allocation or copy (reference convention:
+// /root/reference/src/ebcc_codec.c:613-617,1230-1257 log and return 0).
+struct HipFailure : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+[[noreturn]] inline void hip_fail(const char *what, const char *file, int line, hipError_t e)
+{
+    char buf[384];
+    std::snprintf(buf, sizeof buf, "%s failed at %s:%d: %s", what, file, line, hipGetErrorString(e));
+    throw HipFailure(buf);
+}
 #define EBCC_HIP_CHECK(expr)                                                                    \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess) {                                                                 \
-            std::fprintf(stderr, "ebcc-hip: %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, \
-                         hipGetErrorString(e_));                                                \
-            std::abort();                                                                       \
-        }                                                                                       \
+        if (e_ != hipSuccess) ::ebcc::hip_fail(#expr, __FILE__, __LINE__, e_);                  \
     } while (0)
+// after a group of kernel launches: a launch that the runtime refused (bad configuration, no resources) shows here,
+// not at some later synchronisation
+#define EBCC_HIP_LAUNCH_CHECK() EBCC_HIP_CHECK(hipGetLastError())
+// Every extern "C" function body sits between these two: `ret` is the function's error value.
+#define EBCC_API_TRY try {
+#define EBCC_API_CATCH(ret)                                                                     \
+    } catch (const std::exception &e_) { ::ebcc::set_error("%s", e_.what()); return ret; }
+#define EBCC_API_CATCH_VOID                                                                     \
+    } catch (const std::exception &e_) { ::ebcc::set_error("%s", e_.what()); }
+
+void set_error(const char *fmt, ...);
+// hipMalloc through one door: EBCC_HIP_FAIL_ALLOC=<n> (tests) makes the n-th allocation of the process fail
+hipError_t device_malloc(void **p, size_t bytes);
 
 constexpr int kWave = 64;             // CDNA wavefront
 constexpr int kResidualStages = 3;    // WAVELET_LEVELS, reference src/ebcc_codec.c:28

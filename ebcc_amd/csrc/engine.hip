@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <mutex>
 #include <string>
@@ -25,13 +26,21 @@ void set_error(const char *fmt, ...)
     std::fprintf(stderr, "ebcc-hip: %s\n", buf);
 }
 
+hipError_t device_malloc(void **p, size_t bytes)
+{
+    static const long fail_at = getenv("EBCC_HIP_FAIL_ALLOC") ? strtol(getenv("EBCC_HIP_FAIL_ALLOC"), nullptr, 10) : 0;
+    static std::atomic<long> count{0};
+    if (fail_at > 0 && ++count == fail_at) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+
 template <typename T>
 T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count)
 {
     void *p = nullptr;
     size_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = sizeof(T);
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = device_malloc(&p, bytes);
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return nullptr;
@@ -79,7 +88,7 @@ size_t stage_layout(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n)
         if (ctx->d_stage) EBCC_HIP_CHECK(hipFree(ctx->d_stage));
         ctx->stage_cap = total + total / 2 + 4096;
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_stage, ctx->stage_cap));
-        EBCC_HIP_CHECK(hipMalloc((void **) &ctx->d_stage, ctx->stage_cap));
+        EBCC_HIP_CHECK(device_malloc((void **) &ctx->d_stage, ctx->stage_cap));
     }
     return total;
 }
@@ -176,6 +185,7 @@ void ebcc_hip_timing_enable(ebcc_hip_ctx *ctx, int on)
 
 int ebcc_hip_timing_read(ebcc_hip_ctx *ctx, const char *name, double *total_ms, long *launches)
 {
+    EBCC_API_TRY
     if (ctx) EBCC_HIP_CHECK(hipDeviceSynchronize());
     double tot = 0;
     long n = 0;
@@ -187,6 +197,7 @@ int ebcc_hip_timing_read(ebcc_hip_ctx *ctx, const char *name, double *total_ms, 
     *total_ms = tot;
     *launches = n;
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 int ebcc_hip_device_count(void)
@@ -205,6 +216,7 @@ ebcc_hip_ctx *ebcc_hip_create(int device, size_t max_frames, size_t height, size
 
 ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, size_t width, int tile_period)
 {
+    EBCC_API_TRY
     if (height < 1 || width < 1 || height > 2047 || width > 2047 || max_frames < 1 || tile_period < 1 ||
         (tile_period > 1 && (size_t) tile_period * height > 2047)) {
         set_error("ebcc_hip_create: unsupported geometry %zu x %zu x %zu", max_frames, height, width);
@@ -273,12 +285,14 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     }
     EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return ctx;
+    EBCC_API_CATCH(nullptr)
 }
 
 extern "C" {
 
 void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
 {
+    EBCC_API_TRY
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
@@ -299,10 +313,12 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_table) hipHostFree(ctx->h_table);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->d_stage) hipFree(ctx->d_stage);
+    if (ctx->d_io) hipFree(ctx->d_io);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    EBCC_API_CATCH_VOID
 }
 
 void *ebcc_hip_stream(ebcc_hip_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
@@ -312,7 +328,7 @@ size_t ebcc_hip_padded_pixels(const ebcc_hip_ctx *ctx) { return ctx ? ctx->rb.np
 void *ebcc_hip_malloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    if (device_malloc(&p, bytes ? bytes : 1) != hipSuccess) {
         set_error("ebcc_hip_malloc(%zu) failed", bytes);
         return nullptr;
     }
@@ -370,6 +386,7 @@ static int collect_streams(ebcc_hip_ctx *ctx, size_t n, uint8_t **out_streams, s
 int ebcc_hip_spiht_encode(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, const size_t *trunc_bits,
                           uint8_t **out_streams, size_t *out_sizes)
 {
+    EBCC_API_TRY
     if (check_batch(ctx, n_frames, "ebcc_hip_spiht_encode")) return 1;
     for (size_t f = 0; f < n_frames; f++) {
         // reference buffer is trunc_bits + 1 bytes (spiht_re.c:433); our device slot holds height*width*4
@@ -383,10 +400,12 @@ int ebcc_hip_spiht_encode(ebcc_hip_ctx *ctx, const float *d_images, size_t n_fra
     launch_analysis(ctx->rb, (int) n_frames, nullptr, s);
     run_spiht_encode(ctx, n_frames, trunc_bits);
     return collect_streams(ctx, n_frames, out_streams, out_sizes);
+    EBCC_API_CATCH(1)
 }
 
 int ebcc_hip_spiht_coeffs(ebcc_hip_ctx *ctx, const float *d_images, size_t n_frames, int32_t *coeffs, int *dc)
 {
+    EBCC_API_TRY
     if (check_batch(ctx, n_frames, "ebcc_hip_spiht_coeffs")) return 1;
     hipStream_t s = ctx->stream;
     launch_pad_and_dc_from_image(d_images, ctx->rb, (int) n_frames, s);
@@ -395,10 +414,12 @@ int ebcc_hip_spiht_coeffs(ebcc_hip_ctx *ctx, const float *d_images, size_t n_fra
     fetch_frame_states(ctx, n_frames);
     for (size_t f = 0; f < n_frames; f++) dc[f] = (int) ctx->h_fs[f].dc;
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 int ebcc_hip_spiht_decode_prefix(ebcc_hip_ctx *ctx, size_t n_frames, const size_t *trunc_bits, float *d_images_out)
 {
+    EBCC_API_TRY
     if (check_batch(ctx, n_frames, "ebcc_hip_spiht_decode_prefix")) return 1;
     hipStream_t s = ctx->stream;
     fetch_frame_states(ctx, n_frames);
@@ -414,10 +435,13 @@ int ebcc_hip_spiht_decode_prefix(ebcc_hip_ctx *ctx, size_t n_frames, const size_
     launch_emit_image(d_images_out, ctx->rb, (int) n_frames, s);
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 // parse + validate the 15-byte IMS header on the host (spiht_re.c:480-503)
-static int check_ims_header(ebcc_hip_ctx *ctx, const uint8_t *b, size_t n, size_t num_bits)
+}  // extern "C"
+// header of a SPIHT stream against the context's grid, and a bit budget the decoder can work with (non-zero: reject)
+int ebcc::check_ims_header(ebcc_hip_ctx *ctx, const uint8_t *b, size_t n, size_t num_bits)
 {
     if (n < 15 || b[0] != 'I' || b[1] != 'M' || b[2] != 'S') { set_error("SPIHT stream: bad magic"); return 1; }
     unsigned long long hi = 0;
@@ -437,10 +461,12 @@ static int check_ims_header(ebcc_hip_ctx *ctx, const uint8_t *b, size_t n, size_
     if (nb <= 128) { set_error("SPIHT stream: num_bits must exceed 128"); return 1; }
     return 0;
 }
+extern "C" {
 
 int ebcc_hip_spiht_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes,
                           const size_t *num_bits, size_t n_frames, float *d_images_out)
 {
+    EBCC_API_TRY
     if (check_batch(ctx, n_frames, "ebcc_hip_spiht_decode")) return 1;
     hipStream_t s = ctx->stream;
     const size_t slot = ctx->rb.stream_words * 4;
@@ -458,6 +484,7 @@ int ebcc_hip_spiht_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, cons
     launch_emit_image(d_images_out, ctx->rb, (int) n_frames, s);
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 }  // extern "C"

@@ -40,6 +40,9 @@ struct ebcc_hip_ctx {
     // into one device buffer and cross PCIe as one copy into / out of one pinned buffer (engine.hip: stage_*).
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
+    // device image of the host arrays the reference-compatible entry points are handed (kept between calls)
+    float *d_io = nullptr;
+    size_t io_cap = 0;                      // bytes
     unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 pieces per frame][offset, length]
 };
 
@@ -60,6 +63,9 @@ void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const 
 void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m);
 void stage_send(ebcc_hip_ctx *ctx, size_t m, hipStream_t s);
 void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first, size_t count, hipStream_t s);
+
+// header of a SPIHT stream against the context's grid and a usable bit budget (non-zero: reject, message set)
+int check_ims_header(ebcc_hip_ctx *ctx, const uint8_t *b, size_t n, size_t num_bits);
 
 // synchronous copy of the frame states to ctx->h_fs
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n_frames);

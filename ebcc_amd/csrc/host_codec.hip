@@ -18,10 +18,12 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <tuple>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <memory>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "../../include/ebcc_hip.h"
@@ -163,27 +165,94 @@ struct RateSearch {
 };
 
 // ================================================================================================
-// context cache: one engine per (device, frame geometry), grown on demand
+// devices and the context cache: one engine per (device, frame geometry), grown on demand
 // ================================================================================================
-std::mutex g_mutex;
-std::map<std::tuple<int, int, int>, ebcc_hip_ctx *> g_ctx;
+// The reference-compatible entry points have no device argument.  They run on
+//   EBCC_HIP_DEVICE=<n>          if set, else on the calling thread's current HIP device (what torch.cuda.set_device or
+//                                hipSetDevice chose; 0 in a process that never chose), and
+//   EBCC_HIP_DEVICES=all|a,b,..  lets the chunking entry points spread their chunk list over several devices (default:
+//                                all visible devices in a stand-alone process, the one device above when the process is
+//                                one rank of a multi-process job - LOCAL_WORLD_SIZE / WORLD_SIZE > 1).
+// Every entry point makes its device current for the call and restores the caller's on return.
+int resolve_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;         // (create_engine reports the missing device)
+    if (const char *e = getenv("EBCC_HIP_DEVICE")) { int d = atoi(e); return d >= 0 && d < n ? d : 0; }
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+bool multi_process_job()
+{
+    for (const char *v : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+        if (const char *e = getenv(v)) if (atoi(e) > 1) return true;
+    return false;
+}
+std::vector<int> device_list()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return {0};
+    const char *e = getenv("EBCC_HIP_DEVICES");
+    std::vector<int> out;
+    if (e && strcmp(e, "all") != 0) {
+        for (const char *p = e; *p;) {
+            char *end;
+            long d = strtol(p, &end, 10);
+            if (end == p) break;
+            if (d >= 0 && d < n && std::find(out.begin(), out.end(), (int) d) == out.end()) out.push_back((int) d);
+            p = *end == ',' ? end + 1 : end;
+        }
+    } else if (e || !multi_process_job()) {
+        for (int d = 0; d < n; d++) out.push_back(d);
+    }
+    if (out.empty()) out.push_back(resolve_device());
+    return out;
+}
+struct DeviceScope {               // the engine's device for the duration of a call, the caller's afterwards
+    int prev = -1;
+    explicit DeviceScope(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; EBCC_HIP_CHECK(hipSetDevice(dev)); }
+    ~DeviceScope() { if (prev >= 0) hipSetDevice(prev); }
+};
+// One lock per device (HDF5 serialises filter calls anyway; a multi-threaded writer gets one call per device at a time).
+std::mutex &device_mutex(int dev)
+{
+    static std::mutex m[64];
+    return m[dev & 63];
+}
+std::mutex g_map_mutex;
+std::map<std::tuple<int, int, int, int>, ebcc_hip_ctx *> g_ctx;
 
 // `period` > 1: the frames are the tiles of images of that many tiles each, every tile position with its own
-// JPEG 2000 geometry (j2k.hpp)
-ebcc_hip_ctx *get_context(int H, int W, size_t frames, int period = 1)
+// JPEG 2000 geometry (j2k.hpp).  Called with the device's lock held and the device current.
+ebcc_hip_ctx *get_context(int device, int H, int W, size_t frames, int period = 1)
 {
-    auto key = std::make_tuple(H, W, period);
+    std::lock_guard<std::mutex> lock(g_map_mutex);
+    auto key = std::make_tuple(device, H, W, period);
     auto it = g_ctx.find(key);
     if (it != g_ctx.end() && it->second->max_frames >= frames) return it->second;
     if (it != g_ctx.end()) { ebcc_hip_destroy(it->second); g_ctx.erase(it); }
-    ebcc_hip_ctx *c = create_engine(0, frames, (size_t) H, (size_t) W, period);
-    if (!c && !g_ctx.empty()) {                                 // out of device memory: drop the engines of other geometries
-        for (auto &kv : g_ctx) ebcc_hip_destroy(kv.second);
-        g_ctx.clear();
-        c = create_engine(0, frames, (size_t) H, (size_t) W, period);
+    ebcc_hip_ctx *c = create_engine(device, frames, (size_t) H, (size_t) W, period);
+    if (!c) {                                                   // out of device memory: drop this device's engines of other geometries
+        bool dropped = false;
+        for (auto i = g_ctx.begin(); i != g_ctx.end();)
+            if (std::get<0>(i->first) == device) { ebcc_hip_destroy(i->second); i = g_ctx.erase(i); dropped = true; } else ++i;
+        if (dropped) c = create_engine(device, frames, (size_t) H, (size_t) W, period);
     }
     if (c) g_ctx[key] = c;
     return c;
+}
+
+// the device image of a host array handed to the reference API: kept in the context between calls
+float *io_buffer(ebcc_hip_ctx *ctx, size_t bytes)
+{
+    if (ctx->io_cap >= bytes) return ctx->d_io;
+    if (ctx->d_io) { hipFree(ctx->d_io); ctx->d_io = nullptr; ctx->io_cap = 0; }
+    void *p = nullptr;
+    hipError_t e = device_malloc(&p, bytes);
+    if (e != hipSuccess) { char b[128]; snprintf(b, sizeof b, "device buffer of %zu bytes: %s", bytes, hipGetErrorString(e)); throw HipFailure(b); }
+    ctx->d_io = (float *) p; ctx->io_cap = bytes;
+    return ctx->d_io;
 }
 
 // Frames per device batch of the host-pointer entry points: EBCC_HIP_MAX_BATCH (default 256), reduced for large
@@ -276,19 +345,28 @@ hipStream_t second_stream(ebcc_hip_ctx *c)
     return c->stream2;
 }
 
-// Host threads of one encode call for the entropy stage (level-22 zstd of the residual streams is the longest host
-// step): EBCC_HOST_THREADS, default the CPUs in the affinity mask, at most 32.  Measured on the MI355X box (a 16-CPU
-// container quota on a 256-thread host; tools/gpu/threads_sweep.sh): the work comes in short bursts - 6 ms per
-// frame, once per slice - that stay far below the quota on average, so more threads than the quota's CPU count
-// shorten the burst (32 per slice: 251 ms/step, 16: 262, 64: 255); a process-wide pool shared by the slices was
-// slower than threads of the call's own at every size.
-unsigned entropy_threads()
+// Host threads of one slice of an encode call for the entropy stage (level-22 zstd of the residual streams is the
+// longest host step): EBCC_HOST_THREADS, else from the CPUs in the affinity mask.  Stand-alone process, measured on the
+// MI355X box (a 16-CPU container quota on a 256-thread host; tools/gpu/threads_sweep.sh): the work comes in short bursts
+// - 6 ms per frame, once per slice - that stay far below the quota on average, so more threads than the quota's CPU
+// count shorten the burst (32 per slice: 251 ms/step, 16: 262, 64: 255).  One rank of a multi-process job
+// (LOCAL_WORLD_SIZE ranks share the host): the process as a whole - all its slices - stays within its share
+// cpus / LOCAL_WORLD_SIZE, so eight ranks do not put a thousand compressing threads on one host.
+unsigned entropy_threads_for(unsigned cpus, unsigned local_world, unsigned slices)
+{
+    if (local_world > 1) return std::max(1u, cpus / local_world / std::max(1u, slices));
+    return std::min(32u, std::max(4u, cpus));
+}
+std::atomic<unsigned> g_slices{1};          // slices of the encode call in progress (run_slices)
+unsigned entropy_threads(unsigned slices = 1)
 {
     if (const char *e = getenv("EBCC_HOST_THREADS")) return (unsigned) std::max(1L, strtol(e, nullptr, 10));
     unsigned n = std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned) CPU_COUNT(&set);
-    return std::min(32u, std::max(4u, n));
+    unsigned lws = 1;
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) lws = (unsigned) std::max(1, atoi(e));
+    return entropy_threads_for(n, lws, slices);
 }
 
 // The base layer of a batch of chunks.  A chunk is one frame, or `tiles` frames stacked along the row axis that
@@ -513,13 +591,15 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
     EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemsetAsync(ctx->d_counter, 0, sizeof(int) * 4, s));
     int rounds = search_rounds();
+    // a round = the probe the previous advance asked for (rate allocation + decode of the active chunks), then the advance
+    // that takes it in and asks for the next one
+    launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
     for (;;) {
         for (int r = 0; r < rounds; r++) {
-            launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
             launch_j2k_rate(b.jb, (int) b.nt, b.d_active, s);
             launch_j2k_probe_decode(b.d_frames, b.jb, (int) b.nt, b.d_active, s, k == 0);     // (search 1 uses the statistics only: the field of search 0 stays)
+            launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
         }
-        launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
         EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
@@ -735,14 +815,14 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 }
                 EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, rs));
                 EBCC_HIP_CHECK(hipMemsetAsync(rc->d_counter, 0, sizeof(int) * 4, rs));
-                int rounds = std::max(search_rounds(), 18);
+                int rounds = getenv("EBCC_HIP_SEARCH_ROUNDS") ? search_rounds() : 18;
+                launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                 for (;;) {
                     for (int r = 0; r < rounds; r++) {
-                        launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                         launch_reconstruct(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
                         launch_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+                        launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                     }
-                    launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                     EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
                     EBCC_HIP_CHECK(hipStreamSynchronize(rs));
                     bool done = true;
@@ -825,7 +905,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
         };
         std::vector<std::thread> zpool;
-        for (size_t t = 0; t < std::min<size_t>(entropy_threads(), n); t++) zpool.emplace_back(zworker);
+        struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } join_on_exit{zpool};   // (error paths too)
+        for (size_t t = 0; t < std::min<size_t>(entropy_threads(g_slices.load()), n); t++) zpool.emplace_back(zworker);
         auto zjoin = [&]() { for (auto &t : zpool) if (t.joinable()) t.join(); };
         pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)
@@ -1004,7 +1085,13 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     for (size_t f = 0; f < n; f++) {
         const ParsedFrame &hd = heads[f];
         if (piece[f]) memcpy(ctx->h_stage + piece_off[f], hd.tail, hd.tail_size);
-        if (piece[n + f]) zstd().decompress(ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.z, hd.compressed_size);
+        if (piece[n + f]) {
+            // the residual stream: exactly coeffs_size bytes (the staging buffer holds whatever an earlier call left),
+            // a SPIHT header for this grid and a bit budget the decoder can work with (:1294-1304)
+            const size_t got = zstd().decompress(ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.z, hd.compressed_size);
+            if ((zstd().is_error && zstd().is_error(got)) || got != hd.coeffs_size) { log_fatal("Invalid encoded data: residual payload does not decompress to %zu bytes", hd.coeffs_size); return 1; }
+            if (check_ims_header(ctx, ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.coeffs_size * 8)) { log_fatal("Invalid encoded data: %s", ebcc_hip_last_error()); return 1; }
+        }
     }
     stage_send(ctx, 2 * n, s);
     stage_scatter(ctx, jb.stream, jb.stream_cap, 0, n, s);
@@ -1105,7 +1192,9 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
         if (hd.compressed_size > 0 && hd.coeffs_size > 0) {
             if (hd.coeffs_size > rc->rb.stream_words * 4 - 64) { log_fatal("residual stream larger than the device slot"); return 1; }
             coeffs[c].assign(hd.coeffs_size, 0);
-            zstd().decompress(coeffs[c].data(), hd.coeffs_size, hd.z, hd.compressed_size);
+            const size_t got = zstd().decompress(coeffs[c].data(), hd.coeffs_size, hd.z, hd.compressed_size);
+            if ((zstd().is_error && zstd().is_error(got)) || got != hd.coeffs_size) { log_fatal("Invalid encoded data: residual payload does not decompress to %zu bytes", hd.coeffs_size); return 1; }
+            if (check_ims_header(rc, coeffs[c].data(), hd.coeffs_size, hd.coeffs_size * 8)) { log_fatal("Invalid encoded data: %s", ebcc_hip_last_error()); return 1; }
             rc->h_active[c] = 1;
             any_resid = true;
         }
@@ -1143,20 +1232,21 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
 }
 
 // the engine of the tiles and, for chunks of several frames, the engine of the stacked chunk image
-bool chunk_engines(int H, int W, size_t chunks, size_t tiles, ebcc_hip_ctx **ctx, ebcc_hip_ctx **rc)
+bool chunk_engines(int device, int H, int W, size_t chunks, size_t tiles, ebcc_hip_ctx **ctx, ebcc_hip_ctx **rc)
 {
     *rc = nullptr;
     if (tiles > 1) {
-        *rc = get_context((int) (tiles * (size_t) H), W, chunks);
+        *rc = get_context(device, (int) (tiles * (size_t) H), W, chunks);
         if (!*rc) return false;
     }
     const int period = tiles > 1 && !tile_geometry_uniform((size_t) H) ? (int) tiles : 1;
-    *ctx = get_context(H, W, chunks * tiles, period);
+    *ctx = get_context(device, H, W, chunks * tiles, period);
     if (!*ctx) return false;
     if (tiles > 1) {                                             // (creating the second engine may have evicted the first)
-        *rc = get_context((int) (tiles * (size_t) H), W, chunks);
+        *rc = get_context(device, (int) (tiles * (size_t) H), W, chunks);
         if (!*rc) return false;
-        if (g_ctx.find(std::make_tuple(H, W, period)) == g_ctx.end()) return false;
+        std::lock_guard<std::mutex> lock(g_map_mutex);
+        if (g_ctx.find(std::make_tuple(device, H, W, period)) == g_ctx.end()) return false;
     }
     return true;
 }
@@ -1201,32 +1291,60 @@ int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames,
 int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out);
 
 // host-pointer convenience used by the reference-compatible entry points
-// n chunks of `tiles` frames of H x W each, contiguous in host memory
-size_t encode_host_frames(const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
-                          size_t tiles = 1)
+// n chunks of `tiles` frames of H x W each, contiguous in host memory, on device `device`.  Returns 0 ok, 1 error (logged),
+// 2 NaN / Inf in the data (the caller exits as the reference does, /root/reference/src/ebcc_codec.c:598-605).
+int encode_host_frames(int device, const float *data, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
+                       size_t tiles = 1)
 {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    const size_t n_pix = (size_t) H * W * tiles;
-    const size_t cap = std::min(n, batch_capacity(n_pix));
-    ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
-    if (!chunk_engines(H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
-    float *d = nullptr;
-    EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * n_pix * sizeof(float)));
-    size_t done = 0;
-    while (done < n) {
-        size_t k = std::min(cap, n - done);
-        int rcode;
-        // (the whole batch in one copy: uploads issued from inside the slices slowed every slice down -
-        //  tools/gpu/host_api_rate.py: 5.6 GB/s encode this way, 3.7 with four uploading slices)
-        EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
-        if (tiles == 1) rcode = run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done);   // one-frame chunks: concurrent slices
-        else rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
-        if (rcode == 2) { hipFree(d); exit(1); }                                               // check_nan_inf, :598-605
-        if (rcode) { hipFree(d); return 0; }
-        done += k;
+    try {
+        std::lock_guard<std::mutex> lock(device_mutex(device));
+        DeviceScope scope(device);
+        const size_t n_pix = (size_t) H * W * tiles;
+        const size_t cap = std::min(n, batch_capacity(n_pix));
+        ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+        if (!chunk_engines(device, H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
+        float *d = io_buffer(ctx, cap * n_pix * sizeof(float));
+        size_t done = 0;
+        while (done < n) {
+            size_t k = std::min(cap, n - done);
+            int rcode;
+            // (the whole batch in one copy: uploads issued from inside the slices slowed every slice down -
+            //  tools/gpu/host_api_rate.py: 5.6 GB/s encode this way, 3.7 with four uploading slices)
+            EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
+            if (tiles == 1) rcode = run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done);   // one-frame chunks: concurrent slices
+            else rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
+            if (rcode) return rcode;
+            done += k;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        log_fatal("MI355X engine failure: %s", e.what());
+        set_error("%s", e.what());
+        return 1;
     }
-    hipFree(d);
-    return n;
+}
+
+// A list of independent chunks spread over the devices of device_list(): contiguous blocks, one host thread per device
+// (/root/reference/src/ebcc_codec.c:1007-1046 is a serial loop over the chunks; the order of the results is that of the
+// chunks).  fn(device, first, count) -> status; returns the worst status.
+template <class Fn>
+int run_on_devices(size_t n_chunks, Fn fn)
+{
+    std::vector<int> devs = device_list();
+    if (devs.size() > n_chunks) devs.resize(std::max<size_t>(1, n_chunks));
+    if (devs.size() == 1) return fn(devs[0], (size_t) 0, n_chunks);
+    const size_t per = (n_chunks + devs.size() - 1) / devs.size();
+    std::vector<int> rc(devs.size(), 0);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < devs.size(); i++) {
+        const size_t lo = i * per, hi = std::min(n_chunks, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([&, i, lo, hi]() { rc[i] = fn(devs[i], lo, hi - lo); });
+    }
+    for (auto &t : th) t.join();
+    int worst = 0;
+    for (int r : rc) worst = std::max(worst, r);
+    return worst;
 }
 
 }  // namespace
@@ -1266,23 +1384,35 @@ template <class Fn>
 static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env_name, size_t default_slices)
 {
     const size_t k = slice_engines(ctx, n_frames, env_name, default_slices);
+    g_slices = (unsigned) k;
     if (k == 1) return fn(ctx, (size_t) 0, n_frames, (SliceGate *) nullptr);
     const size_t per = (n_frames + k - 1) / k;
     std::vector<int> rc(k, 0);
+    std::vector<std::string> err(k);
     std::vector<SliceGate> gates(k);
     std::vector<std::thread> th;
     for (size_t i = 0; i < k; i++) {
         const size_t lo = i * per, hi = std::min(n_frames, lo + per);
         if (lo >= hi) break;
         th.emplace_back([&, i, lo, hi]() {
-            EBCC_HIP_CHECK(hipSetDevice(ctx->device));
-            if (i > 0) gates[i - 1].wait();
-            rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i]);
+            // (a thread has its own current device and its own last-error text: the slice reports through rc / err)
+            try {
+                EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+                if (i > 0) gates[i - 1].wait();
+                rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i]);
+                if (rc[i]) err[i] = ebcc_hip_last_error();
+            } catch (const std::exception &e) {
+                rc[i] = 1; err[i] = e.what();
+                gates[i].release();                                    // (never leave the next slice waiting)
+            }
         });
     }
     for (auto &t : th) t.join();
     int worst = 0;
-    for (int r : rc) worst = std::max(worst, r);
+    for (size_t i = 0; i < k; i++) {
+        if (rc[i] && !err[i].empty()) set_error("%s", err[i].c_str());
+        worst = std::max(worst, rc[i]);
+    }
     return worst;
 }
 
@@ -1337,42 +1467,50 @@ void print_config(codec_config_t *c)
     if (t == RELATIVE_ERROR) log_info("relative error:\t%f", c->error);
 }
 
+int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) std::max(1, slices)); }
+
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
 {
+    EBCC_API_TRY
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_prepare: bad batch"); return 1; }
-    std::lock_guard<std::mutex> lock(g_mutex);
-    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
     slice_engines(ctx, n_frames, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);   // (the coarser slicing first:
     slice_engines(ctx, n_frames, "EBCC_HIP_SLICES", default_encode_slices());                        //  its lanes serve both)
     second_stream(ctx);
     for (ebcc_hip_ctx *c : ctx->lanes) second_stream(c);
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
                            uint8_t **out_streams, size_t *out_sizes)
 {
+    EBCC_API_TRY
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_encode_frames: bad batch"); return 1; }
     if (config->dims[0] != 1 || (int) config->dims[1] != ctx->height || (int) config->dims[2] != ctx->width) {
         set_error("ebcc_hip_encode_frames: config dims must be (1, %d, %d)", ctx->height, ctx->width);
         return 1;
     }
-    std::lock_guard<std::mutex> lock(g_mutex);
-    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
     log_set_level_from_env();
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }   // on error: free the non-null ones
     return run_encode_slices(ctx, d_frames, n_frames, config, out_streams, out_sizes);
+    EBCC_API_CATCH(1)
 }
 
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                            float *d_frames_out)
 {
+    EBCC_API_TRY
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_decode_frames: bad batch"); return 1; }
-    std::lock_guard<std::mutex> lock(g_mutex);
-    EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     return run_decode_slices(ctx, streams, sizes, n_frames, d_frames_out);
+    EBCC_API_CATCH(1)
 }
 
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
@@ -1393,7 +1531,9 @@ size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
     }
     size_t size = 0;
     uint8_t *o = nullptr;
-    if (encode_host_frames(data, 1, (int) config->dims[1], (int) config->dims[2], config, &o, &size, config->dims[0]) != 1) return 0;
+    const int rcode = encode_host_frames(resolve_device(), data, 1, (int) config->dims[1], (int) config->dims[2], config, &o, &size, config->dims[0]);
+    if (rcode == 2) exit(1);                                                                   // check_nan_inf, :598-605
+    if (rcode) { free(o); return 0; }
     *out_buffer = o;
     return size;
 }
@@ -1422,21 +1562,28 @@ size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
         log_fatal("streams with %zu tiles of %d rows are not supported", tiles, th);
         return 0;
     }
-    std::lock_guard<std::mutex> lock(g_mutex);
-    ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
-    if (!chunk_engines(th, W, 1, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
-    const size_t n_pix = (size_t) H * W;
-    float *d = nullptr;
-    EBCC_HIP_CHECK(hipMalloc((void **) &d, n_pix * sizeof(float)));
-    const uint8_t *sp = data;
-    int rcode = tiles > 1 ? decode_tiled(ctx, rc, &sp, &data_size, 1, tiles, d) : decode_batch(ctx, &sp, &data_size, 1, d);
-    if (rcode) { hipFree(d); return 0; }
-    // :1126-1128: honour a caller-provided buffer
-    float *o = *out_buffer ? *out_buffer : (float *) malloc(n_pix * sizeof(float));
-    EBCC_HIP_CHECK(hipMemcpy(o, d, n_pix * sizeof(float), hipMemcpyDeviceToHost));
-    hipFree(d);
-    *out_buffer = o;
-    return n_pix;
+    const int device = resolve_device();
+    try {
+        std::lock_guard<std::mutex> lock(device_mutex(device));
+        DeviceScope scope(device);
+        ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+        if (!chunk_engines(device, th, W, 1, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
+        const size_t n_pix = (size_t) H * W;
+        float *d = io_buffer(ctx, n_pix * sizeof(float));
+        const uint8_t *sp = data;
+        int rcode = tiles > 1 ? decode_tiled(ctx, rc, &sp, &data_size, 1, tiles, d) : decode_batch(ctx, &sp, &data_size, 1, d);
+        if (rcode) return 0;
+        // :1126-1128: honour a caller-provided buffer
+        float *o = *out_buffer ? *out_buffer : (float *) malloc(n_pix * sizeof(float));
+        if (!o) { log_fatal("out of memory"); return 0; }
+        EBCC_HIP_CHECK(hipMemcpy(o, d, n_pix * sizeof(float), hipMemcpyDeviceToHost));
+        *out_buffer = o;
+        return n_pix;
+    } catch (const std::exception &e) {
+        log_fatal("MI355X engine failure: %s", e.what());
+        set_error("%s", e.what());
+        return 0;
+    }
 }
 
 // ---- EBCK chunk container (:920-1052) -------------------------------------------------------------
@@ -1486,13 +1633,18 @@ size_t ebcc_encode_chunking(float *data, codec_config_t *config, uint8_t **out_b
     for (int i = 0; i < 3; i++) { cc.dims[i] = cd[i]; cc.chunk_dims[i] = 0; }
     std::vector<uint8_t *> outs(nchunks, nullptr);
     std::vector<size_t> sizes(nchunks, 0);
-    if (encode_host_frames(chunk_data, nchunks, (int) cd[1], (int) cd[2], &cc, outs.data(), sizes.data(), cd[0]) != nchunks) {
+    const int rcode = run_on_devices(nchunks, [&](int device, size_t first, size_t count) {
+        return encode_host_frames(device, chunk_data + first * csize, count, (int) cd[1], (int) cd[2], &cc, outs.data() + first, sizes.data() + first, cd[0]);
+    });
+    if (rcode == 2) exit(1);                                                                   // check_nan_inf, :598-605
+    if (rcode) {
         for (auto p : outs) free(p);
         return 0;
     }
     size_t len = sizeof(ChunkHeader);
     for (size_t c = 0; c < nchunks; c++) len += 8 + sizes[c];
     uint8_t *o = (uint8_t *) malloc(len), *p = o;
+    if (!o) { log_fatal("out of memory"); for (auto q : outs) free(q); return 0; }
     ChunkHeader hd;
     memset(&hd, 0, sizeof hd);
     memcpy(hd.magic, EBCC_CHUNKING_HEADER_MAGIC, 4);
@@ -1579,34 +1731,33 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     std::vector<float> chunks;
     if (!in_place) chunks.resize(nchunks * csize);
     float *h_chunks = in_place ? o : chunks.data();
-    {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        const size_t tiles = cd[0];
-        const size_t cap = std::min(nchunks, batch_capacity(csize));
-        ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
-        if (!chunk_engines(H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); free(o); return 0; }
-        float *d = nullptr;
-        EBCC_HIP_CHECK(hipMalloc((void **) &d, cap * csize * sizeof(float)));
-        for (size_t done = 0; done < nchunks;) {
-            size_t k = std::min(cap, nchunks - done);
-            int rcode;
-            if (tiles > 1) {
-                rcode = decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d);
-                if (!rcode) EBCC_HIP_CHECK(hipMemcpy(h_chunks + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
-            } else {
-                EBCC_HIP_CHECK(hipSetDevice(ctx->device));
-                if (!zstd().ok) { log_fatal("libzstd not available"); rcode = 1; }
-                else {
-                    rcode = run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d);      // (one download below: copies issued
-                                                                                                    //  from inside the slices slowed them down)
-                    if (!rcode) EBCC_HIP_CHECK(hipMemcpy(h_chunks + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
-                }
+    const size_t tiles = cd[0];
+    const int rcode = run_on_devices(nchunks, [&](int device, size_t first, size_t count) {
+        try {
+            std::lock_guard<std::mutex> lock(device_mutex(device));
+            DeviceScope scope(device);
+            const size_t cap = std::min(count, batch_capacity(csize));
+            ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+            if (!chunk_engines(device, H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
+            if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+            float *d = io_buffer(ctx, cap * csize * sizeof(float));
+            for (size_t done = first; done < first + count;) {
+                const size_t k = std::min(cap, first + count - done);
+                // (one download per batch: copies issued from inside the slices slowed them down)
+                const int r = tiles > 1 ? decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d)
+                                        : run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d);
+                if (r) return r;
+                EBCC_HIP_CHECK(hipMemcpy(h_chunks + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
+                done += k;
             }
-            if (rcode) { hipFree(d); free(o); return 0; }
-            done += k;
+            return 0;
+        } catch (const std::exception &e) {
+            log_fatal("MI355X engine failure: %s", e.what());
+            set_error("%s", e.what());
+            return 1;
         }
-        hipFree(d);
-    }
+    });
+    if (rcode) { free(o); return 0; }
     if (!in_place)
         for (size_t cl = 0; cl < nchunks; cl++) box.scatter(chunks.data() + cl * csize, cl, o);          // :353-370
     *out_buffer = o;

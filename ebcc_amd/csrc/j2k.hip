@@ -178,12 +178,18 @@ bool parse_main_header(const uint8_t *cs, size_t n, MainHeader &h)
         const unsigned mk = be16(cs + pos), len = be16(cs + pos + 2);
         const uint8_t *p = cs + pos + 4;
         if (mk == 0xFF90) { h.first_sot = pos; return true; }
-        if (pos + 2 + len > n) { set_error("J2K: truncated marker segment"); return false; }
+        // a segment is its length field (2 bytes) + payload, all inside the stream; the fixed-offset reads below stay
+        // inside the payload (A.5.1: SIZ has 36 bytes + 3 per component, A.6.1: COD 10 or more, A.6.4: QCD 1 + 2 per band)
+        if (len < 2 || pos + 2 + (size_t) len > n) { set_error("J2K: truncated marker segment"); return false; }
         if (mk == 0xFF51) {
+            if (len < 38) { set_error("J2K: SIZ segment too short"); return false; }
             h.W = (int) (be32(p + 2) - be32(p + 10)); h.H = (int) (be32(p + 6) - be32(p + 14));
             h.tile_w = (int) be32(p + 18); h.tile_h = (int) be32(p + 22);
-        } else if (mk == 0xFF52) h.nres = p[5] + 1;
-        else if (mk == 0xFF5C) {
+        } else if (mk == 0xFF52) {
+            if (len < 8) { set_error("J2K: COD segment too short"); return false; }
+            h.nres = p[5] + 1;
+        } else if (mk == 0xFF5C) {
+            if (len < 3) { set_error("J2K: QCD segment too short"); return false; }
             h.qsty = p[0] & 0x1F; h.guard = p[0] >> 5;
             const int nb = (int) (len - 3) / 2;
             for (int i = 0; i < nb && i < kJ2kBands; i++) { unsigned v = be16(p + 1 + 2 * i); h.expn[i] = (int) (v >> 11); h.mant[i] = (int) (v & 0x7FF); }
@@ -231,17 +237,25 @@ bool parse_tile_part(const uint8_t *cs, size_t n, size_t sot, const uint8_t *ori
                     for (int cx = 0; cx < bd.ncw; cx++) {
                         if (!incl.decode(br, cx, cy, 1)) continue;
                         int blk = bd.first_block + cy * bd.ncw + cx;
+                        // everything read from the packet header is checked before it is used as a count, a shift or
+                        // an offset: the tables steer device kernels (OpenJPEG does the same checks for the reference)
                         int i = 1;
-                        while (!imsb.decode(br, cx, cy, i)) i++;
+                        while (!imsb.decode(br, cx, cy, i)) { if (++i > bd.numbps + 1) { set_error("J2K: bad zero-bit-plane count"); return false; } }
+                        const int planes = bd.numbps + 1 - i;
+                        if (planes < 1 || planes > kJ2kMaxPlanes) { set_error("J2K: code-block with %d bit-planes", planes); return false; }
                         int np;
                         if (!br.bit()) np = 1;
                         else if (!br.bit()) np = 2;
                         else { int v = br.bits(2); if (v != 3) np = 3 + v; else { v = br.bits(5); np = v != 31 ? 6 + v : 37 + br.bits(7); } }
+                        if (np > 3 * planes - 2) { set_error("J2K: %d coding passes for %d bit-planes", np, planes); return false; }
                         int lblock = 3;
-                        while (br.bit()) lblock++;
-                        int len = br.bits(lblock + flog2(np));
+                        while (br.bit()) { if (++lblock > 24) { set_error("J2K: bad Lblock"); return false; } }
+                        const int lenbits = lblock + flog2(np);
+                        if (lenbits > 30) { set_error("J2K: bad segment length field"); return false; }
+                        int len = br.bits(lenbits);
+                        if (len < 0 || (size_t) len > (size_t) (tile_end - tile_data)) { set_error("J2K: segment longer than the tile-part"); return false; }
                         table[4 * blk + 1] = len;
-                        table[4 * blk + 2] = bd.numbps + 1 - i;
+                        table[4 * blk + 2] = planes;
                         table[4 * blk + 3] = np;
                         included.push_back(blk);
                     }
@@ -250,7 +264,7 @@ bool parse_tile_part(const uint8_t *cs, size_t n, size_t sot, const uint8_t *ori
         br.align();
         p = br.p;
         for (int blk : included) {
-            if (p + table[4 * blk + 1] > tile_end) { set_error("J2K: packet body overruns the tile-part"); return false; }
+            if (p > tile_end || table[4 * blk + 1] > tile_end - p) { set_error("J2K: packet body overruns the tile-part"); return false; }
             table[4 * blk + 0] = (int) (p - origin);
             p += table[4 * blk + 1];
         }
@@ -320,6 +334,30 @@ using namespace ebcc;
 
 extern "C" {
 
+// Host-only check of the codestream parser (no device work): parses `cs` as a one-tile codestream of height x width
+// and verifies that every code-block entry it would hand to the device kernels lies inside the stream.  0 = accepted,
+// 1 = rejected (message in ebcc_hip_last_error), 2 = ACCEPTED WITH AN ENTRY OUT OF BOUNDS (a parser bug).
+__attribute__((visibility("default"))) int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t width)
+{
+    EBCC_API_TRY
+    if (height < 1 || width < 1 || height > 2047 || width > 2047) { set_error("bad geometry"); return 1; }
+    std::vector<J2kBlock> blocks;
+    J2kGeom g = make_j2k_geom((int) height, (int) width, blocks);
+    g.period = 1; g.stride = g.nblocks;
+    std::vector<int> table((size_t) g.stride * 4, 0);
+    if (!j2k_parse_codestream(cs, n, g, table.data())) return 1;
+    for (int b = 0; b < g.nblocks; b++) {
+        const int off = table[4 * b], len = table[4 * b + 1], planes = table[4 * b + 2], np = table[4 * b + 3];
+        if (np == 0 && len == 0) continue;
+        if (off < 0 || len < 0 || (size_t) off + (size_t) len > n || planes < 1 || planes > kJ2kMaxPlanes || np < 1 || np > 3 * planes - 2) {
+            set_error("parser accepted code-block %d with offset %d length %d planes %d passes %d", b, off, len, planes, np);
+            return 2;
+        }
+    }
+    return 0;
+    EBCC_API_CATCH(1)
+}
+
 // ---- unit-level entry points of the base layer (parity tests) -------------------------------------
 // j2k_encode_internal (src/ebcc_codec.c:105-180) for a batch: frames are scaled to u16 with their own
 // min/max as ebcc_encode does (:675-689), then coded at rate cr[f].
@@ -327,6 +365,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx
                                                                const float *cr, uint8_t **out_streams, size_t *out_sizes,
                                                                float *minmax)
 {
+    EBCC_API_TRY
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_j2k_encode: bad batch"); return 1; }
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
@@ -357,6 +396,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx
     }
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 // After ebcc_hip_j2k_encode: the field j2k_decode_internal (:1092-1136) would return for those streams,
@@ -365,6 +405,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_emulated_decode(ebcc_hip
                                                                          const float *target, float *d_out,
                                                                          unsigned long long *nbad, double *err_sum)
 {
+    EBCC_API_TRY
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_j2k_emulated_decode: bad batch"); return 1; }
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
@@ -380,12 +421,14 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_emulated_decode(ebcc_hip
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     for (size_t f = 0; f < n_frames; f++) { nbad[f] = jf[f].nbad; err_sum[f] = jf[f].err_sum; }
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 // j2k_decode_internal for a batch of codestreams with the given (minval, maxval)
 __attribute__((visibility("default"))) int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes,
                                                                size_t n_frames, const float *minmax, float *d_out)
 {
+    EBCC_API_TRY
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_j2k_decode: bad batch"); return 1; }
     EBCC_HIP_CHECK(hipSetDevice(ctx->device));
     J2kBuffers &jb = *static_cast<J2kBuffers *>(ctx->j2k);
@@ -407,6 +450,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n_frames * ctx->n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
     EBCC_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
+    EBCC_API_CATCH(1)
 }
 
 }  // extern "C"

@@ -1018,13 +1018,17 @@ void launch_input_stats(const float *data, int n_frames, size_t n_pix, FrameStat
     hipLaunchKernelGGL(k_in_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, fs, n_frames);
     hipLaunchKernelGGL(k_in_minmax, dim3(64, n_frames), dim3(256), 0, s, data, n_pix, fs);
     hipLaunchKernelGGL(k_in_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, data, n_pix, fs, n_frames);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
-static short *g_luts = nullptr;
+static short *g_luts_dev[64] = {nullptr};   // one copy per device
 static const short *nmsedec_luts(hipStream_t s)
 {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    EBCC_HIP_CHECK(hipGetDevice(&dev));
+    short *&g_luts = g_luts_dev[dev & 63];
     if (!g_luts) {
         short h[4 * 128];
         for (int i = 0; i < 128; i++) {                                // t1_generate_luts: T.800 J.14.4 estimates
@@ -1042,7 +1046,7 @@ static const short *nmsedec_luts(hipStream_t s)
             x = (int) (std::floor((u * u) * std::pow(2, 6) + 0.5) / std::pow(2, 6) * 8192.0);
             h[3 * 128 + i] = (short) std::max(0, x);
         }
-        EBCC_HIP_CHECK(hipMalloc(&g_luts, sizeof h));
+        EBCC_HIP_CHECK(device_malloc((void **) &g_luts, sizeof h));
         EBCC_HIP_CHECK(hipMemcpyAsync(g_luts, h, sizeof h, hipMemcpyHostToDevice, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
     }
@@ -1104,6 +1108,7 @@ void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool si
     timing_end("t1_encode", s);
     hipLaunchKernelGGL(k_distortion, dim3(g.stride, n_frames), dim3(256), 0, s, jb.Q6, jb.SPS, jb.numbps, jb.totalpasses,
                        jb.disto, nmsedec_luts(s), jb.d_geom, jb.d_blocks, fs);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 bool j2k_tier1_retry(const J2kBuffers &jb, int n_frames, const J2kFrame *host_jf, hipStream_t s)
@@ -1135,6 +1140,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     hipLaunchKernelGGL(k_quantize, dim3(g.stride, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
                        jb.d_geom, jb.d_blocks, fs);
     launch_j2k_tier1(jb, n_frames, s, false);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 // dequantisation + inverse transform of the tier-1 decoder's output V through the tile buffers B to the decoded
@@ -1149,6 +1155,7 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
         if (r + 1 < kJ2kRes) dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
         else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u});
     }
+    EBCC_HIP_LAUNCH_CHECK();
     return partials;
 }
 

@@ -1155,12 +1155,14 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
     });
     hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), lds, s, jb.numbps, jb.totalpasses, jb.rates,
                        jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want, jb.rate_path, jb.rate_path_n);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_write, dim3(n_frames), dim3(kWriteThreads), rate_lds(jb), s, jb.numbps, jb.rates, jb.npass,
                        jb.cblk_bytes, jb.stream, jb.stream_cap, jb.d_geom, jb.jf, jb.fs, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s,
@@ -1188,6 +1190,8 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
                        d_active, total, lpw);
     timing_end("t1_probe_decode", s);
     decode_tail(data, jb, n_frames, d_active, true, s, keep_field);
+    EBCC_HIP_LAUNCH_CHECK();
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
@@ -1203,6 +1207,7 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
                        jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 }  // namespace ebcc

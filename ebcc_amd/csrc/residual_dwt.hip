@@ -662,6 +662,7 @@ void launch_residual_minmax(const float *data, const float *decoded, int n_frame
     hipLaunchKernelGGL(k_residual_minmax, dim3(64, n_frames), dim3(256), 0, s, data, decoded, n_pix, fs);
     hipLaunchKernelGGL(k_residual_minmax_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, data, decoded, n_pix,
                        fs, n_frames);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 static void finish_dc(const ResidualBuffers &rb, int n_frames, const int *active, hipStream_t s)
@@ -678,6 +679,7 @@ void launch_pad_and_dc(const float *data, const float *decoded, const ResidualBu
     hipLaunchKernelGGL(k_pad_load<false>, dim3(kPartials, n_frames), dim3(256), 0, s, data, decoded, rb.A, rb.g, n_pix,
                        rb.np, rb.fs, rb.partial, d_active);
     finish_dc(rb, n_frames, d_active, s);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_pad_and_dc_from_image(const float *image, const ResidualBuffers &rb, int n_frames, hipStream_t s)
@@ -686,21 +688,25 @@ void launch_pad_and_dc_from_image(const float *image, const ResidualBuffers &rb,
     hipLaunchKernelGGL(k_pad_load<true>, dim3(kPartials, n_frames), dim3(256), 0, s, image, (const float *) nullptr,
                        rb.A, rb.g, n_pix, rb.np, rb.fs, rb.partial, (const int *) nullptr);
     finish_dc(rb, n_frames, nullptr, s);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
-static int *g_step_table = nullptr;   // device copy of floor(log(2^k)/log(2.0)) evaluated by the host libm
+static int *g_step_table_dev[64] = {nullptr};   // device copies (one per device) of floor(log(2^k)/log(2.0)) evaluated by the host libm
 
 static const int *step_table(hipStream_t s)
 {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    EBCC_HIP_CHECK(hipGetDevice(&dev));
+    int *&g_step_table = g_step_table_dev[dev & 63];
     if (!g_step_table) {
         int h[32];
         for (int k = 0; k < 32; k++) {
             float m = (float) (1u << k);
             h[k] = (int) floor(log((double) m) / log(2.0));        // spiht_re.c:60 with max = 2^k
         }
-        EBCC_HIP_CHECK(hipMalloc(&g_step_table, sizeof h));
+        EBCC_HIP_CHECK(device_malloc((void **) &g_step_table, sizeof h));
         EBCC_HIP_CHECK(hipMemcpyAsync(g_step_table, h, sizeof h, hipMemcpyHostToDevice, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
     }
@@ -726,6 +732,8 @@ void launch_analysis(const ResidualBuffers &rb, int n_frames, const int *d_activ
     }
     hipLaunchKernelGGL(k_descmax, dim3(ceil_div(g.lx * g.ly, 256), n_frames), dim3(256), 0, s, rb.C, rb.D, rb.G, g,
                        rb.np, g.lx, g.ly, 0, 0, g.stages > 1 ? 1 : 0, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s)
@@ -736,6 +744,7 @@ void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_acti
         cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
         rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
     }
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 // the synthesis whose last row pass consumes the rows (RowUse) instead of storing the grid; returns the workgroups
@@ -750,6 +759,7 @@ void launch_synthesis_head(const ResidualBuffers &rb, int n_frames, const int *d
         rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
     }
     cols_pass<false>(rb.A, rb.T, rb, g.ny, g.nx, n_frames, d_active, s);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 static int synthesis_tail(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s, RowUse u)
@@ -772,6 +782,7 @@ void launch_synthesis_stats(const float *data, const float *decoded, const Resid
     launch_synthesis_head(rb, n_frames, d_active, s);
     const int partials = synthesis_tail(rb, n_frames, d_active, s, u);
     hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, partials, rb.fs, n_frames, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 // after launch_synthesis_head: the last row pass with out += residual (ebcc_codec.c:1307) instead of a stored grid
@@ -780,12 +791,14 @@ void launch_synthesis_tail_add(float *out, const ResidualBuffers &rb, int n_fram
     RowUse u{};
     u.out = out;
     synthesis_tail(rb, n_frames, d_active, s, u);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_emit_image(float *image_out, const ResidualBuffers &rb, int n_frames, hipStream_t s)
 {
     size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
     hipLaunchKernelGGL(k_emit_image, dim3(128, n_frames), dim3(256), 0, s, image_out, rb.A, rb.g, n_pix, rb.np, rb.fs);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 }  // namespace ebcc

@@ -20,15 +20,27 @@ namespace ebcc {
 namespace {
 
 // list entries swept per step (one per thread).  A step costs its scans and barriers, not its work: 512 entries per
-// step take 5.0 ms per launch where 256 took 8.5 (tools/gpu/spiht_threads.sh); 1024 does not build into a correct kernel.
+// step take 5.4 ms per launch where 256 took 8.5, 1024 take 3.9 (tools/gpu/spiht_threads.sh, tools/gpu/spiht1024.sh).
 #ifndef EBCC_SPIHT_ENC_THREADS
-#define EBCC_SPIHT_ENC_THREADS 512
+#define EBCC_SPIHT_ENC_THREADS 1024
 #endif
 constexpr int kEncThreads = EBCC_SPIHT_ENC_THREADS;
 constexpr int kEncWaves = kEncThreads / kWave;
 constexpr int kHeaderBits = 120;      // IMS header incl. the 8-bit step (spiht_re.c:448-464,63)
 constexpr int kMaxEntryBits = 9;      // set bit + 4 x (significance + sign)
 constexpr int kWindowWords = (kEncThreads * kMaxEntryBits) / 32 + 4;
+// The LIS sweep scans five per-entry counters as fields of ONE 64-bit word; a field must hold the sum over a whole
+// sweep of kEncThreads entries: bits <= 9 per entry, new LSP / LIP entries and appended LIS entries <= 4 each, survivors
+// <= 1.  (Round 1 used 12-bit fields: 512 entries x 9 bits = 4608 carried into the next field - every child of every
+// entry of a sweep significant on one plane - and 1024 entries overflowed on ordinary data.)
+constexpr int bits_for(unsigned long long v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
+constexpr int kFldBits = bits_for((unsigned long long) kEncThreads * kMaxEntryBits);
+constexpr int kFldCnt = bits_for((unsigned long long) kEncThreads * 4);
+constexpr int kFldSurv = bits_for((unsigned long long) kEncThreads);
+constexpr int kShLsp = kFldBits, kShLip = kShLsp + kFldCnt, kShApp = kShLip + kFldCnt, kShSurv = kShApp + kFldCnt;
+static_assert(kShSurv + kFldSurv <= 64, "the packed scan word of the LIS sweep does not fit 64 bits: fewer entries per sweep");
+static_assert(kEncThreads % kWave == 0 && kEncThreads <= 1024, "entries per sweep = threads of the workgroup");
+constexpr unsigned long long fld_mask(int bits) { return (1ull << bits) - 1; }
 
 __device__ inline int first_child(const Grid &g, int x, int y)
 {
@@ -225,6 +237,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
                 bool sig = valid && (a >> s) != 0;
                 int nb = valid ? (sig ? 2 : 1) : 0;
                 unsigned int val = sig ? (2u | (c > 0 ? 0u : 1u)) : 0u;          // sign: 0 = positive, :229
+                static_assert(2 * kEncThreads < 65536, "16-bit fields of the LIP sweep");
                 unsigned long long pack = (unsigned long long) nb | ((unsigned long long) (sig ? 1 : 0) << 16) |
                                           ((unsigned long long) ((valid && !sig) ? 1 : 0) << 32);
                 unsigned long long tot;
@@ -296,19 +309,19 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
                         else surv = 1;
                     }
                 }
-                unsigned long long pack = (unsigned long long) nb | ((unsigned long long) n_lsp << 12) |
-                                          ((unsigned long long) n_lip << 24) | ((unsigned long long) n_app << 36) |
-                                          ((unsigned long long) surv << 48);
+                unsigned long long pack = (unsigned long long) nb | ((unsigned long long) n_lsp << kShLsp) |
+                                          ((unsigned long long) n_lip << kShLip) | ((unsigned long long) n_app << kShApp) |
+                                          ((unsigned long long) surv << kShSurv);
                 unsigned long long tot;
                 unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, tot);
-                unsigned long long off = nbits + (ex & 0xFFF);
+                unsigned long long off = nbits + (ex & fld_mask(kFldBits));
                 window_open(bw, nbits);
                 window_put(bw, val, nb, off, limit);
                 if (valid) {
-                    unsigned int r_lsp = nlsp + (unsigned int) ((ex >> 12) & 0xFFF);
-                    unsigned int r_lip = nlip + (unsigned int) ((ex >> 24) & 0xFFF);
-                    unsigned int r_app = ncur + (unsigned int) ((ex >> 36) & 0xFFF);
-                    unsigned int r_surv = nnext + (unsigned int) ((ex >> 48) & 0xFFF);
+                    unsigned int r_lsp = nlsp + (unsigned int) ((ex >> kShLsp) & fld_mask(kFldCnt));
+                    unsigned int r_lip = nlip + (unsigned int) ((ex >> kShLip) & fld_mask(kFldCnt));
+                    unsigned int r_app = ncur + (unsigned int) ((ex >> kShApp) & fld_mask(kFldCnt));
+                    unsigned int r_surv = nnext + (unsigned int) ((ex >> kShSurv) & fld_mask(kFldSurv));
                     if (!isB && ch >= 0) {
                         unsigned long long pos = off + 1;                        // next bit after the set bit
 #pragma unroll
@@ -337,11 +350,11 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
                     if (surv) nxt[r_surv] = e;
                 }
                 window_flush(bw, stream, stream_words);
-                nbits += tot & 0xFFF;
-                nlsp += (unsigned int) ((tot >> 12) & 0xFFF);
-                nlip += (unsigned int) ((tot >> 24) & 0xFFF);
-                ncur += (unsigned int) ((tot >> 36) & 0xFFF);
-                nnext += (unsigned int) ((tot >> 48) & 0xFFF);
+                nbits += tot & fld_mask(kFldBits);
+                nlsp += (unsigned int) ((tot >> kShLsp) & fld_mask(kFldCnt));
+                nlip += (unsigned int) ((tot >> kShLip) & fld_mask(kFldCnt));
+                ncur += (unsigned int) ((tot >> kShApp) & fld_mask(kFldCnt));
+                nnext += (unsigned int) ((tot >> kShSurv) & fld_mask(kFldSurv));
                 base = chunk_end;
                 if (nbits > budget) stop = true;
             }
@@ -726,6 +739,7 @@ void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned
     ScopedTiming t("spiht_encode", s);
     hipLaunchKernelGGL(k_spiht_encode, dim3(n_frames), dim3(kEncThreads), 0, s, rb.C, rb.D, rb.G, rb.lip, rb.lsp,
                        rb.lis0, rb.lis1, rb.sigord, rb.lspidx, rb.stream, rb.stream_words, rb.g, rb.np, rb.fs, d_bits0, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,
@@ -733,6 +747,7 @@ void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned 
 {
     hipLaunchKernelGGL(k_reconstruct, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, rb.A, rb.np,
                        rb.fs, d_trunc_bits, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const unsigned long long *d_sizes,
@@ -744,6 +759,7 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
     hipLaunchKernelGGL(k_spiht_decode, dim3(n_frames), dim3(kWave), 0, s, d_streams, stream_stride, d_sizes, d_num_bits,
                        rb.C, rb.lip, rb.lsp, rb.lis0, rb.lis1, rb.g, rb.np, rb.fs, d_active);
     hipLaunchKernelGGL(k_int_to_float, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.A, rb.np, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 }  // namespace ebcc

@@ -130,6 +130,7 @@ void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_
 {
     hipLaunchKernelGGL(k_search_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, jf, d_active, n_chunks, tiles, k, n_pix,
                        unfinished);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 void launch_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
@@ -137,6 +138,7 @@ void launch_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long 
 {
     hipLaunchKernelGGL(k_trunc_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, fs, trunc_bits, d_active, n_chunks, n_pix,
                        unfinished);
+    EBCC_HIP_LAUNCH_CHECK();
 }
 
 }  // namespace ebcc

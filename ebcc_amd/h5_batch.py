@@ -84,6 +84,9 @@ class BatchCodec:
         outs = (ctypes.c_void_p * n)()
         sizes = (ctypes.c_size_t * n)()
         if self.lib.ebcc_hip_encode_frames(self.ctx, self.d_buf, n, ctypes.byref(cfg), outs, sizes):
+            for i in range(n):                                   # (streams finished before the failure are still ours to free)
+                if outs[i]:
+                    self.lib.free_buffer(outs[i])
             raise RuntimeError("ebcc_hip_encode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
         res = []
         for i in range(n):

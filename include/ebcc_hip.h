@@ -81,6 +81,11 @@ int ebcc_hip_j2k_emulated_decode(ebcc_hip_ctx *ctx, const float *d_frames, size_
 int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                         const float *minmax, float *d_out);
 
+/* Host-only check of the codestream parser behind the decode path (no device needed): 0 = `cs` is accepted as a one-tile
+ * codestream of height x width and every code-block entry lies inside it, 1 = rejected, 2 = accepted with an entry out of
+ * bounds (never expected).  The reference leaves this to OpenJPEG (/root/reference/src/ebcc_codec.c:1096-1135). */
+int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t width);
+
 /* ---- frame codec -----------------------------------------------------------------------------
  * Batch forms of ebcc_encode / ebcc_decode (src/ebcc_codec.h:41-42) for frames resident in HBM.
  * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
@@ -95,6 +100,11 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
                            uint8_t **out_streams, size_t *out_sizes);
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                            float *d_frames_out);
+
+/* Host threads one slice of an encode call uses for the zstd stage when the call runs as `slices` concurrent slices:
+ * EBCC_HOST_THREADS, else from the CPUs the process may run on - divided by LOCAL_WORLD_SIZE and the slices when the
+ * process is one rank of a multi-process job, so that the ranks of a node share its cores. */
+int ebcc_hip_host_threads(int slices);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).  Names: "t1_encode",
  * "t1_probe_decode", "t1_decode", "rate_alloc", "j2k_dwt_fwd", "spiht_encode".  Process-wide switch. */

@@ -97,3 +97,90 @@ def test_filter_wrapper_mirrors_reference_interface():
     assert hash(f) == hash(EBCC_Filter(30, 721, 1440, ("max_error", 0.5)))
     with pytest.raises(ValueError):
         EBCC_Filter(10, 64, 64, ("lossless", 0))
+
+
+# ---- exit(1) contract of populate_config (/root/reference/src/h5z_ebcc.c:41-92): a fresh child per case
+_POPULATE_CHILD = r"""
+import ctypes, struct, sys
+sys.path.insert(0, {root!r})
+from tests import _lib as L
+lib = ctypes.CDLL(L.PRODUCT_SO)
+lib.populate_config.argtypes = [ctypes.POINTER(L.CodecConfig), ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint), ctypes.c_size_t]
+f2u = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+vals, buf = {vals!r}, {buf!r}
+cd = (ctypes.c_uint * max(1, len(vals)))(*[f2u(v) if isinstance(v, float) else v for v in vals])
+cfg = L.CodecConfig()
+lib.populate_config(ctypes.byref(cfg), len(vals), cd, buf)
+print("returned", tuple(cfg.dims))
+"""
+
+
+@pytest.mark.parametrize("name,vals,buf,ok", [
+    ("valid", [64, 96, 30.0, 1, 0.5], 64 * 96 * 4, True),
+    ("three_values", [64, 96, 30.0], 64 * 96 * 4, False),                     # :41
+    ("height_16", [16, 96, 30.0, 0], 16 * 96 * 4, False),                     # :51-57
+    ("width_4096", [64, 4096, 30.0, 0], 64 * 4096 * 4, False),
+    ("buffer_smaller_than_tile", [64, 96, 30.0, 0], 64 * 95 * 4, False),      # :60-63
+    ("buffer_not_divisible", [64, 96, 30.0, 0], 64 * 96 * 4 * 2 + 4, False),  # :64-68
+    ("frames_times_height_over_2047", [64, 96, 30.0, 0], 64 * 96 * 4 * 32, False),   # :74-79
+    ("mode1_with_4_values", [64, 96, 30.0, 1], 64 * 96 * 4, False),           # :81-92
+    ("mode2_with_4_values", [64, 96, 30.0, 2], 64 * 96 * 4, False),
+])
+def test_populate_config_exit_contract(name, vals, buf, ok):
+    import sys
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    r = subprocess.run([sys.executable, "-c", _POPULATE_CHILD.format(root=ROOT, vals=vals, buf=buf)], capture_output=True, text=True)
+    if ok:
+        assert r.returncode == 0 and "returned (1, 64, 96)" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    else:
+        assert r.returncode == 1 and "returned" not in r.stdout, (name, r.returncode, r.stdout, r.stderr[-300:])
+
+
+# ---- the host-side codestream parser takes hostile input (the reference leaves that to OpenJPEG)
+def test_codestream_parser_rejects_malformed_streams():
+    import numpy as np
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    lib = ctypes.CDLL(L.PRODUCT_SO)
+    lib.ebcc_hip_j2k_parse_check.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
+    lib.ebcc_hip_j2k_parse_check.restype = ctypes.c_int
+    h, w = 100, 130
+    u16, _, _ = L.scale_u16(L.era5_like(h, w, 5))
+    good = L.orc_j2k_encode(u16, 8.0)
+    assert lib.ebcc_hip_j2k_parse_check(good, len(good), h, w) == 0
+    assert lib.ebcc_hip_j2k_parse_check(good, len(good), h, w + 1) == 1            # another geometry
+    r = np.random.default_rng(7)
+    verdicts = {0: 0, 1: 0}
+    cases = [good[:k] for k in list(range(0, 200)) + [len(good) // 2, len(good) - 3, len(good) - 1]]
+    for _ in range(3000):
+        b = bytearray(good)
+        for _ in range(int(r.integers(1, 4))):
+            pos = int(r.integers(0, min(len(b), 600) if r.random() < 0.7 else len(b)))
+            b[pos] = int(r.integers(0, 256)) if r.random() < 0.5 else b[pos] ^ (1 << int(r.integers(0, 8)))
+        cases.append(bytes(b))
+    for k in range(2, 160, 2):                                                    # every marker length field, maximal
+        b = bytearray(good); b[k:k + 2] = b"\xff\xff"; cases.append(bytes(b))
+    for c in cases:
+        v = lib.ebcc_hip_j2k_parse_check(c, len(c), h, w)
+        assert v in (0, 1), "parser accepted an out-of-bounds table entry"
+        verdicts[v] += 1
+    assert verdicts[1] > 200 and verdicts[0] > 0                                  # both verdicts occur; no crash on the way
+
+
+def test_host_thread_budget_per_rank():
+    """One rank of a multi-process job keeps its compressing threads within cpus / LOCAL_WORLD_SIZE (all slices together)."""
+    import sys
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    child = ("import ctypes, os; lib = ctypes.CDLL(%r); lib.ebcc_hip_host_threads.restype = ctypes.c_int; "
+             "print(lib.ebcc_hip_host_threads(1), lib.ebcc_hip_host_threads(4), len(os.sched_getaffinity(0)))" % L.PRODUCT_SO)
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "EBCC_HOST_THREADS")}
+    one, four, cpus = map(int, subprocess.check_output([sys.executable, "-c", child], env=env).split())
+    assert one == four == min(32, max(4, cpus))                                   # stand-alone: the measured burst setting
+    env["LOCAL_WORLD_SIZE"] = "8"
+    one, four, cpus = map(int, subprocess.check_output([sys.executable, "-c", child], env=env).split())
+    share = max(1, cpus // 8)
+    assert one == share and 1 <= four and 4 * four <= max(4, share)
+    env["EBCC_HOST_THREADS"] = "3"
+    assert int(subprocess.check_output([sys.executable, "-c", child], env=env).split()[0]) == 3

@@ -365,3 +365,110 @@ def test_invalid_dims_return_zero():
     cfg = L.make_config((1, 16, 16))
     out = ctypes.c_void_p()
     assert lib.ebcc_encode(data.ctypes.data, ctypes.byref(cfg), ctypes.byref(out)) == 0
+
+
+# ---- contracts that end the process or depend on its environment: a fresh child per case -----------------------
+_CHILD = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from tests import _lib as L
+lib = L.product()
+shape = {shape!r}
+frames = np.stack([L.era5_like(shape[1], shape[2], 40 + s, 1.1, 0.7) for s in range(shape[0])]).astype(np.float32)
+{prep}
+cfg = L.make_config(shape, {chunk!r}, base_cr=20.0, error=0.05, residual_type=L.MAX_ERROR)
+out = ctypes.c_void_p()
+n = getattr(lib, {fn!r})(np.ascontiguousarray(frames).ctypes.data, ctypes.byref(cfg), ctypes.byref(out))
+print("RETURNED", n)
+if n:
+    s = ctypes.string_at(out.value, n)
+    import hashlib
+    print("SHA", hashlib.sha256(s).hexdigest())
+    dec = ctypes.c_void_p()
+    b = ctypes.create_string_buffer(s, len(s))
+    m = getattr(lib, {dfn!r})(b, len(s), ctypes.byref(dec))
+    print("DECODED", m, hashlib.sha256(ctypes.string_at(dec.value, 4 * m)).hexdigest() if m else "-")
+"""
+
+
+def _child(env=None, shape=(1, 64, 96), chunk=None, prep="", fn="ebcc_encode", dfn="ebcc_decode"):
+    import os
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if not k.startswith("EBCC_HIP_")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=L.ROOT, shape=shape, chunk=chunk, prep=prep, fn=fn, dfn=dfn)],
+                       capture_output=True, text=True, env=e, timeout=600)
+    return r
+
+
+@pytest.mark.parametrize("bad", ["nan", "inf", "-inf"])
+def test_nan_inf_input_exits_with_status_1(bad):
+    """check_nan_inf, /root/reference/src/ebcc_codec.c:598-605: log_fatal + exit(1)."""
+    r = _child(prep=f"frames[0, 10, 17] = float({bad!r})")
+    assert r.returncode == 1 and "RETURNED" not in r.stdout, (r.returncode, r.stdout, r.stderr[-400:])
+    assert "NaN or Inf" in r.stderr
+    r = _child(shape=(6, 64, 96), chunk=(1, 64, 96), prep=f"frames[4, 3, 3] = float({bad!r})", fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    assert r.returncode == 1 and "RETURNED" not in r.stdout
+
+
+def test_failed_device_allocation_returns_zero():
+    """An allocation that fails inside the engine makes the entry point log and return 0 (reference convention,
+    /root/reference/src/ebcc_codec.c:613-617); the process survives.  EBCC_HIP_FAIL_ALLOC=<n> fails the n-th one."""
+    ok = _child()
+    assert ok.returncode == 0 and "RETURNED 0" not in ok.stdout and "DECODED 6144" in ok.stdout, ok.stderr[-400:]
+    for nth in (1, 5, 40, 70):                                      # engine workspaces, the tier-1 buffers, the i/o buffer ...
+        r = _child(env={"EBCC_HIP_FAIL_ALLOC": str(nth)})
+        assert r.returncode == 0, (nth, r.returncode, r.stderr[-400:])
+        assert "RETURNED 0" in r.stdout or ok.stdout.split("SHA")[1][:70] in r.stdout, (nth, r.stdout)   # (failed cleanly, or the n-th allocation was never reached)
+    assert "RETURNED 0" in _child(env={"EBCC_HIP_FAIL_ALLOC": "1"}).stdout
+
+
+def test_device_selection_and_multi_device_chunking():
+    """EBCC_HIP_DEVICE / EBCC_HIP_DEVICES choose where the reference API runs; the chunk list of the chunking entry points
+    is spread over the devices of the list (contiguous blocks, results in chunk order): same bytes on any device count."""
+    shape, chunk = (10, 64, 96), (1, 64, 96)
+    runs = {}
+    for name, env in (("dev0", {"EBCC_HIP_DEVICES": "0"}), ("all", {"EBCC_HIP_DEVICES": "all"}), ("default", {}),
+                      ("rank", {"LOCAL_WORLD_SIZE": "8", "EBCC_HIP_DEVICE": "0"})):
+        r = _child(env=env, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+        assert r.returncode == 0 and "SHA" in r.stdout, (name, r.stderr[-400:])
+        runs[name] = r.stdout
+    assert runs["dev0"] == runs["all"] == runs["default"] == runs["rank"]
+    n = L.product().ebcc_hip_device_count()
+    if n > 1:                                                       # the last device alone, and the caller's current device is restored
+        r = _child(env={"EBCC_HIP_DEVICE": str(n - 1)}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+        assert r.stdout == runs["dev0"]
+
+
+def test_host_and_device_search_loops_agree(monkeypatch):
+    """The device-side state machines of the rate search and the truncation bisection (search.hpp) against the host
+    loops they replace, and batches of rounds too short for a search (more rounds are enqueued then)."""
+    frames = np.stack([L.era5_like(96, 160, 700 + s, 1.0 + 0.15 * (s % 3), 0.5 + 0.2 * (s % 4)) for s in range(9)])
+    for mode, err in ((L.MAX_ERROR, 0.03), (L.RELATIVE_ERROR, 2e-3)):
+        cfg = L.make_config((1, 96, 160), base_cr=40.0, error=err, residual_type=mode)
+        got = {}
+        for name, env in (("device", {}), ("host", {"EBCC_HIP_HOST_SEARCH": "1"}), ("short", {"EBCC_HIP_SEARCH_ROUNDS": "3"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with L.Context(len(frames), 96, 160) as ctx:
+                got[name] = ctx.encode_frames(frames, cfg)
+            for k in env:
+                monkeypatch.delenv(k)
+        assert got["device"] == got["host"] == got["short"], mode
+        L.oracle().orc_set_j2k_backend(0)
+        assert got["device"][3] == L.orc_encode(frames[3], cfg)
+
+
+def test_tier1_retry_when_decisions_outgrow_their_rows(monkeypatch):
+    """EBCC_HIP_SYM_ROWS shrinks the decision buffer of the segmented tier-1 encoder: the engine notices (J2kFrame::overflow
+    bit 1) and codes the batch again with the single-kernel encoder - same streams."""
+    frames = np.stack([L.era5_like(96, 160, 900 + s, 1.1, 0.9) for s in range(5)])
+    cfg = L.make_config((1, 96, 160), base_cr=12.0, error=0.05, residual_type=L.MAX_ERROR)
+    with L.Context(len(frames), 96, 160) as ctx:
+        want = ctx.encode_frames(frames, cfg)
+    monkeypatch.setenv("EBCC_HIP_SYM_ROWS", "40")
+    with L.Context(len(frames), 96, 160) as ctx:
+        got = ctx.encode_frames(frames, cfg)
+    assert got == want

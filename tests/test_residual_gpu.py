@@ -69,3 +69,18 @@ def test_prefix_reconstruction_matches_real_decode(shape):
             for f, s in enumerate(streams):
                 ref = L.orc_spiht_decode(s[:nbytes[f]], h, w, 8 * nbytes[f])
                 assert np.array_equal(got[f], ref), (frac, f)
+
+
+def test_dense_planes_bit_exact():
+    """Every child of every set of a sweep significant on one bit-plane: 9 bits per list entry, the most a sweep of the
+    encoder can produce (its packed scan fields once overflowed there)."""
+    h, w = 128, 256
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = np.stack([((xx + yy) % 2).astype(np.float32), ((xx // 2 + yy // 2) % 2).astype(np.float32),
+                     (0.5 + 0.5 * ((xx % 2) * 2 - 1) * ((yy % 2) * 2 - 1) * (0.25 + 0.75 * ((xx * 7 + yy * 13) % 5) / 4)).astype(np.float32)])
+    for tb in (0, 8 * (h * w // 2)):
+        with L.Context(len(imgs), h, w) as ctx:
+            got = ctx.spiht_encode(imgs, [tb] * len(imgs))
+        for f, img in enumerate(imgs):
+            ref = L.orc_spiht_encode(img, tb)
+            assert got[f] == ref, (tb, f)

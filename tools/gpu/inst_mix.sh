@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/inst
 rm -rf $O && mkdir -p $O
 for C in SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES; do
-  EBCC_HIP_SLICES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 bench.py --steps 1 --warmup 1 --frames 64 --no-cpu-baseline > $O/$C.log 2>&1
+  EBCC_HIP_SLICES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 bench.py --steps 1 --warmup 1 --frames 64 --no-cpu-baseline --no-extras > $O/$C.log 2>&1
   echo "$C rc=$?"
   c=$(find $O/$C -name "*counter_collection.csv" | head -1)
   [ -n "$c" ] && python3 tools/pmc_summary.py "$c" $C 64 > $O/$C.json

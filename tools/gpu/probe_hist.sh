@@ -1,4 +1,4 @@
-EBCC_LOG_LEVEL=0 EBCC_HIP_SLICES=1 python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline 2> gpurun_out/trace.txt > /dev/null
+EBCC_LOG_LEVEL=0 EBCC_HIP_SLICES=1 python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras 2> gpurun_out/trace.txt > /dev/null
 python - <<'PY'
 import re,collections
 per=collections.defaultdict(lambda: [0,0]); crs=collections.defaultdict(list)

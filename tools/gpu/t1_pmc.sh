@@ -7,7 +7,7 @@ F=${2:-64}
 O=gpurun_out/t1pmc
 rm -rf $O && mkdir -p $O
 for C in SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT; do
-  EBCC_HIP_SLICES=1 EBCC_HIP_T1_STATS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 bench.py --steps 1 --warmup 1 --frames $F --no-cpu-baseline > $O/$C.log 2>&1
+  EBCC_HIP_SLICES=1 EBCC_HIP_T1_STATS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 bench.py --steps 1 --warmup 1 --frames $F --no-cpu-baseline --no-extras > $O/$C.log 2>&1
   echo "$C rc=$?"
   c=$(find $O/$C -name "*counter_collection.csv" | head -1)
   [ -n "$c" ] && python3 tools/pmc_summary.py "$c" $C $F > $O/$C.json

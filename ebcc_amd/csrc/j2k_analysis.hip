@@ -455,6 +455,95 @@ __global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const
     }
 }
 
+// The last inverse column pass as a STREAM: one thread per column walks down the rows with the four lifting steps as a
+// register pipeline two samples deep, so every global access is a full row segment (64 columns = 256 B per wave) and
+// nothing goes through LDS.  Possible because this pass does not write in place (its result becomes the fp32 field
+// or only the statistics); the expressions, their order and the boundary forms are those of idwt_tile for a line that
+// starts with a low-pass sample (cas == 0: every frame that is not a tile at an odd offset).
+__device__ inline float fin_map(float v, float rng, float mn)
+{
+    long long q;
+    if (v > 2147483647.0f) q = 65535;
+    else if (v < -2147483648.0f) q = 0;
+    else {
+        q = (long long) __float2int_rn(v) + 32768;
+        q = q < 0 ? 0 : (q > 65535 ? 65535 : q);
+    }
+    return ((float) (int) q / 65535.0f) * rng + mn;
+}
+constexpr int kFinT = 128;           // columns per workgroup
+__global__ __launch_bounds__(kFinT) void k_j2k_cols_fin(const float *__restrict__ B, const J2kGeom *geom, int r, const FrameState *fs,
+                                                         const int *active, J2kFinish fin)
+{
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    const int W = g.W, n = g.rh[r], sn = g.rh[r - 1], cols = g.rw[r], dn = n - sn;
+    const size_t n_pix = (size_t) W * g.H;
+    const int col = blockIdx.x * kFinT + threadIdx.x;
+    const bool live = col < cols;
+    const float *lo = B + (size_t) frame * n_pix + (live ? col : 0), *hi = lo + (size_t) sn * W;
+    const float *x = fin.data ? fin.data + (size_t) frame * n_pix + (live ? col : 0) : nullptr;
+    float *d = fin.DEC ? fin.DEC + (size_t) frame * n_pix + (live ? col : 0) : nullptr;       // (null: statistics only)
+    const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
+    const float target = x ? fin.jf[frame].target : 0.0f;
+    const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
+    double acc = 0;
+    unsigned int bad = 0;
+    auto out = [&](int y, float v) {
+        const float dv = fin_map(v, rng, mn);
+        if (d) d[(size_t) y * W] = dv;
+        if (x) {
+            const float e = x[(size_t) y * W] - (dv + 0.0f);
+            acc += (double) e;
+            if (fabsf(e) > target) bad++;
+        }
+    };
+    if (live) {
+        // e0/o0: scaled inputs; e1, o1, e2, o2: after lifting steps 1..4 (istep_lo -kD, istep_hi -kG, istep_lo -kB, istep_hi -kA)
+        float o0_prev = 0, e1_prev = 0, o1_prev = 0, o1_prev2 = 0, e2_prev = 0;
+        // j runs two past the end: position j enters the pipeline, position j - 2 leaves it
+        for (int j = 0; j < sn + 2; j++) {
+            float e1 = 0, o0 = 0;
+            if (j < sn) {
+                const float e0 = lo[(size_t) j * W] * kK;
+                if (j < dn) o0 = hi[(size_t) j * W] * kTwoInvK;
+                if (j < dn) e1 = e0 + (((j == 0 ? o0 : o0_prev) + o0) * c1);
+                else        e1 = e0 + (o0_prev * (c1 + c1));
+            }
+            // o1[j - 1] = o0[j - 1] + (e1[j - 1] + e1[j]) * c2, boundary form when e1[j] does not exist
+            float o1 = 0;
+            const int i1 = j - 1;
+            if (i1 >= 0 && i1 < dn) o1 = (i1 + 1 < sn) ? o0_prev + ((e1_prev + e1) * c2) : o0_prev + (e1_prev * (c2 + c2));
+            // e2[j - 1] = e1[j - 1] + (o1[j - 2] + o1[j - 1]) * c3   (o1[-1] := o1[0])
+            float e2 = 0;
+            if (i1 >= 0 && i1 < sn) e2 = (i1 < dn) ? e1_prev + (((i1 == 0 ? o1 : o1_prev) + o1) * c3) : e1_prev + (o1_prev * (c3 + c3));
+            // o2[j - 2] = o1[j - 2] + (e2[j - 2] + e2[j - 1]) * c4
+            const int i2 = j - 2;
+            if (i2 >= 0) {
+                if (i2 < sn) out(2 * i2, e2_prev);
+                if (i2 < dn) out(2 * i2 + 1, (i2 + 1 < sn) ? o1_prev + ((e2_prev + e2) * c4) : o1_prev + (e2_prev * (c4 + c4)));
+            }
+            o0_prev = o0; e1_prev = e1; o1_prev2 = o1_prev; o1_prev = o1; e2_prev = e2;
+        }
+        (void) o1_prev2;
+    }
+    if (x) {
+        __shared__ double red[kFinT / 64];
+        __shared__ unsigned int redu[kFinT / 64];
+        for (int k = 32; k >= 1; k >>= 1) { acc += __shfl_xor(acc, k); bad += __shfl_xor(bad, k); }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = acc; redu[threadIdx.x >> 6] = bad; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0;
+            unsigned long long b = 0;
+            for (int k = 0; k < kFinT / 64; k++) { a += red[k]; b += redu[k]; }
+            fin.partial[(size_t) frame * kPartials + blockIdx.x] = a;
+            fin.partial_u[(size_t) frame * kPartials + blockIdx.x] = b;
+        }
+    }
+}
+
 template <typename K>
 void big_lds(K k, size_t bytes)
 {
@@ -478,6 +567,14 @@ int dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameSta
 {
     const int n = max_rows(jb, r), cols = jb.geom.rw[r];
     if (n <= 1) return 0;
+    if constexpr (FIN && !FWD) {
+        // plain frames (every column starts with a low-pass sample): the streaming form; EBCC_HIP_FIN_LDS=1 keeps the LDS tiles
+        static const bool lds_form = getenv("EBCC_HIP_FIN_LDS") != nullptr;
+        if (jb.geom.period == 1 && jb.geom.ry0[r] % 2 == 0 && !lds_form) {
+            hipLaunchKernelGGL(k_j2k_cols_fin, dim3(ceil_div(cols, kFinT), n_frames), dim3(kFinT), 0, s, B, jb.d_geom, r, fs, active, fin);
+            return ceil_div(cols, kFinT);
+        }
+    }
     if ((size_t) n * 32 * 4 <= 156 * 1024) {
         size_t lds = (size_t) n * 32 * 4;
         auto k = k_j2k_cols<FWD, 32, FIN>;
@@ -499,62 +596,73 @@ void dwt_rows(float *B, const int32_t *V, const J2kBuffers &jb, int r, int n_fra
 }
 
 // ================================================================================================
-// quantisation -> Q6 + bit-plane row masks (one workgroup per code-block, one wave per row)
+// quantisation -> Q6 + bit-plane row masks.  One workgroup per GROUP of 64 code-blocks (the unit the masks are
+// interleaved in): for every row index y the waves ballot the y-th row of each code-block of the group into LDS, and
+// the 64 masks of a (plane, y) - one per code-block, 512 contiguous bytes - leave as one full line.
 // ================================================================================================
+constexpr int kQuantMasks = kJ2kMaxPlanes + 1 + (kJ2kMaxPlanes + 2);     // bit-planes, sign, suffix-ORs
 __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, int32_t *__restrict__ Q6,
                                                    unsigned long long *__restrict__ BP, unsigned long long *__restrict__ SGN,
                                                    unsigned long long *__restrict__ SUF, int *__restrict__ blkmax, const J2kGeom *geom, const J2kBlock *blocks,
-                                                   const FrameState *fs)
+                                                   const FrameState *fs, int total)
 {
-    __shared__ int smax[4];
-    const int frame = blockIdx.y, bi = blockIdx.x;
-    if (fs[frame].const_field) return;
-    const int gid = frame * geom->stride + bi;
-    blocks = j2k_frame_blocks(geom, blocks, frame);                   // (slots past the tile's last code-block hold empty ones)
-    geom = &j2k_frame_geom(geom, frame);
-    const J2kBlock blk = blocks[bi];
-    const float step = geom->bands[blk.band].step_enc;
-    const int W = geom->W;
-    const size_t n_pix = (size_t) W * geom->H;
-    const float *b = B + (size_t) frame * n_pix;
-    int32_t *q = Q6 + (size_t) frame * n_pix;
-    const size_t grp = (size_t) (gid >> 6);
-    const int gl = gid & 63;
+    __shared__ unsigned long long m[kQuantMasks][64];                   // [mask][code-block of the group]
+    __shared__ int smax[64];
+    const size_t grp = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int mx = 0;
-    for (int row = wave; row < 64; row += 4) {
-        const bool valid = row < blk.h && lane < blk.w;
-        int q6 = 0;
-        if (valid) {
-            size_t p = (size_t) (blk.y + row) * W + blk.x + lane;
-            q6 = __float2int_rn((b[p] / step) * 64.0f);             // lrintf((c / stepsize) * 64), opj_t1_encode_cblks
-            q[p] = q6;
-        }
-        int a6 = q6 < 0 ? -q6 : q6;
-        mx = a6 > mx ? a6 : mx;
-        unsigned long long sg = __ballot(q6 < 0);
-        if (lane == 0) SGN[(grp * 64 + row) * 64 + gl] = sg;
-        const int a = a6 >> 6;
-        unsigned long long suf = 0;                                 // OR of the planes >= p: "some bit at or above p"
-        if (lane == 0) {
-            SUF[((grp * (kJ2kMaxPlanes + 2) + kJ2kMaxPlanes + 1) * 64 + row) * 64 + gl] = 0;
-            SUF[((grp * (kJ2kMaxPlanes + 2) + kJ2kMaxPlanes) * 64 + row) * 64 + gl] = 0;
-        }
-        for (int p = kJ2kMaxPlanes - 1; p >= 0; p--) {
-            unsigned long long m = __ballot((a >> p) & 1);
-            suf |= m;
+    const int nb = geom->stride;
+    if (threadIdx.x < 64) smax[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long *bp = BP + grp * kJ2kMaxPlanes * 64 * 64, *sg = SGN + grp * 64 * 64, *su = SUF + grp * (kJ2kMaxPlanes + 2) * 64 * 64;
+    for (int row = 0; row < 64; row++) {
+        for (int k = wave; k < 64; k += 4) {                             // the code-blocks of the group, 16 per wave
+            const int gid = (int) (grp * 64) + k;
+            int q6 = 0;
+            if (gid < total) {
+                const int frame = gid / nb;
+                if (!fs[frame].const_field) {
+                    const J2kBlock blk = j2k_frame_blocks(geom, blocks, frame)[gid - frame * nb];   // (slots past the tile's last code-block hold empty ones)
+                    const J2kGeom &g = j2k_frame_geom(geom, frame);
+                    if (row < blk.h && lane < blk.w) {
+                        const size_t p = (size_t) frame * ((size_t) g.W * g.H) + (size_t) (blk.y + row) * g.W + blk.x + lane;
+                        q6 = __float2int_rn((B[p] / g.bands[blk.band].step_enc) * 64.0f);      // lrintf((c / stepsize) * 64), opj_t1_encode_cblks
+                        Q6[p] = q6;
+                    }
+                }
+            }
+            const int a6 = q6 < 0 ? -q6 : q6;
+            int mx = a6;
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+            const unsigned long long sgn = __ballot(q6 < 0);
+            const int a = a6 >> 6;
+            unsigned long long suf = 0;                                  // OR of the planes >= p: "some bit at or above p"
             if (lane == 0) {
-                BP[((grp * kJ2kMaxPlanes + p) * 64 + row) * 64 + gl] = m;
-                SUF[((grp * (kJ2kMaxPlanes + 2) + p) * 64 + row) * 64 + gl] = suf;
+                if (mx > smax[k]) smax[k] = mx;                          // (this wave owns code-block k)
+                m[kJ2kMaxPlanes][k] = sgn;
+                m[kJ2kMaxPlanes + 1 + kJ2kMaxPlanes + 1][k] = 0;
+                m[kJ2kMaxPlanes + 1 + kJ2kMaxPlanes][k] = 0;
+            }
+            for (int p = kJ2kMaxPlanes - 1; p >= 0; p--) {
+                const unsigned long long bits = __ballot((a >> p) & 1);
+                suf |= bits;
+                if (lane == 0) { m[p][k] = bits; m[kJ2kMaxPlanes + 1 + p][k] = suf; }
             }
         }
+        __syncthreads();
+        for (int t = threadIdx.x; t < kQuantMasks * 64; t += 256) {
+            const int i = t >> 6, k = t & 63;
+            const unsigned long long v = m[i][k];
+            if (i < kJ2kMaxPlanes) bp[((size_t) i * 64 + row) * 64 + k] = v;
+            else if (i == kJ2kMaxPlanes) sg[(size_t) row * 64 + k] = v;
+            else su[((size_t) (i - kJ2kMaxPlanes - 1) * 64 + row) * 64 + k] = v;
+        }
+        __syncthreads();
     }
-    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-    if (lane == 0) smax[wave] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) blkmax[gid] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    if (threadIdx.x < 64) {
+        const int gid = (int) (grp * 64) + (int) threadIdx.x;
+        if (gid < total) blkmax[gid] = smax[threadIdx.x];
+    }
 }
-
 
 // MQ state table in LDS (see t1_core.hpp ConstTable): filled by the first 47 lanes of the workgroup
 struct LdsTable {
@@ -1137,8 +1245,8 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
         if (g.rw[r] > 1) dwt_rows<true>(jb.B, nullptr, jb, r, n_frames, fs, nullptr, s);
     }
     timing_end("j2k_dwt_fwd", s);
-    hipLaunchKernelGGL(k_quantize, dim3(g.stride, n_frames), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
-                       jb.d_geom, jb.d_blocks, fs);
+    hipLaunchKernelGGL(k_quantize, dim3((unsigned) (((size_t) total + 63) / 64)), dim3(256), 0, s, jb.B, jb.Q6, jb.BP, jb.SGN, jb.SUF, jb.blkmax,
+                       jb.d_geom, jb.d_blocks, fs, total);
     launch_j2k_tier1(jb, n_frames, s, false);
     EBCC_HIP_LAUNCH_CHECK();
 }

@@ -13,6 +13,7 @@
 
 #include "j2k.hpp"
 #include "t1_core.hpp"
+#include "t1_device.hpp"
 
 namespace ebcc {
 
@@ -941,16 +942,6 @@ __global__ __launch_bounds__(64) void k_t1_emit(const unsigned long long *BP, co
 }
 
 // ---- arithmetic coding of the row streams: one wave per group, a code-block per lane (t1::mq_encode_rows)
-struct LdsTable2 {
-    // t1::mq_entry2 for every state code, 8 bytes per entry; the code IS the entry's byte offset
-    uint32_t base;                 // LDS byte address of the table
-    __device__ void operator()(uint32_t code, uint32_t &qe, uint32_t &next) const
-    {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 e = *(const __attribute__((address_space(3))) u32x2 *) (uintptr_t) (base + code);
-        qe = e.x; next = e.y;
-    }
-};
 // The rows come through LDS: the workgroup's second wave (the loader) copies them from HBM kRowChunk rows at a time
 // into one half of a double buffer while the coder wave works on the other, with a workgroup barrier per chunk.  The
 // coder wave therefore never waits for vector memory: its own global accesses are stores only (checkpoints, bytes,
@@ -969,22 +960,6 @@ struct RowSrcDev {
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     }
     __device__ bool any(bool b) const { return __any(b) != 0; }
-};
-struct CtxLds2 {
-    // the state codes of every lane, a dword slot each (code in its low half): context c of lane l at (c * 64 + l) * 4,
-    // so a handle - the byte address - is one shift-add away from the decision byte and the bank is the lane
-    uint32_t base;                 // LDS byte address of this lane's context 0
-    __device__ uint32_t handle(uint32_t c) const { return base + (c << 8); }
-    __device__ uint32_t ld(uint32_t h) const { return *(const __attribute__((address_space(3))) unsigned short *) (uintptr_t) h; }
-    __device__ void st(uint32_t h, uint32_t v) { *(__attribute__((address_space(3))) unsigned short *) (uintptr_t) h = (unsigned short) v; }
-    __device__ void words(uint32_t x[5]) const
-    {
-        for (int j = 0; j < 5; j++) {
-            uint32_t v = 0;
-            for (int k = 0; k < 4; k++) if (4 * j + k < t1::NCTX) v |= t1::mq_code_state(ld(handle((uint32_t) (4 * j + k)))) << (8 * k);
-            x[j] = v;
-        }
-    }
 };
 struct MqSinkLds {
     // coded bytes go into a 64-byte ring per lane in LDS (lane stride 68 bytes: lanes at the same offset never

@@ -13,6 +13,8 @@
 
 #include "j2k.hpp"
 #include "t1_core.hpp"
+#include "t1_decode.hpp"
+#include "t1_device.hpp"
 
 namespace ebcc {
 
@@ -981,6 +983,82 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
 }
 
 
+// ---- the same decode with the segment-locked decoder (t1_decode.hpp): one wave per group of 64 code-blocks, a
+// code-block per lane, every lane in the same (bit-plane, pass, stripe).  The bytes of a code-block's segment come
+// through a 256-byte ring per lane in LDS that the wave tops up at the start of every coding pass (and whenever a lane
+// runs short): the decision loops read LDS only.
+constexpr int kRingBytes = 256, kRingStride = 272;                       // (16-byte aligned rows for the 128-bit LDS stores)
+struct RingBytes {
+    const uint8_t *base;           // 16-byte aligned address at or before the segment's first byte
+    uint32_t ring;                 // LDS byte address of this lane's ring
+    int a0, len, filled;           // offset of the first byte inside its aligned chunk; segment bytes; bytes (from base) in the ring
+    __device__ uint32_t get(int i) const
+    {
+        if (i >= len) return 0xFFu;                                     // C.3.4: past the end of the segment
+        return *(const __attribute__((address_space(3))) unsigned char *) (uintptr_t) (ring + (((uint32_t) (i + a0)) & (kRingBytes - 1)));
+    }
+    // 16-byte chunks from global memory while the ring has room behind the decoder's position `pos`
+    __device__ void top_up(int pos)
+    {
+        while (filled < len + a0 && filled + 16 - (pos + a0) <= kRingBytes) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = *(const u32x4 *) (base + filled);
+            *(__attribute__((address_space(3))) u32x4 *) (uintptr_t) (ring + ((uint32_t) filled & (kRingBytes - 1))) = v;
+            filled += 16;
+        }
+    }
+};
+struct DecEnv {
+    RingBytes src;
+    __device__ bool any(bool b) const { return __any(b) != 0; }
+    __device__ RingBytes &bytes() { return src; }
+    __device__ bool starved(int pos) const { return pos + src.a0 >= src.filled && src.filled < src.len + src.a0; }
+    __device__ void refill_point(int pos) { src.top_up(pos); }
+    __device__ void pass_point(int pos) { src.top_up(pos); }
+};
+
+__global__ __launch_bounds__(64) void k_t1_decode_seg(unsigned long long *T1S, const uint8_t *bytes, size_t stream_cap,
+                                                       const int *dec_table, int32_t *V, const J2kGeom *geom,
+                                                       const J2kBlock *blocks, const FrameState *fs, int total)
+{
+    __shared__ uint2 tab_store[128];
+    __shared__ uint32_t ctxw[32 * 64];
+    __shared__ uint32_t rings[64 * kRingStride / 4];
+    fill_mq_table2(tab_store);
+    __syncthreads();
+    const LdsTable2 tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
+    const size_t grp = blockIdx.x;
+    const int gid = (int) (grp * 64) + (int) threadIdx.x;
+    int len = 0, P = 0, np = 0, w = 1, h = 1, orient = 0;
+    const uint8_t *src = bytes;
+    int32_t *v = V;
+    int W = 1;
+    if (gid < total) {
+        const int nb = geom->stride;
+        const int frame = gid / nb, bi = gid - frame * nb;
+        if (!fs[frame].const_field) {
+            const J2kGeom &g = j2k_frame_geom(geom, frame);
+            const J2kBlock blk = j2k_frame_blocks(geom, blocks, frame)[bi];
+            const int *e = dec_table + (size_t) gid * 4;
+            len = e[1]; P = e[2]; np = e[3];
+            if (np <= 0 || P <= 0) { P = 0; np = 0; len = 0; }
+            src = bytes + (size_t) frame * stream_cap + e[0];
+            w = blk.w; h = blk.h; orient = g.bands[blk.band].orient; W = g.W;
+            v = V + (size_t) frame * g.W * g.H + (size_t) blk.y * g.W + blk.x;
+        }
+    }
+    int pmax = P;
+    for (int d = 32; d >= 1; d >>= 1) pmax = max(pmax, __shfl_xor(pmax, d));
+    pmax = __builtin_amdgcn_readfirstlane(pmax);
+    if (pmax <= 0) return;
+    DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), threadIdx.x * 8u, v, W};
+    CtxLds2 cx{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + threadIdx.x * 4u};
+    const int a0 = (int) ((uintptr_t) src & 15);
+    DecEnv env{RingBytes{src - a0, (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) rings + threadIdx.x * kRingStride, a0, len, 0}};
+    env.src.top_up(0);                                                   // (the decoder's first bytes)
+    t1::decode_block_segments(st, cx, tab, env, w, h, orient, P, np, pmax);
+}
+
 // ================================================================================================
 // rate-probe decode, restarted at the last coding pass the layer keeps
 //   k_probe_plan : per code-block, the restart pass r (last kept pass, or an earlier one if the checkpoint there
@@ -1202,9 +1280,18 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
     timing_begin("t1_decode", s);
-    const int lpw = t1_lanes_per_wave(T1_DECODE);
-    hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
-                       jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
+    // EBCC_HIP_T1_DECODE_SEG=1: the segment-locked decoder (t1_decode.hpp) - identical results, 64 code-blocks per wave;
+    // measured 67 ms per 256 frames against 29 ms for the per-sample decoder at 4 code-blocks per wave (its decision loop
+    // is still ~600 instructions), so it is not the default
+    static const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
+    if (seg_decoder) {
+        hipLaunchKernelGGL(k_t1_decode_seg, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap, jb.dec_table, jb.V,
+                           jb.d_geom, jb.d_blocks, jb.fs, total);
+    } else {
+        const int lpw = t1_lanes_per_wave(T1_DECODE);
+        hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
+                           jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
+    }
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);
     EBCC_HIP_LAUNCH_CHECK();

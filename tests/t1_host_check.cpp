@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../ebcc_amd/csrc/t1_core.hpp"
+#include "../ebcc_amd/csrc/t1_decode.hpp"
 
 extern "C" {
 int orc_j2k_t1_encode(const int32_t *q, int w, int h, int orient, int level, float stepsize, uint8_t *out, int out_cap,
@@ -116,6 +117,7 @@ struct CtxCodes { uint16_t *b; uint32_t handle(uint32_t c) const { return c; } u
                   void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= mq_code_state(b[i]) << (8 * (i & 3)); } };
 struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end(int) {} void finish(int n) { v->resize((size_t) n); } };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
+struct HostEnv { BufSrc src; bool any(bool b) const { return b; } BufSrc &bytes() { return src; } bool starved(int) const { return false; } void refill_point(int) {} void pass_point(int) {} };
 
 int main(int argc, char **argv)
 {
@@ -298,6 +300,21 @@ int main(int argc, char **argv)
             ds.out = d2.data(); ds.w = w;
             decode_block(ds, BufSrc{bytes.data(), len}, w, h, orient, numbps, np);
             if (d1 != d2) { printf("trial %d DECODE mismatch np %d/%d\n", t, np, opasses); bad++; break; }
+            {                                                             // the segment-locked decoder (t1_decode.hpp)
+                std::vector<int32_t> d4((size_t) w * h, 0);
+                HostStore ss;
+                ss.out = d4.data(); ss.w = w;
+                uint16_t codes[32];
+                CtxCodes cc{codes};
+                HostEnv env{BufSrc{bytes.data(), len}};
+                ConstTable2 tab2;
+                decode_block_segments(ss, cc, tab2, env, w, h, orient, numbps, np, numbps + (int) (rng() % 3));
+                if (d1 != d4) {
+                    size_t k2 = 0; while (k2 < d1.size() && d1[k2] == d4[k2]) k2++;
+                    printf("trial %d SEGMENT DECODER mismatch np %d/%d (w %d h %d orient %d P %d) first at (%zu,%zu): %d vs %d\n", t, np, opasses, w, h, orient, numbps, k2 % w, k2 / w, d1[k2], d4[k2]);
+                    bad++; break;
+                }
+            }
             // ---- resume at the last coded plane from a checkpoint of the FULL-segment decode
             static Obs obs;
             obs.nstr = nstr;

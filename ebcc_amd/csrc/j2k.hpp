@@ -72,18 +72,19 @@ constexpr int kJ2kSegCount = kJ2kMaxPlanes * 3 * 16;           // segments of a 
 constexpr int kJ2kSymRows = (4096 * (kJ2kMaxPlanes + 2)) / 16 + kJ2kSegCount;   // 16-decision rows of a code-block's stream: decisions (a zero-coding / refinement decision per sample and plane, a sign, at most 3 run-length decisions per column and stripe) + one partial row per segment
 constexpr int kJ2kCkptPerBlock = kJ2kMaxPasses * 16;   // checkpoint slots of one code-block (pass-major, then stripe)
 
-// Checkpoint storage: nine words per slot (a, c, ct, pos, then the 19 context states one byte each in five words),
-// lane-interleaved inside a group of 64 code-blocks like every other per-code-block array of tier-1:
-// [group][slot = pass * 16 + stripe][word][lane].  The MQ pass stores the checkpoints of all 64 code-blocks of a
-// wave at the same (uniform) point of its loop, so every store instruction writes one contiguous 256-byte line.
-constexpr int kJ2kCkptFields = 9;
-__host__ __device__ inline size_t j2k_ckpt_block_bytes() { return (size_t) kJ2kCkptFields * kJ2kCkptPerBlock * 4; }
+// Checkpoint storage: one 32-byte record per slot, the slots of a code-block contiguous: [code-block][slot = pass * 16 +
+// stripe][8 words] = { a | ct << 16, pos, the 19 context states one byte each in five words, c }.  A record is one
+// 32-byte sector: the MQ pass writes a, the shift count (word 1) and the contexts from its interval chain and the low
+// half of the ENCODER's c (word 7) from its code chain; the finalising sweep turns words 0, 1 and 7 into the decoder's
+// registers; the restart reads the record whole.
+constexpr int kJ2kCkptWords = 8;
+__host__ __device__ inline size_t j2k_ckpt_block_bytes() { return (size_t) kJ2kCkptWords * kJ2kCkptPerBlock * 4; }
 struct J2kCkptView {
-    std::uint32_t *rec;            // word 0 of slot 0 of this code-block (its lane's column of the group)
-    __host__ __device__ std::uint32_t &at(int field, std::uint32_t slot) const { return rec[(slot * kJ2kCkptFields + (std::uint32_t) field) * 64u]; }
+    std::uint32_t *rec;            // first record of this code-block
+    __host__ __device__ std::uint32_t *slot(std::uint32_t i) const { return rec + i * kJ2kCkptWords; }
     __host__ __device__ static J2kCkptView of(void *all, size_t gid)
     {
-        return J2kCkptView{(std::uint32_t *) ((unsigned char *) all + (gid >> 6) * 64 * j2k_ckpt_block_bytes()) + (gid & 63)};
+        return J2kCkptView{(std::uint32_t *) ((unsigned char *) all + gid * j2k_ckpt_block_bytes())};
     }
 };
 
@@ -115,7 +116,7 @@ struct J2kBuffers {
     unsigned long long *SUF;      // [groups][planes+2][64][64] suffix-OR of BP over planes >= p (significance above a plane)
     unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
     unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
-    void *ckpt;                   // [frames*nblocks][passes * 16 stripes][9 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
+    void *ckpt;                   // [frames*nblocks][passes * 16 stripes][8 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
     uint8_t *SYM;                 // [groups][sym_rows][64 lanes][16] decision rows of the segmented two-phase encoder (t1_core.hpp: row format); null: single-kernel encoder
     int sym_rows;                 // 1-KB rows of SYM per group (kJ2kSymRows; EBCC_HIP_SYM_ROWS overrides, for tests of the retry)
     std::uint16_t *seglen;        // [groups][kJ2kSegCount][64] decisions of every segment of every code-block, then its first row in the block's stream

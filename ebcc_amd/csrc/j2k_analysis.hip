@@ -545,6 +545,131 @@ __global__ __launch_bounds__(kFinT) void k_j2k_cols_fin(const float *__restrict_
     }
 }
 
+// The vertical half of the last inverse level as a two-deep register pipeline (see k_j2k_cols_fin): step(j) takes the low- and
+// high-pass samples of vertical position j and hands out the finished samples of position j - 2.
+struct ColPipe {
+    float o0_prev = 0, e1_prev = 0, o1_prev = 0, e2_prev = 0;
+    template <class Out>
+    __device__ void step(int j, int sn, int dn, float lo_raw, float hi_raw, Out out)
+    {
+        const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
+        float e1 = 0, o0 = 0;
+        if (j < sn) {
+            const float e0 = lo_raw * kK;
+            if (j < dn) o0 = hi_raw * kTwoInvK;
+            if (j < dn) e1 = e0 + (((j == 0 ? o0 : o0_prev) + o0) * c1);
+            else        e1 = e0 + (o0_prev * (c1 + c1));
+        }
+        float o1 = 0;
+        const int i1 = j - 1;
+        if (i1 >= 0 && i1 < dn) o1 = (i1 + 1 < sn) ? o0_prev + ((e1_prev + e1) * c2) : o0_prev + (e1_prev * (c2 + c2));
+        float e2 = 0;
+        if (i1 >= 0 && i1 < sn) e2 = (i1 < dn) ? e1_prev + (((i1 == 0 ? o1 : o1_prev) + o1) * c3) : e1_prev + (o1_prev * (c3 + c3));
+        const int i2 = j - 2;
+        if (i2 >= 0) {
+            if (i2 < sn) out(2 * i2, e2_prev);
+            if (i2 < dn) out(2 * i2 + 1, (i2 + 1 < sn) ? o1_prev + ((e2_prev + e2) * c4) : o1_prev + (e2_prev * (c4 + c4)));
+        }
+        o0_prev = o0; e1_prev = e1; o1_prev = o1; e2_prev = e2;
+    }
+};
+
+// The WHOLE last inverse level (horizontal then vertical, opj_dwt_decode_tile_97 at the top resolution) with
+// dequantisation, field mapping and statistics in one pass over the data: a wave owns 60 sample pairs of the width
+// (+ 2 pairs of halo on either side), one pair per lane; for every vertical position it synthesises the low-pass and
+// the high-pass row horizontally in registers (neighbours through wave shuffles) and feeds two ColPipes, one per
+// column of the pair.  Nothing is written but the fp32 field (if wanted) and the statistics: against the separate
+// row and column passes this saves one write and one read of the frame per probe.  cas == 0 frames only.
+constexpr int kL5Pairs = 60;
+__global__ __launch_bounds__(64) void k_j2k_level5_fin(const float *__restrict__ B, const int32_t *__restrict__ V, const J2kGeom *geom,
+                                                        const FrameState *fs, const int *active, J2kFinish fin)
+{
+    const int frame = blockIdx.y;
+    if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    constexpr int r = kJ2kRes - 1;
+    const int W = g.W, nh = g.rw[r], snh = g.rw[r - 1], dnh = nh - snh;          // horizontal: samples, low-pass, high-pass
+    const int nv = g.rh[r], snv = g.rh[r - 1], dnv = nv - snv;                   // vertical
+    const size_t n_pix = (size_t) W * g.H;
+    const int i = (int) blockIdx.x * kL5Pairs + (int) threadIdx.x - 2;           // this lane's pair
+    const bool has_e = i >= 0 && i < snh, has_o = i >= 0 && i < dnh;
+    const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kL5Pairs && has_e;    // (halo lanes compute, owners put out)
+    const float *b = B + (size_t) frame * n_pix;
+    const int32_t *v = V + (size_t) frame * n_pix;
+    const float s_hl = 0.5f * g.bands[3 * (r - 1) + 1].step_dec, s_lh = 0.5f * g.bands[3 * (r - 1) + 2].step_dec,
+                s_hh = 0.5f * g.bands[3 * (r - 1) + 3].step_dec;
+    const float *x = fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
+    float *d = fin.DEC ? fin.DEC + (size_t) frame * n_pix : nullptr;             // (null: statistics only)
+    const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
+    const float target = x ? fin.jf[frame].target : 0.0f;
+    const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
+    // horizontal synthesis of one row: the pair's low-/high-pass inputs -> its two output samples (idwt_tile, cas 0)
+    auto hsynth = [&](float e_raw, float o_raw, float &even, float &odd) {
+        const float e0 = has_e ? e_raw * kK : 0.0f, o0 = has_o ? o_raw * kTwoInvK : 0.0f;
+        const float o0l = __shfl_up(o0, 1);
+        const float e1 = i < dnh ? e0 + (((i == 0 ? o0 : o0l) + o0) * c1) : e0 + (o0l * (c1 + c1));
+        const float e1r = __shfl_down(e1, 1);
+        const float o1 = i + 1 < snh ? o0 + ((e1 + e1r) * c2) : o0 + (e1 * (c2 + c2));
+        const float o1l = __shfl_up(o1, 1);
+        const float e2 = i < dnh ? e1 + (((i == 0 ? o1 : o1l) + o1) * c3) : e1 + (o1l * (c3 + c3));
+        const float e2r = __shfl_down(e2, 1);
+        even = e2;
+        odd = i + 1 < snh ? o1 + ((e2 + e2r) * c4) : o1 + (e2 * (c4 + c4));
+    };
+    double acc = 0;
+    unsigned int bad = 0;
+    ColPipe p0, p1;
+    // every lane loads every step (halo and out-of-range lanes from clamped positions, their results are dropped), and
+    // the inputs of step j + 1 are requested before step j is computed: no divergent control flow around the memory
+    // accesses, one row of latency in flight
+    const size_t c_lo = (size_t) min(max(i, 0), snh - 1), c_hi = (size_t) snh + (size_t) min(max(i, 0), max(dnh - 1, 0));
+    const size_t c0 = (size_t) min(max(2 * i, 0), nh - 1), c1x = (size_t) min(max(2 * i + 1, 0), nh - 1);
+    float in_ll, in_hl, in_lh, in_hh;
+    auto fetch = [&](int j, float &ll, float &hl, float &lh, float &hh) {
+        const size_t rl = (size_t) min(j, snv - 1) * W, rh = (size_t) (snv + min(j, max(dnv - 1, 0))) * W;
+        ll = b[rl + c_lo];
+        hl = (float) v[rl + c_hi] * s_hl;
+        lh = (float) v[rh + c_lo] * s_lh;
+        hh = (float) v[rh + c_hi] * s_hh;
+    };
+    // the vertical extent is cut into gridDim.z pieces (more waves in flight): a piece puts out positions [ja, jb) and
+    // starts its pipeline two positions early - an output depends on the inputs of positions i - 2 .. i + 2 only
+    const int per = ceil_div(snv, (int) gridDim.z), ja = (int) blockIdx.z * per, jb = min(snv, ja + per);
+    const int jstart = max(ja - 2, 0);
+    fetch(jstart, in_ll, in_hl, in_lh, in_hh);
+    for (int j = jstart; j < jb + 2; j++) {
+        float n_ll, n_hl, n_lh, n_hh;
+        fetch(j + 1, n_ll, n_hl, n_lh, n_hh);
+        // the frame's samples at the four positions this step puts out (rows 2 (j - 2) and the next, this pair's columns)
+        const int y0 = min(max(2 * (j - 2), 0), nv - 1), y1 = min(max(2 * (j - 2) + 1, 0), nv - 1);
+        float x00 = 0, x01 = 0, x10 = 0, x11 = 0;
+        if (x) { x00 = x[(size_t) y0 * W + c0]; x01 = x[(size_t) y0 * W + c1x]; x10 = x[(size_t) y1 * W + c0]; x11 = x[(size_t) y1 * W + c1x]; }
+        float lo_even = 0, lo_odd = 0, hi_even = 0, hi_odd = 0;
+        if (j < snv) hsynth(in_ll, in_hl, lo_even, lo_odd);              // (uniform) low-pass row j: LL from the previous level, HL from the decoder
+        if (j < dnv) hsynth(in_lh, in_hh, hi_even, hi_odd);              // high-pass row j: LH, HH
+        auto put = [&](bool mine, int col, int y, float val, float xv) {
+            const float dv = fin_map(val, rng, mn);
+            if (d && mine) d[(size_t) y * W + (size_t) col] = dv;
+            if (x) {
+                const float e = xv - (dv + 0.0f);
+                acc += mine ? (double) e : 0.0;
+                bad += (mine && fabsf(e) > target) ? 1u : 0u;
+            }
+        };
+        const bool emit = owner && j - 2 >= ja;                          // (positions before the piece belong to its neighbour)
+        p0.step(j, snv, dnv, lo_even, hi_even, [&](int y, float val) { put(emit, 2 * i, y, val, (y & 1) ? x10 : x00); });
+        p1.step(j, snv, dnv, lo_odd, hi_odd, [&](int y, float val) { put(emit && has_o, 2 * i + 1, y, val, (y & 1) ? x11 : x01); });
+        in_ll = n_ll; in_hl = n_hl; in_lh = n_lh; in_hh = n_hh;
+    }
+    if (x) {
+        for (int k = 32; k >= 1; k >>= 1) { acc += __shfl_xor(acc, k); bad += __shfl_xor(bad, k); }
+        if (threadIdx.x == 0) {
+            fin.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = acc;
+            fin.partial_u[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = bad;
+        }
+    }
+}
+
 template <typename K>
 void big_lds(K k, size_t bytes)
 {
@@ -725,19 +850,27 @@ struct CkObserver {
         m.cx.to_bytes(x);
         store(0, cur + (y0 >> 2), m.a, m.c & 0xFFFFu, m.shifts, x);
     }
-    // CkArray of t1::mq_encode_stream / t1::finalize_checkpoints
+    // CkArray of the MQ pass (interval chain: a, shifts, contexts; code chain: the low half of C) and of
+    // t1::finalize_checkpoints.  Record: { a | ct << 16, shifts -> pos, five context words, c16 -> c } (j2k.hpp)
     __device__ void store(int p, int s, uint32_t a, uint32_t c16, uint32_t shifts, const uint32_t x[5])
     {
-        const uint32_t i = (uint32_t) (p * 16 + s);
-        ck.at(0, i) = a; ck.at(1, i) = c16; ck.at(3, i) = shifts;
-        for (int j = 0; j < 5; j++) ck.at(4 + j, i) = x[j];
+        uint4 *r = (uint4 *) ck.slot((uint32_t) (p * 16 + s));
+        r[0] = make_uint4(a, shifts, x[0], x[1]);
+        r[1] = make_uint4(x[2], x[3], x[4], c16);
     }
-    __device__ uint32_t shifts(int p, int s) const { return ck.at(3, (uint32_t) (p * 16 + s)); }
-    __device__ uint32_t c16(int p, int s) const { return ck.at(1, (uint32_t) (p * 16 + s)); }
+    __device__ void store_interval(int p, int s, uint32_t a, uint32_t shifts, const uint32_t x[5])
+    {
+        uint32_t *r = ck.slot((uint32_t) (p * 16 + s));
+        *(uint4 *) r = make_uint4(a, shifts, x[0], x[1]);
+        r[4] = x[2]; r[5] = x[3]; r[6] = x[4];
+    }
+    __device__ void store_code(int p, int s, uint32_t c16) { ck.slot((uint32_t) (p * 16 + s))[7] = c16; }
+    __device__ uint32_t shifts(int p, int s) const { return ck.slot((uint32_t) (p * 16 + s))[1]; }
+    __device__ uint32_t c16(int p, int s) const { return ck.slot((uint32_t) (p * 16 + s))[7]; }
     __device__ void finish(int p, int s, uint32_t c, int ct, int pos)
     {
-        const uint32_t i = (uint32_t) (p * 16 + s);
-        ck.at(1, i) = c; ck.at(2, i) = (uint32_t) ct; ck.at(3, i) = (uint32_t) pos;
+        uint32_t *r = ck.slot((uint32_t) (p * 16 + s));
+        r[0] = (r[0] & 0xFFFFu) | ((uint32_t) ct << 16); r[1] = (uint32_t) pos; r[7] = c;
     }
     template <class Store>
     __device__ void sigprop_done(int bp, Store &st)
@@ -942,40 +1075,60 @@ __global__ __launch_bounds__(64) void k_t1_emit(const unsigned long long *BP, co
 }
 
 // ---- arithmetic coding of the row streams: one wave per group, a code-block per lane (t1::mq_encode_rows)
-// The rows come through LDS: the workgroup's second wave (the loader) copies them from HBM kRowChunk rows at a time
-// into one half of a double buffer while the coder wave works on the other, with a workgroup barrier per chunk.  The
-// coder wave therefore never waits for vector memory: its own global accesses are stores only (checkpoints, bytes,
-// rates), and on gfx9 a load's data would wait for every older store of the wave (one counter, in issue order).
-constexpr int kRowChunk = 8;
+// The MQ pass runs as TWO waves per group of 64 code-blocks (t1_core.hpp: mq_rows_interval / MqCodeChain):
+//   wave 0 - the interval chain: reads the decision rows (from LDS), keeps the context states, hands a 16-bit word
+//            per decision over through LDS, stores the interval half of the checkpoints;
+//   wave 1 - copies the rows from HBM into LDS kRowChunk rows ahead, and runs the code chain kRowChunk rows behind
+//            wave 0: output bytes, pass rates, the code half of the checkpoints.
+// One workgroup barrier per chunk of kRowChunk rows keeps the three stages (load chunk q + 1 | interval chunk q | code
+// chunk q - 1) in step.  Wave 0 never waits for vector memory: its global accesses are stores only (on gfx9 a load's data
+// would wait for every older store of the wave: one counter, in issue order).
+constexpr int kRowChunk = 2;
 struct RowSrcDev {
     uint32_t buf;                  // LDS byte address of this lane's 16 bytes of row 0 of buffer 0 (row stride 1 KB, buffers kRowChunk KB apart)
     uint32_t n, wn;                // rows of this lane, of the longest lane of the wave
     __device__ uint32_t rows() const { return n; }
     __device__ uint32_t wave_rows() const { return wn; }
     __device__ void sync(uint32_t row) const { if (row % kRowChunk == 0) __syncthreads(); }
+    __device__ void finish() const { __syncthreads(); __syncthreads(); }                 // (the code chain is two chunks behind)
     __device__ void load(uint32_t row, uint32_t w[4]) const
     {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *) (uintptr_t) (buf + (row % (2 * kRowChunk)) * 1024u);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     }
-    __device__ bool any(bool b) const { return __any(b) != 0; }
+};
+struct HandDev {
+    uint32_t buf;                  // LDS byte address of this lane's word 0 of row 0 of buffer 0: [row % (2 kRowChunk)][j][lane] 16-bit words
+    __device__ void put(uint32_t row, int j, uint32_t word) const
+    {
+        *(__attribute__((address_space(3))) unsigned short *) (uintptr_t) (buf + ((row % (2 * kRowChunk)) * 16u + (uint32_t) j) * 128u) = (unsigned short) word;
+    }
+    __device__ uint32_t get(uint32_t row, int j) const
+    {
+        return *(const __attribute__((address_space(3))) unsigned short *) (uintptr_t) (buf + ((row % (2 * kRowChunk)) * 16u + (uint32_t) j) * 128u);
+    }
 };
 struct MqSinkLds {
     // coded bytes go into a 64-byte ring per lane in LDS (lane stride 68 bytes: lanes at the same offset never
-    // conflict) and leave as aligned 8-byte words at the uniform points of the loop (every 16 decisions)
+    // conflict) and leave as whole 32-byte sectors at the uniform points of the loop (every 16 decisions: at most 30
+    // new bytes on top of at most 31 waiting ones)
     unsigned char *ring;           // LDS, this lane's 64 bytes
     uint8_t *out; int *overflow;
-    int fl = 0;                    // bytes written out (multiple of 8)
+    int fl = 0;                    // bytes written out (multiple of 32)
     __device__ void put(int i, uint32_t b) { ring[(uint32_t) i & 63u] = (unsigned char) b; }    // (i == -1 lands in byte 63 and is overwritten later)
-    __device__ void word()
+    __device__ void sector()
     {
         const uint32_t *q = (const uint32_t *) (ring + ((uint32_t) fl & 63u));
-        if (fl + 8 <= kJ2kCblkBytes) *(uint2 *) (out + fl) = make_uint2(q[0], q[1]); else *overflow = 1;
-        fl += 8;
+        if (fl + 32 <= kJ2kCblkBytes) {
+            uint4 *o = (uint4 *) (out + fl);
+            o[0] = make_uint4(q[0], q[1], q[2], q[3]);
+            o[1] = make_uint4(q[4], q[5], q[6], q[7]);
+        } else *overflow = 1;
+        fl += 32;
     }
-    __device__ void row_end(int n) { while (fl + 8 <= n) word(); }
-    __device__ void finish(int n) { row_end(n); if (fl < n) word(); }
+    __device__ void row_end(int n) { while (fl + 32 <= n) sector(); }
+    __device__ void finish(int n) { row_end(n); if (fl < n) sector(); }
 };
 
 __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uint32_t *lanerows, const int *blkmax, int *cblk_len,
@@ -983,12 +1136,14 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
                                                     const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows)
 {
     __shared__ uint2 tab_store[128];
-    __shared__ uint32_t ctxw[32 * 64];
+    __shared__ uint32_t ctxw[CtxLds2::kBytes / 4];
     __shared__ uint32_t bring[17 * 64];
     __shared__ uint4 rowbuf[2 * kRowChunk * 64];
+    __shared__ unsigned short handbuf[2 * kRowChunk * 16 * 64];
+    __shared__ uint32_t a_end[64];
     const int lane = (int) threadIdx.x & 63;
-    const bool loader = threadIdx.x >= 64;
-    for (int i = (int) threadIdx.x; i < 128; i += 128) { uint32_t qe, nx; t1::mq_entry2(i, qe, nx); tab_store[i] = make_uint2(qe, nx); }
+    const bool code_wave = threadIdx.x >= 64;
+    fill_mq_table2(tab_store);
     const LdsTable2 tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
     const size_t grp = blockIdx.x;
     const int gid = (int) (grp * 64) + lane;
@@ -999,34 +1154,62 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
     for (int d = 32; d >= 1; d >>= 1) wrows = max(wrows, (uint32_t) __shfl_xor((int) wrows, d));
     wrows = (uint32_t) __builtin_amdgcn_readfirstlane((int) wrows);      // (both waves of the workgroup compute the same value)
     if (wrows == 0) return;
-    const uint8_t *sym = SYM + grp * (size_t) sym_rows * 1024 + (size_t) lane * 16u;
-    if (loader) {
-        // chunk q of the rows goes to buffer q & 1 and is handed over at barrier number q (RowSrcDev::sync at row q * kRowChunk)
-        const uint32_t nchunks = (wrows + kRowChunk - 1) / kRowChunk;
-        for (uint32_t q = 0; q < nchunks; q++) {
-            uint4 v[kRowChunk];
-#pragma unroll
-            for (int i = 0; i < kRowChunk; i++) {
-                const uint32_t row = q * kRowChunk + (uint32_t) i;
-                v[i] = row < wrows ? *(const uint4 *) (sym + (size_t) row * 1024) : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < kRowChunk; i++) rowbuf[((q & 1u) * kRowChunk + (uint32_t) i) * 64 + (uint32_t) lane] = v[i];
-            __syncthreads();
-        }
-        return;
-    }
     // (lanes without a code-block run along with no rows: nothing is coded or stored for them)
     const bool on = nrows > 0;
-    uint8_t *out = cblk_bytes + (size_t) (on ? gid : 0) * kJ2kCblkBytes;
-    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, (uint32_t) lane * 8u};
-    RowSrcDev src{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint4 *) rowbuf + (uint32_t) lane * 16u, nrows, wrows};
     const int P = on ? l.P : 0, nstr = (l.h + 3) >> 2;
-    const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + (uint32_t) lane * 4u;
-    t1::EncodeResult r = t1::mq_encode_rows(src, CtxLds2{ctx_base}, P, nstr,
-                                            MqSinkLds{(unsigned char *) bring + lane * 68, out, &jf[l.frame].overflow},
-                                            DevAt{out, kJ2kCblkBytes}, rates + (size_t) (on ? gid : 0) * kJ2kMaxPasses, ck, tab);
+    CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, (uint32_t) lane * 8u};
+    const HandDev hand{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned short *) handbuf + (uint32_t) lane * 2u};
+    const uint32_t nchunks = (wrows + kRowChunk - 1) / kRowChunk;
+    if (!code_wave) {
+        RowSrcDev src{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint4 *) rowbuf + (uint32_t) lane * 16u, nrows, wrows};
+        const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + (uint32_t) lane * 2u;
+        a_end[lane] = t1::mq_rows_interval(src, CtxLds2{ctx_base}, P, nstr, hand, ck, tab);
+        __syncthreads();                                                 // (a_end, and this wave's checkpoint stores, before the other wave's epilogue)
+        return;
+    }
+    // ---- wave 1: loader + code chain.  Barrier k hands chunk k of the rows to wave 0 and chunk k - 1 of the hand-over words to this wave.
+    const uint8_t *sym = SYM + grp * (size_t) sym_rows * 1024 + (size_t) lane * 16u;
+    uint8_t *out = cblk_bytes + (size_t) (on ? gid : 0) * kJ2kCblkBytes;
+    int *myrates = rates + (size_t) (on ? gid : 0) * kJ2kMaxPasses;
+    MqSinkLds sink{(unsigned char *) bring + lane * 68, out, &jf[l.frame].overflow};
+    t1::MqCodeChain chain;
+    auto load_chunk = [&](uint32_t q, uint4 v[kRowChunk]) {
+#pragma unroll
+        for (int i = 0; i < kRowChunk; i++) {
+            const uint32_t row = q * kRowChunk + (uint32_t) i;
+            v[i] = row < wrows ? *(const uint4 *) (sym + (size_t) row * 1024) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto put_chunk = [&](uint32_t q, const uint4 v[kRowChunk]) {
+#pragma unroll
+        for (int i = 0; i < kRowChunk; i++) rowbuf[((q & 1u) * kRowChunk + (uint32_t) i) * 64 + (uint32_t) lane] = v[i];
+    };
+    {
+        uint4 v[kRowChunk];
+        load_chunk(0, v);
+        put_chunk(0, v);
+    }
+    __syncthreads();                                                     // barrier 0: the table and chunk 0 are in LDS
+    for (uint32_t q = 0; q <= nchunks; q++) {
+        uint4 v[kRowChunk];
+        if (q + 1 < nchunks) load_chunk(q + 1, v);                       // (in flight while the code chain works)
+        if (q >= 1) {                                                    // the hand-over words of chunk q - 1
+            for (uint32_t row = (q - 1) * kRowChunk; row < min(q * kRowChunk, wrows); row++) {
+                if (row < nrows) {
+                    uint32_t hw[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) hw[j] = hand.get(row, j);
+                    chain.row(hw, nstr, myrates, sink, ck, tab, [](bool b) { return __any(b) != 0; });
+                }
+            }
+        }
+        if (q + 1 < nchunks) put_chunk(q + 1, v);
+        __syncthreads();                                                 // barrier q + 1
+    }
+    __syncthreads();                                                     // (matches wave 0's last one: a_end and its checkpoint stores are visible)
     if (P <= 0) return;
+    __threadfence();
+    t1::EncodeResult r = chain.finish(a_end[lane], 3 * P - 2, myrates, sink, DevAt{out, kJ2kCblkBytes});
     cblk_len[gid] = r.length;
     __threadfence();                                                    // the sweep below re-reads this lane's own bytes
     t1::finalize_checkpoints(ck, r.totalpasses, nstr, CkSrc{out, r.length < kJ2kCblkBytes ? r.length : kJ2kCblkBytes});
@@ -1233,7 +1416,19 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
                     const int *active, hipStream_t s, bool keep_field)
 {
     int partials = 0;
+    // plain frames: the top level in one fused pass (k_j2k_level5_fin); EBCC_HIP_L5_SPLIT=1 keeps the separate row / column passes
+    static const bool split5 = getenv("EBCC_HIP_L5_SPLIT") != nullptr;
+    const bool fuse5 = !split5 && V && jb.geom.period == 1 && jb.geom.ry0[kJ2kRes - 1] % 2 == 0 && jb.geom.rw[kJ2kRes - 2] >= 2 && jb.geom.rh[kJ2kRes - 2] >= 1 &&
+                       ceil_div(jb.geom.rw[kJ2kRes - 2], kL5Pairs) <= kPartials;
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
+        if (fuse5 && r == kJ2kRes - 1) {
+            const int strips = ceil_div(jb.geom.rw[r - 1], kL5Pairs);
+            const int pieces = std::max(1, std::min({4, kPartials / strips, jb.geom.rh[r - 1] / 16}));
+            partials = strips * pieces;
+            hipLaunchKernelGGL(k_j2k_level5_fin, dim3(strips, n_frames, pieces), dim3(64), 0, s, B, V, jb.d_geom, fs, active,
+                               J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u});
+            break;
+        }
         dwt_rows<false>(B, V, jb, r, n_frames, fs, active, s);
         if (r + 1 < kJ2kRes) dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
         else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u});

@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(64) void k_t1_decode_seg(unsigned long long *T1S, c
                                                        const J2kBlock *blocks, const FrameState *fs, int total)
 {
     __shared__ uint2 tab_store[128];
-    __shared__ uint32_t ctxw[32 * 64];
+    __shared__ uint32_t ctxw[CtxLds2::kBytes / 4];
     __shared__ uint32_t rings[64 * kRingStride / 4];
     fill_mq_table2(tab_store);
     __syncthreads();
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_t1_decode_seg(unsigned long long *T1S, c
     pmax = __builtin_amdgcn_readfirstlane(pmax);
     if (pmax <= 0) return;
     DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), threadIdx.x * 8u, v, W};
-    CtxLds2 cx{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + threadIdx.x * 4u};
+    CtxLds2 cx{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + threadIdx.x * 2u};
     const int a0 = (int) ((uintptr_t) src & 15);
     DecEnv env{RingBytes{src - a0, (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) rings + threadIdx.x * kRingStride, a0, len, 0}};
     env.src.top_up(0);                                                   // (the decoder's first bytes)
@@ -1093,7 +1093,7 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             const int mp = mid / nstr, ms = mid - mp * nstr;
-            if ((int) ck.at(3, (uint32_t) (mp * 16 + ms)) + 1 < len) lo = mid; else hi = mid - 1;
+            if ((int) ck.slot((uint32_t) (mp * 16 + ms))[1] + 1 < len) lo = mid; else hi = mid - 1;
         }
         const int r = lo / nstr, st = lo - r * nstr;
         plan = r | (st << 8);
@@ -1198,11 +1198,11 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
         st.VIS(y) = Vv;
     }
     const J2kCkptView cv = J2kCkptView::of(ckpt, (size_t) gid);
-    const uint32_t ci = (uint32_t) (r * 16 + stripe);
-    uint32_t cxb[5];
-    for (int j = 0; j < 5; j++) cxb[j] = cv.at(4 + j, ci);
+    const uint4 *rec = (const uint4 *) cv.slot((uint32_t) (r * 16 + stripe));
+    const uint4 r0 = rec[0], r1 = rec[1];
+    const uint32_t cxb[5] = {r0.z, r0.w, r1.x, r1.y, r1.z};                // record: { a | ct << 16, pos, five context words, c } (j2k.hpp)
     const t1::Contexts cxp = t1::Contexts::from_bytes(cxb);
-    const t1::MqCheckpoint ck{cv.at(0, ci), cv.at(1, ci), (int) cv.at(2, ci), (int) cv.at(3, ci), cxp.w0, cxp.w1, cxp.w2};
+    const t1::MqCheckpoint ck{r0.x & 0xFFFFu, r1.w, (int) (r0.x >> 16), (int) r0.y, cxp.w0, cxp.w1, cxp.w2};
     t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
                       np, r, stripe, ck, tab);
 }

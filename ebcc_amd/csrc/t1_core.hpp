@@ -1225,7 +1225,7 @@ T1_HD EncodeResult mq_encode_stream(SymSrc sym, CtxMem cx, uint32_t nsym, int np
 // is the arithmetic coder and nothing else, the same instruction stream for all 64 code-blocks of a wave.
 //   scan_block            -> VISP, SPS and the number of decisions of every segment
 //   emit_stripe_segments  -> the decisions of the three segments of one (plane, stripe)
-//   mq_encode_rows        -> bytes, pass rates and checkpoints (identical to encode_block_observed)
+//   mq_rows_interval + MqCodeChain -> bytes, pass rates and checkpoints (identical to encode_block_observed)
 // ------------------------------------------------------------------------------------------------
 constexpr int kSegPlanes = 26;                                            // == kJ2kMaxPlanes (j2k.hpp)
 constexpr int kSegCount = kSegPlanes * 3 * 16;
@@ -1393,29 +1393,90 @@ struct ConstTable2 {
 constexpr uint32_t kRowPad = 0x80u | kCtxNull, kRowStart = 0x40u;
 T1_HD uint32_t seg_rows(uint32_t decisions) { return decisions ? (decisions + 15u) >> 4 : 1u; }
 
+// The MQ pass is TWO dependency chains per decision that meet nowhere:
+//   * the INTERVAL chain: context state -> table entry (Qe, successors) -> A -> renormalisation shift count k, and
+//     whether Qe is added to the code register (the decision falls into the upper sub-interval);
+//   * the CODE chain: C += addend, k shifts, output bytes whenever the down-counter runs out (C.2.6, C.2.7).
+// The code chain needs from the interval chain 12 bits per decision - the context's state before the decision (Qe
+// follows from it), the "no addend" flag and k - so the two run as two waves of one workgroup, a few rows apart, with
+// a 16-bit word per decision handed over through LDS (mq_rows_interval / MqCodeChain).  A lone wave issues one
+// instruction every ~4-6 cycles whatever it does; two waves halve what each has to issue per decision.
+//
+// Hand-over word: bits 0..6 state (6-bit index | mps << 6) before the decision, bit 7 = nothing is added to C,
+// bits 8..11 = k, bit 15 (first decision of a row only) = the row starts a segment.
+constexpr uint32_t kHandNoAdd = 0x80u, kHandStart = 0x8000u;
+
 // RowSrc: uint32_t rows()                      rows of this lane's code-block
 //         uint32_t wave_rows()                 the most rows any lane of the wave has (uniform)
 //         void sync(uint32_t row)              called by every lane before row `row` is loaded (a uniform point)
 //         void load(uint32_t row, uint32_t w[4])
-//         bool any(bool)                       true if the argument is true for any lane of the wave
 // CtxMem: uint32_t handle(uint32_t ctx) (an address on the device), uint32_t ld(handle) / void st(handle, code): the state
 //         codes (contexts 0 .. 31; 19 is the null context), void words(uint32_t out[5]): the 19 context states as
 //         bytes (state | mps << 6), four per word - the checkpoint format
-// Sink:   void put(int index, uint32_t byte) (index -1 ignored; an index may be written again until a higher one
-//         has been), void row_end(int n) (a uniform point: bytes below n are final and may leave), void finish(int n)
-// CkArray: store(p, s, a, c16, shifts, cx[5]) as for mq_encode_stream
-// Every lane of a wave runs this loop in lock-step over wave_rows() rows; lanes differ in what their rows hold.  A
-// row is straight-line code: MPS/LPS, renormalisation and the first output byte of a decision are selects, only a
-// second output byte (a renormalisation of 8+ bits across a byte boundary) takes a branch.
-template <class RowSrc, class CtxMem, class Sink, class ByteAt, class CkArray, class Table = ConstTable2>
-T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink sink, ByteAt bytes, int *rates, CkArray &ck,
-                                  Table tab = Table())
+// Hand:   void put(uint32_t row, int j, uint32_t word)
+// CkArray: store_interval(p, s, a, shifts, cx[5])
+template <class RowSrc, class CtxMem, class Hand, class CkArray, class Table = ConstTable2>
+T1_HD uint32_t mq_rows_interval(RowSrc src, CtxMem cx, int P, int nstr, Hand hand, CkArray &ck, Table tab = Table())
 {
-    uint32_t a = 0x8000, c = 0, cur = 0, shifts = 0;
-    int ct = 12, n = -1;
+    uint32_t a = 0x8000, shifts = 0;
     for (uint32_t i = 0; i < 32; i++)
         cx.st(cx.handle(i), i >= (uint32_t) NCTX ? kNullCode : mq_code(i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u))));
-    auto byteout = [&]() {
+    const uint32_t nrows = P > 0 ? src.rows() : 0u, wrows = src.wave_rows();
+    int pass = 0, stripe = 0;
+    for (uint32_t row = 0; row < wrows; row++) {
+        src.sync(row);                                                    // (uniform: the device source swaps its staging buffers here)
+        if (row < nrows) {
+            uint32_t w[4];
+            src.load(row, w);
+            const bool start = (w[0] & kRowStart) != 0;
+            if (start) {
+                uint32_t x[5];
+                cx.words(x);
+                ck.store_interval(pass, stripe, a, shifts, x);
+                if (++stripe == nstr) { stripe = 0; pass++; }
+            }
+            uint32_t h = cx.handle(w[0] & 31u);
+            uint32_t code = cx.ld(h);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t wj = w[j >> 2] >> (8 * (j & 3));           // this decision's byte in bits 0..7
+                uint32_t qe, nxt;
+                tab(code, qe, nxt);
+                uint32_t hn = 0, coden = 0;
+                if (j < 15) {
+                    hn = cx.handle((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31u);
+                    coden = cx.ld(hn);                                    // (issued before this decision's state store)
+                }
+                const bool lps = (((wj << 4) ^ code) & 0x200u) != 0;      // decision bit (bit 5) against the mps (bit 9 of the code)
+                a -= qe;
+                const bool small = a < 0x8000u;
+                const bool lower = (a < qe) != lps;                       // which sub-interval the symbol is coded in
+                a = lower ? qe : a;
+                const uint32_t ncode = lps ? nxt >> 16 : (small ? nxt & 0xFFFFu : code);
+                cx.st(h, ncode);
+                if (j < 15 && hn == h) coden = ncode;                     // the next decision uses the same context
+                const int k = renorm_shifts(a);                           // 0 when bit 15 is set
+                shifts += (uint32_t) k;
+                a <<= k;
+                hand.put(row, j, mq_code_state(code) | (lower ? kHandNoAdd : 0u) | ((uint32_t) k << 8) | ((j == 0 && start) ? kHandStart : 0u));
+                h = hn; code = coden;
+            }
+        }
+    }
+    src.finish();
+    return a;                                                             // (the code chain's FLUSH needs it)
+}
+
+// The code chain of one lane.  Table as above (Qe from the state code).
+// Sink:   void put(int index, uint32_t byte) (index -1 ignored; an index may be written again until a higher one
+//         has been), void row_end(int n) (a uniform point: bytes below n are final and may leave), void finish(int n)
+// CkArray: store_code(p, s, c16)
+struct MqCodeChain {
+    uint32_t c = 0, cur = 0;
+    int ct = 12, n = -1, pass = 0, stripe = 0;
+    template <class Sink>
+    T1_HD void byteout(Sink &sink)
+    {
         // C.2.7 without branches: a carry goes into the byte being held unless that byte is 0xFF; a byte that is
         // (or becomes) 0xFF is followed by a 7-bit byte
         const uint32_t carry = cur != 0xFFu ? (c >> 27) & 1u : 0u;
@@ -1428,86 +1489,57 @@ T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink s
         cur = (c >> sh) & 0xFFu;
         c &= (1u << sh) - 1u;
         ct = stuff ? 7 : 8;
-    };
-    const int npasses = P > 0 ? 3 * P - 2 : 0;
-    const uint32_t nrows = P > 0 ? src.rows() : 0u, wrows = src.wave_rows();
-    int pass = 0, stripe = 0;
-    for (uint32_t row = 0; row < wrows; row++) {
-        src.sync(row);                                                    // (uniform: the device source swaps its staging buffers here)
-        if (row < nrows) {
-            uint32_t w[4];
-            src.load(row, w);
-            if (w[0] & kRowStart) {
-                if (stripe == 0 && pass > 0) rates[pass - 1] = (int) ((uint32_t) n + 3u);
-                uint32_t x[5];
-                cx.words(x);
-                ck.store(pass, stripe, a, c & 0xFFFFu, shifts, x);
-                if (++stripe == nstr) { stripe = 0; pass++; }
-            }
-            // Two dependency chains per decision: the INTERVAL chain (context state -> table entry -> A -> shift count;
-            // one table read long) and the CODE chain (C register, down-counter, output bytes; needs only the addend
-            // and the shift count of its decision).  The code chain of decision j - 1 is placed between the table
-            // read of decision j and its first use, so a lone wave has work while the read is in flight.
-            uint32_t h = cx.handle(w[0] & 31u);
-            uint32_t code = cx.ld(h);
-            uint32_t add = 0;                                             // addend and shift count of the decision whose code chain is due
-            int k = 0;
-            auto code_chain = [&]() {
-                c += add;
-                const bool need = k >= ct;                                // a byte leaves when the down-counter runs out (selects, no branch)
-                const int sh1 = need ? ct : k;
-                int k2 = k - sh1;
-                c <<= sh1;
-                const uint32_t carry = (need && cur != 0xFFu) ? (c >> 27) & 1u : 0u;
-                const uint32_t curc = cur + carry;
-                c -= carry << 27;
-                const bool stuff = curc == 0xFFu;
-                sink.put(n, curc);                                        // (written again later unless `need`)
-                n += need ? 1 : 0;
-                const int shn = stuff ? 20 : 19;
-                cur = need ? (c >> shn) & 0xFFu : cur;
-                c = need ? c & ((1u << shn) - 1u) : c;
-                ct = need ? (stuff ? 7 : 8) : ct - sh1;
-                if (src.any(k2 >= ct)) {                                  // rare: a second byte (k <= 15: never a third)
-                    if (k2 >= ct) { c <<= ct; k2 -= ct; byteout(); }
-                }
-                c <<= k2; ct -= k2;
-            };
+    }
+    // one row of hand-over words (hw[j], j = 0..15); any(b): true if b holds for any lane of the wave
+    template <class Sink, class CkArray, class Table, class Any>
+    T1_HD void row(const uint32_t hw[16], int nstr, int *rates, Sink &sink, CkArray &ck, const Table &tab, Any any)
+    {
+        if (hw[0] & kHandStart) {
+            if (stripe == 0 && pass > 0) rates[pass - 1] = (int) ((uint32_t) n + 3u);
+            ck.store_code(pass, stripe, c & 0xFFFFu);
+            if (++stripe == nstr) { stripe = 0; pass++; }
+        }
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t wj = w[j >> 2] >> (8 * (j & 3));           // this decision's byte in bits 0..7
-                uint32_t qe, nxt;
-                tab(code, qe, nxt);
-                uint32_t hn = 0, coden = 0;
-                if (j < 15) {
-                    hn = cx.handle((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31u);
-                    coden = cx.ld(hn);                                    // (issued before this decision's state store)
-                }
-                if (j > 0) code_chain();                                  // decision j - 1
-                const bool lps = (((wj << 4) ^ code) & 0x200u) != 0;      // decision bit (bit 5) against the mps (bit 9 of the code)
-                a -= qe;
-                const bool small = a < 0x8000u;
-                const bool lower = (a < qe) != lps;                       // which sub-interval the symbol is coded in
-                add = lower ? 0u : qe;
-                a = lower ? qe : a;
-                const uint32_t ncode = lps ? nxt >> 16 : (small ? nxt & 0xFFFFu : code);
-                cx.st(h, ncode);
-                if (j < 15 && hn == h) coden = ncode;                     // the next decision uses the same context
-                k = renorm_shifts(a);                                     // 0 when bit 15 is set
-                shifts += (uint32_t) k;
-                a <<= k;
-                h = hn; code = coden;
+        for (int j = 0; j < 16; j++) {
+            uint32_t qe, nxt;
+            tab(mq_code(hw[j] & 0x7Fu), qe, nxt);
+            const int k = (int) ((hw[j] >> 8) & 15u);
+            c += (hw[j] & kHandNoAdd) ? 0u : qe;
+            const bool need = k >= ct;                                    // a byte leaves when the down-counter runs out (selects, no branch)
+            const int sh1 = need ? ct : k;
+            int k2 = k - sh1;
+            c <<= sh1;
+            const uint32_t carry = (need && cur != 0xFFu) ? (c >> 27) & 1u : 0u;
+            const uint32_t curc = cur + carry;
+            c -= carry << 27;
+            const bool stuff = curc == 0xFFu;
+            sink.put(n, curc);                                            // (written again later unless `need`)
+            n += need ? 1 : 0;
+            const int shn = stuff ? 20 : 19;
+            cur = need ? (c >> shn) & 0xFFu : cur;
+            c = need ? c & ((1u << shn) - 1u) : c;
+            ct = need ? (stuff ? 7 : 8) : ct - sh1;
+            if (any(k2 >= ct)) {                                          // rare: a second byte (k <= 15: never a third)
+                if (k2 >= ct) { c <<= ct; k2 -= ct; byteout(sink); }
             }
-            code_chain();                                                 // decision 15
+            c <<= k2; ct -= k2;
         }
         sink.row_end(n);
     }
-    if (npasses > 0) {                                                    // FLUSH (C.2.9)
+    // FLUSH (C.2.9) and the pass rates (OpenJPEG: bytes completed + 3 for unterminated passes, clipped to be
+    // non-decreasing, never ending on 0xFF); `a` = the interval register at the end (from the interval chain)
+    template <class Sink, class ByteAt>
+    T1_HD EncodeResult finish(uint32_t a, int npasses, int *rates, Sink &sink, ByteAt bytes)
+    {
+        EncodeResult r;
+        r.totalpasses = npasses;
+        r.length = 0;
+        if (npasses <= 0) return r;
         const uint32_t tempc = c + a;
         c |= 0xFFFFu;
         if (c >= tempc) c -= 0x8000u;
-        c <<= ct; byteout();
-        c <<= ct; byteout();
+        c <<= ct; byteout(sink);
+        c <<= ct; byteout(sink);
         sink.put(n, cur);
         if (cur != 0xFFu) n++;
         sink.finish(n);                                                   // (a buffering sink writes out its tail)
@@ -1519,12 +1551,10 @@ T1_HD EncodeResult mq_encode_rows(RowSrc src, CtxMem cx, int P, int nstr, Sink s
         }
         for (int q = 0; q < npasses; q++)
             if (rates[q] > 0 && bytes(rates[q] - 1) == 0xFF) rates[q]--;
+        r.length = n;
+        return r;
     }
-    EncodeResult r;
-    r.totalpasses = npasses;
-    r.length = npasses > 0 ? n : 0;
-    return r;
-}
+};
 
 // index of the first coding pass of bit-plane `bp` in a code-block with P planes; plane / type of pass i
 T1_HD int first_pass_of_plane(int P, int bp) { return bp == P - 1 ? 0 : 3 * (P - 1 - bp) - 2; }

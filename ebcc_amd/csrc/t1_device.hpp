@@ -17,10 +17,11 @@ struct LdsTable2 {
     }
 };
 struct CtxLds2 {
-    // the state codes of every lane, a dword slot each (code in its low half): context c of lane l at (c * 64 + l) * 4,
-    // so a handle - the byte address - is one shift-add away from the decision byte and the bank is the lane
+    // the state codes of every lane, 16 bits each: context c of lane l at (c * 64 + l) * 2 - a handle (the byte address)
+    // is one shift-add away from the decision byte
     uint32_t base;                 // LDS byte address of this lane's context 0
-    __device__ uint32_t handle(uint32_t c) const { return base + (c << 8); }
+    static constexpr int kBytes = 32 * 64 * 2;
+    __device__ uint32_t handle(uint32_t c) const { return base + (c << 7); }
     __device__ uint32_t ld(uint32_t h) const { return *(const __attribute__((address_space(3))) unsigned short *) (uintptr_t) h; }
     __device__ void st(uint32_t h, uint32_t v) { *(__attribute__((address_space(3))) unsigned short *) (uintptr_t) h = (unsigned short) v; }
     __device__ void words(uint32_t x[5]) const

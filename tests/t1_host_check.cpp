@@ -80,6 +80,13 @@ struct CkView {                   // CkArray over a plain [pass * nstr + stripe]
         const Contexts c = Contexts::from_bytes(x);
         ck[p * nstr + s] = MqCheckpoint{a, c16, 0, (int) shifts, c.w0, c.w1, c.w2};
     }
+    void store_interval(int p, int s, uint32_t a, uint32_t shifts, const uint32_t x[5])
+    {
+        const Contexts c = Contexts::from_bytes(x);
+        MqCheckpoint &k = ck[p * nstr + s];
+        k.a = a; k.ct = 0; k.pos = (int) shifts; k.w0 = c.w0; k.w1 = c.w1; k.w2 = c.w2;
+    }
+    void store_code(int p, int s, uint32_t c16) { ck[p * nstr + s].c = c16; }
 };
 
 // ---- segmented encoder (scan_block / emit_stripe_segments / mq_encode_segments) ----
@@ -112,7 +119,9 @@ struct RowSrcHost {               // one code-block's row stream (t1_core.hpp: r
     void load(uint32_t row, uint32_t o[4]) const { for (int k = 0; k < 4; k++) o[k] = row < rows() ? (*w)[(size_t) row * 4 + k] : 0x12345678u; }
     bool any(bool b) const { return b; }
     void sync(uint32_t) const {}
+    void finish() const {}
 };
+struct HostHand { std::vector<uint16_t> *v; void put(uint32_t row, int j, uint32_t word) { size_t i = (size_t) row * 16 + j; if (v->size() <= i) v->resize(i + 1); (*v)[i] = (uint16_t) word; } };
 struct CtxCodes { uint16_t *b; uint32_t handle(uint32_t c) const { return c; } uint32_t ld(uint32_t h) const { return b[h]; } void st(uint32_t h, uint32_t v) { b[h] = (uint16_t) v; }
                   void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= mq_code_state(b[i]) << (8 * (i & 3)); } };
 struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end(int) {} void finish(int n) { v->resize((size_t) n); } };
@@ -258,7 +267,17 @@ int main(int argc, char **argv)
                             rowsw.push_back(word);
                         }
                 }
-                EncodeResult r3 = mq_encode_rows(RowSrcHost{&rowsw}, CtxCodes{ctxb3}, numbps, nstr, VecSink3{&bytes3}, VecAt{&bytes3}, rates3, ckv3);
+                std::vector<uint16_t> handv;
+                const uint32_t a_end = mq_rows_interval(RowSrcHost{&rowsw}, CtxCodes{ctxb3}, numbps, nstr, HostHand{&handv}, ckv3);
+                MqCodeChain chain;
+                VecSink3 sink3{&bytes3};
+                ConstTable2 tab3;
+                for (size_t rr = 0; rr * 16 < handv.size(); rr++) {
+                    uint32_t hw[16];
+                    for (int j = 0; j < 16; j++) hw[j] = handv[rr * 16 + j];
+                    chain.row(hw, nstr, rates3, sink3, ckv3, tab3, [](bool b_) { return b_; });
+                }
+                EncodeResult r3 = chain.finish(a_end, numbps > 0 ? 3 * numbps - 2 : 0, rates3, sink3, VecAt{&bytes3});
                 finalize_checkpoints(ckv3, r3.totalpasses, nstr, BufSrc{bytes3.data(), r3.length});
                 bool same = r3.totalpasses == r.totalpasses && r3.length == r.length && memcmp(bytes3.data(), bytes.data(), (size_t) r.length) == 0;
                 for (int p_ = 0; same && p_ < r.totalpasses; p_++) same = rates3[p_] == rates[p_];

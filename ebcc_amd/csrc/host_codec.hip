@@ -782,8 +782,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             auto probe_residual = [&]() {
                 EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64b, rc->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
                 b.push_ractive();
-                launch_reconstruct(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
-                launch_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+                launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
                 fetch_frame_states(rc, n);
             };
             probe_residual();
@@ -819,8 +818,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                 for (;;) {
                     for (int r = 0; r < rounds; r++) {
-                        launch_reconstruct(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
-                        launch_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
+                        launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
                         launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                     }
                     EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));

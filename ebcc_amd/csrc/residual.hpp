@@ -81,6 +81,14 @@ void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned
 void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,
                         const int *d_active, hipStream_t s);
 
+// the same for the LL quadrant of the finest level only (what the coarser synthesis levels read)
+void launch_reconstruct_coarse(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,
+                               const int *d_active, hipStream_t s);
+// launch_reconstruct + launch_synthesis_stats in one: the probe of the truncation search (the finest level's detail bands
+// go from the bookkeeping straight into the streaming column pass)
+void launch_prefix_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
+                                   const unsigned long long *d_trunc_bits, const int *d_active, hipStream_t s);
+
 // idwt2full on A (dwt.h:305-317); result in A
 void launch_synthesis(const ResidualBuffers &rb, int n_frames, const int *d_active, hipStream_t s);
 // The same with the last row pass consuming the rows instead of storing the grid:

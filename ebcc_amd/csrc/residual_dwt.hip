@@ -11,6 +11,7 @@
 // access is a CW*4-byte row segment; the strided walk happens only in LDS.
 #include <mutex>
 #include "residual.hpp"
+#include "residual_device.hpp"
 
 namespace ebcc {
 
@@ -332,6 +333,101 @@ __global__ __launch_bounds__(kColThreads) void k_cols_inv(const float *__restric
             if (c < w) dst[(size_t) y * stride + x0 + c] = ((y & 1) ? O : E)[(y >> 1) * CW + c];
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The finest level's inverse column pass as a STREAM (one thread per column, registers only - cf. k_j2k_cols_fin of
+// the base layer), for the probes of the truncation search: its three detail bands are not read from a reconstructed
+// grid but computed on the fly from the encoder's bookkeeping (prefix_value), the LL quadrant comes from `src` (the
+// coarser levels' result); the result goes to `dst`.  lift_inverse_tile's expressions in its order; the reference's
+// boundary taps (dwt.h:125-139: first low-pass uses O[0] + O[1], last high-pass of step 2 E[h-1] + E[h-2], of step 4
+// (2 alpha) x[n-2]) make the pipeline four positions deep.
+// ------------------------------------------------------------------------------------------------
+struct RPipe {
+    float E_1 = 0, O_1 = 0, O_2 = 0;       // inputs (scaled) of positions j - 1, j - 1, j - 2
+    float a1 = 0, a2 = 0;                  // after step 1: positions j - 2, j - 3
+    float b1 = 0, b2 = 0;                  // after step 2: positions j - 3, j - 4
+    float c1 = 0;                          // after step 3: position j - 4
+    // inputs of position j in; finished samples 2 (j - 4), 2 (j - 4) + 1 out (valid when j - 4 is in [0, half))
+    __device__ void step(int j, int half, float Ein, float Oin, float &x_even, float &x_odd)
+    {
+        const float E0 = Ein / kXi, O0 = Oin * kXi;
+        int k = j - 1;                                                  // step 1
+        float e1 = 0;
+        if (k >= 0 && k < half) e1 = E_1 - kDelta * (O_1 + (k > 0 ? O_2 : O0));
+        k = j - 2;                                                      // step 2
+        float o1 = 0;
+        if (k >= 0 && k < half) o1 = O_2 - kGamma * (a1 + (k + 1 < half ? e1 : a2));
+        k = j - 3;                                                      // step 3
+        float e2 = 0;
+        if (k >= 0 && k < half) e2 = a2 - kBeta * (b1 + (k > 0 ? b2 : o1));
+        k = j - 4;                                                      // step 4
+        x_even = c1;
+        x_odd = (k + 1 < half) ? b2 - kAlpha * (c1 + e2) : b2 - (2 * kAlpha) * c1;
+        O_2 = O_1; O_1 = O0; E_1 = E0;
+        a2 = a1; a1 = e1;
+        b2 = b1; b1 = o1;
+        c1 = e2;
+    }
+};
+
+constexpr int kStreamT = 128;
+__global__ __launch_bounds__(kStreamT) void k_cols_inv_stream(const float *__restrict__ src, float *__restrict__ dst, Grid g, size_t np,
+                                                               const int32_t *__restrict__ Cb, const uint32_t *__restrict__ sigordb,
+                                                               const uint32_t *__restrict__ lspidxb, const FrameState *fsb,
+                                                               const unsigned long long *trunc_bits, const int *active)
+{
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const FrameState &fs = fsb[frame];
+    unsigned long long nb = trunc_bits[frame], bits0 = fs.budget + 128;   // spiht_decode: num_bits = min(num_bits, bits0) - 128 (spiht_re.c:495-500)
+    if (nb > bits0) nb = bits0;
+    const unsigned long long B = nb - 128;
+    __shared__ unsigned int rbase[32], rreach[32];
+    if (threadIdx.x < 32) { rbase[threadIdx.x] = fs.refine_base[threadIdx.x]; rreach[threadIdx.x] = fs.step_reached[threadIdx.x]; }
+    __syncthreads();
+    const int nx = g.nx, ny = g.ny, half = ny >> 1, hx = nx >> 1;
+    const int col = blockIdx.x * kStreamT + threadIdx.x;
+    if (col >= nx) return;
+    const float *a = src + (size_t) frame * np;
+    float *out = dst + (size_t) frame * np;
+    const int32_t *C = Cb + (size_t) frame * np;
+    const uint32_t *so = sigordb + (size_t) frame * np, *li = lspidxb + (size_t) frame * np;
+    // the column is cut into gridDim.z pieces; a piece starts its pipeline two positions early (an output of position
+    // k depends on the inputs of positions k - 2 .. k + 2)
+    const int per = (half + (int) gridDim.z - 1) / (int) gridDim.z, ka = (int) blockIdx.z * per, kb = min(half, ka + per);
+    const int jstart = max(ka - 2, 0);
+    // raw inputs of a position: every lane loads all of them (no data-dependent control flow around the loads), the
+    // values are worked out when the position enters the pipeline, one step later
+    struct Raw { float ll; uint32_t eo, el; int ec; uint32_t oo, ol; int oc; };
+    const bool left = col < hx;
+    auto fetch = [&](int j, Raw &r) {
+        const int jj = min(j, half - 1);
+        const size_t ie = (size_t) jj * nx + col, io = (size_t) (half + jj) * nx + col;
+        r.ll = left ? a[ie] : 0.0f;                                      // (rows above `half` of the left half: the LL quadrant)
+        r.eo = so[ie]; r.ec = C[ie]; r.el = li[ie];
+        r.oo = so[io]; r.oc = C[io]; r.ol = li[io];
+    };
+    auto value = [&](const Raw &r, float &e, float &o) {
+        e = left ? r.ll : prefix_value_of(r.eo, r.ec, r.el, B, rbase, rreach);
+        o = prefix_value_of(r.oo, r.oc, r.ol, B, rbase, rreach);
+    };
+    RPipe p;
+    Raw cur;
+    fetch(jstart, cur);
+    for (int j = jstart; j < kb + 4; j++) {
+        Raw nxt;
+        fetch(j + 1, nxt);
+        float e_in, o_in, xe, xo;
+        value(cur, e_in, o_in);
+        p.step(j, half, e_in, o_in, xe, xo);
+        const int k = j - 4;
+        if (k >= ka && k < kb) {
+            out[(size_t) (2 * k) * nx + col] = xe;
+            out[(size_t) (2 * k + 1) * nx + col] = xo;
+        }
+        cur = nxt;
     }
 }
 
@@ -780,6 +876,36 @@ void launch_synthesis_stats(const float *data, const float *decoded, const Resid
     RowUse u{};
     u.data = data; u.decoded = decoded;
     launch_synthesis_head(rb, n_frames, d_active, s);
+    const int partials = synthesis_tail(rb, n_frames, d_active, s, u);
+    hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, partials, rb.fs, n_frames, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
+// launch_reconstruct + launch_synthesis_stats for the probes of the truncation search, without the finest level's
+// detour through the grid: coarse quadrant reconstructed, coarser levels as usual, then k_cols_inv_stream and the
+// consuming row pass.  (EBCC_HIP_RESIDUAL_SPLIT=1: the separate kernels.)
+void launch_prefix_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
+                                   const unsigned long long *d_trunc_bits, const int *d_active, hipStream_t s)
+{
+    static const bool split = getenv("EBCC_HIP_RESIDUAL_SPLIT") != nullptr;
+    const Grid &g = rb.g;
+    if (split || g.stages < 2 || g.ny < 32) {
+        launch_reconstruct(rb, n_frames, d_trunc_bits, d_active, s);
+        launch_synthesis_stats(data, decoded, rb, n_frames, d_active, s);
+        return;
+    }
+    hipLaunchKernelGGL(k_probe_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, d_active);
+    launch_reconstruct_coarse(rb, n_frames, d_trunc_bits, d_active, s);
+    for (int lv = g.stages - 1; lv >= 1; lv--) {
+        int nx = g.nx >> lv, ny = g.ny >> lv;
+        cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
+        rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
+    }
+    const int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
+    hipLaunchKernelGGL(k_cols_inv_stream, dim3(ceil_div(g.nx, kStreamT), n_frames, pieces), dim3(kStreamT), 0, s, rb.A, rb.T, g, rb.np, rb.C,
+                       rb.sigord, rb.lspidx, rb.fs, d_trunc_bits, d_active);
+    RowUse u{};
+    u.data = data; u.decoded = decoded;
     const int partials = synthesis_tail(rb, n_frames, d_active, s, u);
     hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, partials, rb.fs, n_frames, d_active);
     EBCC_HIP_LAUNCH_CHECK();

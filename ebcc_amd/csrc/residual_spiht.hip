@@ -14,6 +14,7 @@
 // turns the reference's truncation search (17 full SPIHT decodes, ebcc_codec.c:777-795) into an
 // element-wise reconstruction per probe.
 #include "residual.hpp"
+#include "residual_device.hpp"
 
 namespace ebcc {
 
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
 __global__ __launch_bounds__(256) void k_reconstruct(const int32_t *__restrict__ Cb, const uint32_t *__restrict__ sigordb,
                                                       const uint32_t *__restrict__ lspidxb, float *__restrict__ Ab,
                                                       size_t np, const FrameState *fsb,
-                                                      const unsigned long long *trunc_bits, const int *active)
+                                                      const unsigned long long *trunc_bits, const int *active, Grid g, int coarse_only)
 {
     const int frame = blockIdx.y;
     if (active && !active[frame]) return;
@@ -418,24 +419,13 @@ __global__ __launch_bounds__(256) void k_reconstruct(const int32_t *__restrict__
     const uint32_t *so = sigordb + (size_t) frame * np;
     const uint32_t *li = lspidxb + (size_t) frame * np;
     float *A = Ab + (size_t) frame * np;
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (size_t) gridDim.x * blockDim.x) {
-        uint32_t o = so[i];
-        float out = 0.0f;
-        if (o != 0xFFFFFFFFu && (unsigned long long) o <= B) {
-            int c = C[i];
-            unsigned int a = (unsigned int) (c < 0 ? -c : c);
-            int ss = 31 - __clz(a);
-            unsigned int mag = 1u << ss;                                 // spiht_re.c:338,370
-            uint32_t slot = li[i];
-            for (int s = ss - 1; s >= 0; --s) {
-                if (!rreach[s]) break;
-                unsigned long long ord = (unsigned long long) rbase[s] + slot + 1;   // 1-based ordinal of the refinement bit
-                if (ord > B + 1) break;                                  // the bit crossing the budget is still applied (:418-426)
-                mag |= a & (1u << s);
-            }
-            out = c < 0 ? -(float) mag : (float) mag;
-        }
-        A[i] = out;
+    // (coarse_only: the LL quadrant of the finest level - what the coarser synthesis levels need; the finest level takes
+    //  its three detail bands straight from the bookkeeping, k_cols_inv_stream in residual_dwt.hip)
+    const int cx = coarse_only ? g.nx >> 1 : g.nx, cy = coarse_only ? g.ny >> 1 : g.ny;
+    const size_t cnt = (size_t) cx * cy;
+    for (size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += (size_t) gridDim.x * blockDim.x) {
+        const size_t i = coarse_only ? (t / cx) * g.nx + (t % cx) : t;
+        A[i] = prefix_value(C, so, li, i, B, rbase, rreach);
     }
 }
 
@@ -746,7 +736,15 @@ void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned 
                         const int *d_active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_reconstruct, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, rb.A, rb.np,
-                       rb.fs, d_trunc_bits, d_active);
+                       rb.fs, d_trunc_bits, d_active, rb.g, 0);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
+void launch_reconstruct_coarse(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,
+                               const int *d_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reconstruct, dim3(64, n_frames), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, rb.A, rb.np,
+                       rb.fs, d_trunc_bits, d_active, rb.g, 1);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

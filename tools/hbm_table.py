@@ -48,6 +48,7 @@ def algo_bytes(kernel, rank, nkeys):
     if re.match(r"k_(rows|cols)_(fwd|inv)", k):
         lv = rank                                  # 0 = full grid
         return 8 * (NX >> lv) * (NY >> lv), f"level {3 - lv}: read + write {(NX >> lv)}x{(NY >> lv)} fp32"
+    if k.startswith("k_cols_inv_stream"): return 12 * 3 * (NX * NY // 4) + 4 * (NX * NY // 4) + 4 * NX * NY, "finest level columns: three detail bands from the bookkeeping (coefficient + two ordinals), LL read, grid written"
     if k.startswith("k_rows_inv_use"): return 4 * NX * NY + 8 * PIX, "read the grid, the frame and the decoded field (statistics only)"
     if k.startswith("k_truncate"): return 8 * NX * NY, "read fp32 grid, write int32 coefficients"
     if k.startswith("k_descmax"): return 12 * NX * NY, "read coefficients, write two maxima pyramids"

@@ -592,13 +592,42 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
     EBCC_HIP_CHECK(hipMemsetAsync(ctx->d_counter, 0, sizeof(int) * 4, s));
     int rounds = search_rounds();
     // a round = the probe the previous advance asked for (rate allocation + decode of the active chunks), then the advance
-    // that takes it in and asks for the next one
-    launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
+    // that takes it in and asks for the next one.  Speculative rate allocation (EBCC_HIP_NO_SPECULATION=1 turns it off): a
+    // step of the search can go two ways, so the layers of both rates it may ask for next are worked out on the engine's
+    // second stream while the first stream decodes the current probe; the advance then takes the matching one over
+    // (k_rate_publish) and the round's own k_rate only runs for the frames whose rate was not among the guesses.
+    static const bool speculate = getenv("EBCC_HIP_NO_SPECULATION") == nullptr;
+    hipStream_t s2 = nullptr;
+    J2kBuffers &jb = b.jb;
+    if (speculate) {
+        s2 = second_stream(ctx);
+        if (!ctx->ev_a) {
+            EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+            EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+        }
+        EBCC_HIP_CHECK(hipMemsetAsync(jb.cand_cr, 0xFF, sizeof(float) * 2 * b.nt, s));       // (NaN: no candidate matches)
+        EBCC_HIP_CHECK(hipMemsetAsync(jb.have_rate, 0, sizeof(int) * b.nt, s));
+    }
+    auto advance = [&]() {
+        launch_search_advance(d, jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s,
+                              speculate ? jb.cand_cr : nullptr, speculate ? jb.cand_sel : nullptr);
+        if (speculate) launch_j2k_rate_publish(jb, (int) b.nt, s);
+    };
+    advance();
     for (;;) {
         for (int r = 0; r < rounds; r++) {
-            launch_j2k_rate(b.jb, (int) b.nt, b.d_active, s);
-            launch_j2k_probe_decode(b.d_frames, b.jb, (int) b.nt, b.d_active, s, k == 0);     // (search 1 uses the statistics only: the field of search 0 stays)
-            launch_search_advance(d, b.jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s);
+            launch_j2k_rate(jb, (int) b.nt, b.d_active, s, speculate ? jb.have_rate : nullptr);
+            if (speculate) {
+                // the candidates read the record of bisection steps this k_rate may have extended, and the masks / rates of
+                // the advance: after both; the next advance reads their results: after them
+                EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));
+                EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
+                launch_j2k_rate_candidates(jb, (int) b.nt, b.d_active, s2);
+                EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
+            }
+            launch_j2k_probe_decode(b.d_frames, jb, (int) b.nt, b.d_active, s, k == 0);     // (search 1 uses the statistics only: the field of search 0 stays)
+            if (speculate) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
+            advance();
         }
         EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int) * 4, hipMemcpyDeviceToHost, s));

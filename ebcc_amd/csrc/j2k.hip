@@ -65,6 +65,11 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->totalpasses = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->cblk_len = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
     ok &= (jb->npass = (int *) ctx_alloc<int32_t>(ctx, groups * 64)) != nullptr;
+    ok &= (jb->cand_cr = ctx_alloc<float>(ctx, F * 2)) != nullptr;
+    ok &= (jb->cand_out = (int *) ctx_alloc<int32_t>(ctx, F * 6)) != nullptr;
+    ok &= (jb->cand_npass = (int *) ctx_alloc<int32_t>(ctx, 2 * F * (size_t) stride)) != nullptr;
+    ok &= (jb->cand_sel = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
+    ok &= (jb->have_rate = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
     ok &= (jb->rate_path = (int *) ctx_alloc<int32_t>(ctx, F * 1536 * 3)) != nullptr;
     ok &= (jb->rate_path_n = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
     ok &= (jb->rates = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;

@@ -131,6 +131,13 @@ struct J2kBuffers {
     int *rates;                   // [frames*nblocks][kJ2kMaxPasses]
     double *disto;                // [frames*nblocks][kJ2kMaxPasses]
     int *npass;                   // [frames*nblocks] passes in the current layer
+    // speculative rate allocation of the device-driven search (search.hpp): the layers of the two rates the search may ask
+    // for next, worked out beside the current probe's decode
+    float *cand_cr;               // [frames][2] candidate rates (<= 0: none)
+    int *cand_out;                // [frames][2][3] body bytes, stream bytes, byte budget of a candidate's layer
+    int *cand_npass;              // [2][frames*nblocks] its passes per code-block
+    int *cand_sel;                // [frames] candidate whose layer becomes the current one (-1: none)
+    int *have_rate;               // [frames] 1: the current layer was taken over from a candidate (k_rate skips the frame)
     int *rate_path;               // [frames][1536][3] packet bytes at the steps of the rate bisection k_rate has visited, as a trie
     int *rate_path_n;             // [frames] nodes in it; reset by the analysis
     uint8_t *cblk_bytes;          // [frames*nblocks][kJ2kCblkBytes]
@@ -167,7 +174,11 @@ void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool si
 // caller then fetches them again)
 bool j2k_tier1_retry(const J2kBuffers &jb, int n_frames, const J2kFrame *host_jf, hipStream_t s);
 // rate allocation for jf[f].cr (opj_tcd_rateallocate) -> npass, jf.body_bytes/stream_bytes
-void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
+void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, const int *have_rate = nullptr);
+// the same for the candidate rates jb.cand_cr (two per frame) into the candidate slots; launch_j2k_rate_publish makes
+// candidate jb.cand_sel[f] the frame's current layer and sets jb.have_rate
+void launch_j2k_rate_candidates(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
+void launch_j2k_rate_publish(const J2kBuffers &jb, int n_frames, hipStream_t s);
 // write the codestream of the current layer assignment into jb.stream
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
 // what opj_decode returns for the current layer assignment (decoded in place from the code-block

@@ -33,7 +33,7 @@ int t1_lanes_per_wave(int kernel, int total_blocks)
 {
     // EBCC_T1_LPW = "<n>" (all kernels) or "<decision pass>,<MQ pass>,<probe restart>,<decode>", each a power of two up to 64
     // (read at every launch: a tuning knob, results do not depend on it)
-    int t[4] = {64, 64, 4, 4};
+    int t[4] = {64, 64, 4, 2};                                            // (decode: 2 lanes 26.5 ms per 256 frames, 4 lanes 29, 8 lanes 37 - tools/gpu/r2_sweep.sh)
     if (const char *e = getenv("EBCC_T1_LPW")) {
         int v[4], n = sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
         for (int i = 0; i < 4; i++) {

@@ -503,7 +503,8 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                                                         const int *__restrict__ rates, const double *__restrict__ disto,
                                                         int *__restrict__ npass_out, const J2kGeom *geom, J2kFrame *jf,
                                                         const FrameState *fs, const int *active, int pass_capacity,
-                                                        int *__restrict__ path_bytes, int *__restrict__ path_n)
+                                                        int *__restrict__ path_bytes, int *__restrict__ path_n,
+                                                        const float *cand_cr, int *cand_out, size_t cand_stride, const int *have_rate)
 {
     extern __shared__ unsigned char lds_raw[];
     __shared__ int s_sum, s_changed;
@@ -515,6 +516,16 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     __shared__ int s_ti[5], s_nun, s_list[64];
     const int frame = blockIdx.x, lane = threadIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
+    // Candidate mode (cand_cr != null; launch_j2k_rate_candidates): the layer of a rate the search MAY ask for next, worked out
+    // beside the decode of the current probe - blockIdx.y = which of the two candidates; results go to the candidate slots
+    // (cand_out, npass_out + slot * cand_stride) and the trie of recorded bisection steps is only read.  Normal mode: frames
+    // whose layer was taken over from a candidate (have_rate) are done already.
+    const bool candidate = cand_cr != nullptr;
+    const int slot = candidate ? (int) blockIdx.y : 0;
+    const float cr_in = candidate ? cand_cr[2 * frame + slot] : jf[frame].cr;
+    if (candidate ? !(cr_in > 0.0f) : (have_rate && have_rate[frame])) return;
+    if (candidate) npass_out += (size_t) slot * cand_stride;
+    const bool record = !candidate;
     const J2kGeom &g = j2k_frame_geom(geom, frame);
     const int gid0 = frame * g.stride;
     RateLds L;
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     };
 
     // opj_j2k_setup_encoder / opj_j2k_update_rates: byte budget of the single layer
-    float rate = jf[frame].cr / 2;                                   // tcp_rates[0] = base_cr / 2, ebcc_codec.c:116
+    float rate = cr_in / 2;                                          // tcp_rates[0] = base_cr / 2, ebcc_codec.c:116
     if (rate <= 1.0f) rate = 0.0f;                                   // "force lossless"
     if (rate > 0.0f) {
         rate = (float) (((double) 16 * (double) g.W * (double) g.H) / ((double) rate * (double) 8)) - 0.0f;
@@ -676,7 +687,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             n_it++; n_real += (at_lo || at_hi) ? 0 : s_changed;
 #endif
             const bool fits = (long long) bytes <= maxlen;
-            if (n_nodes < kRateTrieNodes && (parent >= 0 || n_nodes == 0)) {   // record this step and hang it under the previous one
+            if (record && n_nodes < kRateTrieNodes && (parent >= 0 || n_nodes == 0)) {   // record this step and hang it under the previous one
                 if (lane == 0) {
                     trie[3 * n_nodes] = bytes; trie[3 * n_nodes + 1] = 0; trie[3 * n_nodes + 2] = 0;
                     if (parent >= 0) trie[3 * parent + 1 + pdir] = n_nodes;
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                         tthresh = t; tprev = t; ti = j;
                         const int bytes = all_lo ? bytes_lo : bytes_hi;
                         const bool fits = (long long) bytes <= maxlen;
-                        if (tn < kRateTrieNodes && (tparent >= 0 || tn == 0)) {
+                        if (record && tn < kRateTrieNodes && (tparent >= 0 || tn == 0)) {
                             if (lane == 0) {
                                 trie[3 * tn] = bytes; trie[3 * tn + 1] = 0; trie[3 * tn + 2] = 0;
                                 if (tparent >= 0) trie[3 * tparent + 1 + tpdir] = tn;
@@ -760,7 +771,11 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     if (!converged) make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, good, lane);
     const int body = sized();
     for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
-    if (lane == 0) {
+    if (lane == 0 && candidate) {
+        int *o = cand_out + (size_t) (2 * frame + slot) * 3;
+        o[0] = body; o[1] = kMainHeaderBytes + 12 + 2 + body + 2; o[2] = (int) (rate > 0.0f ? ceil((double) rate) : 0);
+    }
+    if (lane == 0 && !candidate) {
         jf[frame].body_bytes = body;
         jf[frame].stream_bytes = kMainHeaderBytes + 12 + 2 + body + 2;
         jf[frame].maxlen = (int) (rate > 0.0f ? ceil((double) rate) : 0);
@@ -1218,9 +1233,8 @@ size_t rate_lds(const J2kBuffers &jb)
 }  // namespace
 
 // ================================================================================================
-void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
+static void rate_launch(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, bool candidates, const int *have_rate)
 {
-    ScopedTiming t("rate_alloc", s);
     // dynamic LDS: the carve-up, the per-block table offsets, then as many (rate, distortion) entries as fit
     const size_t head = ((rate_lds(jb) + 15) & ~(size_t) 15) + rate_off_bytes(jb.geom.stride) + rate_path_bytes(jb.geom.stride);
     const size_t budget = 150 * 1024;
@@ -1231,8 +1245,42 @@ void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hi
     std::call_once(once, [] {
         EBCC_HIP_CHECK(hipFuncSetAttribute((const void *) k_rate, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     });
-    hipLaunchKernelGGL(k_rate, dim3(n_frames), dim3(kRateThreads), lds, s, jb.numbps, jb.totalpasses, jb.rates,
-                       jb.disto, jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want, jb.rate_path, jb.rate_path_n);
+    hipLaunchKernelGGL(k_rate, dim3(n_frames, candidates ? 2 : 1), dim3(kRateThreads), lds, s, jb.numbps, jb.totalpasses, jb.rates,
+                       jb.disto, candidates ? jb.cand_npass : jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want, jb.rate_path, jb.rate_path_n,
+                       candidates ? jb.cand_cr : nullptr, jb.cand_out, (size_t) jb.max_frames * (size_t) jb.geom.stride, have_rate);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
+void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, const int *have_rate)
+{
+    ScopedTiming t("rate_alloc", s);
+    rate_launch(jb, n_frames, d_active, s, false, have_rate);
+}
+
+void launch_j2k_rate_candidates(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s)
+{
+    rate_launch(jb, n_frames, d_active, s, true, nullptr);
+}
+
+// takes the layer of candidate sel[f] (0 / 1; -1: none) over as the frame's current layer
+__global__ void k_rate_publish(const int *sel, const int *cand_npass, const int *cand_out, size_t cand_stride, int *npass, J2kFrame *jf,
+                               const J2kGeom *geom, int *have_rate)
+{
+    const int frame = blockIdx.x, c = sel[frame];
+    if (threadIdx.x == 0) have_rate[frame] = c >= 0 ? 1 : 0;
+    if (c < 0) return;
+    const int nb = geom->stride;
+    const int *src = cand_npass + (size_t) c * cand_stride + (size_t) frame * nb;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) npass[(size_t) frame * nb + b] = src[b];
+    if (threadIdx.x == 0) {
+        const int *o = cand_out + (size_t) (2 * frame + c) * 3;
+        jf[frame].body_bytes = o[0]; jf[frame].stream_bytes = o[1]; jf[frame].maxlen = o[2];
+    }
+}
+void launch_j2k_rate_publish(const J2kBuffers &jb, int n_frames, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rate_publish, dim3(n_frames), dim3(64), 0, s, jb.cand_sel, jb.cand_npass, jb.cand_out,
+                       (size_t) jb.max_frames * (size_t) jb.geom.stride, jb.npass, jb.jf, jb.d_geom, jb.have_rate);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

@@ -41,15 +41,53 @@ __device__ const DevProbe *find_probe(const DevChunk &c, float cr)
     return nullptr;
 }
 
+// The rate the search would ask for next if the probe it is waiting for (at R.want_cr) came back with quantile q_hyp
+// (1.0: "feasible", 0.0: "not feasible" - the two ways a step of :545-596 can go); -1 if it would ask for none.  Works
+// on copies: a guess for the speculative rate allocation, the search itself is advanced by k_search_advance alone.
+__device__ float next_rate_if(const DevChunk &C, const DevRateSearch &R, int k, double q_hyp, double n_pix)
+{
+    if (R.phase > 3) return -1.0f;                                      // (the probe restoring the decode is the last one)
+    DevRateSearch T = R;
+    rs_feed(T, q_hyp);
+    const float scr = k == 0 ? R.want_cr : C.state_cr;                   // the decode the engine will hold then
+    while (T.phase < 4) {
+        float cr;
+        if (!rs_next(T, cr)) break;
+        const DevProbe *rec = find_probe(C, cr);
+        const bool known = rec != nullptr || cr == R.want_cr;
+        const bool needs_state = k == 0 && T.phase == 3 && scr != cr;
+        if (!known || needs_state) return cr;
+        rs_feed(T, rec ? 1. - ((double) rec->nbad / n_pix) : q_hyp);
+    }
+    if (T.phase == 4 && k == 0 && scr != T.result) return T.result;
+    return -1.0f;
+}
+
 __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, int n_chunks, int tiles, int k, double n_pix,
-                                 int *unfinished)
+                                 int *unfinished, float *cand_cr, int *cand_sel)
 {
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= n_chunks) return;
     DevChunk &C = chunks[ci];
     DevRateSearch &R = C.rs[k];
     const int t0 = ci * tiles;
-    auto set_active = [&](int v) { for (int t = 0; t < tiles; t++) active[t0 + t] = v; };
+    // speculative rate allocation: which of the previous round's two candidates (if any) is the rate asked for now, and the
+    // two candidates for the next round
+    const float old0 = cand_cr ? cand_cr[2 * t0] : -1.0f, old1 = cand_cr ? cand_cr[2 * t0 + 1] : -1.0f;
+    auto set_active = [&](int v) {
+        for (int t = 0; t < tiles; t++) active[t0 + t] = v;
+        if (cand_cr) {
+            int sel = -1;
+            float c0 = -1.0f, c1 = -1.0f;
+            if (v) {
+                sel = R.want_cr == old0 ? 0 : (R.want_cr == old1 ? 1 : -1);
+                c0 = next_rate_if(C, R, k, 1.0, n_pix);
+                c1 = next_rate_if(C, R, k, 0.0, n_pix);
+                if (c1 == c0) c1 = -1.0f;
+            }
+            for (int t = 0; t < tiles; t++) { cand_sel[t0 + t] = sel; cand_cr[2 * (t0 + t)] = c0; cand_cr[2 * (t0 + t) + 1] = c1; }
+        }
+    };
     if (C.const_field || R.phase == 6) { set_active(0); return; }
     auto feed = [&](const DevProbe &rec) {
         if (R.phase == 3) R.last = rec;
@@ -126,10 +164,10 @@ __global__ void k_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned
 }  // namespace
 
 void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_chunks, int tiles, int k, double n_pix,
-                           int *unfinished, hipStream_t s)
+                           int *unfinished, hipStream_t s, float *cand_cr, int *cand_sel)
 {
     hipLaunchKernelGGL(k_search_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, jf, d_active, n_chunks, tiles, k, n_pix,
-                       unfinished);
+                       unfinished, cand_cr, cand_sel);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

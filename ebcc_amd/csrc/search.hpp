@@ -50,8 +50,10 @@ struct DevChunk {                  // per chunk (= frame, or the frames coded as
 // One round of rate search k for every chunk: take in the probe made for it in the previous round (if any), walk the
 // state machine through probes already on record, and either ask for the next probe (jf[tile].cr, active[tile] = 1)
 // or finish.  `unfinished` (device int) is incremented by every chunk that still wants a probe.
+// cand_cr / cand_sel (J2kBuffers, may be null): speculative rate allocation - the round also says which of the previous round's
+// two candidate rates is the one asked for now (cand_sel) and writes the two rates the search can ask for next (cand_cr).
 void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_chunks, int tiles, int k, double n_pix,
-                           int *unfinished, hipStream_t s);
+                           int *unfinished, hipStream_t s, float *cand_cr = nullptr, int *cand_sel = nullptr);
 
 // One round of the truncation bisection: take in the statistics of the cut made in the previous round, choose the next
 // cut (trunc_bits[f], active[f] = 1) or finish.

@@ -450,14 +450,15 @@ def test_host_and_device_search_loops_agree(monkeypatch):
     for mode, err in ((L.MAX_ERROR, 0.03), (L.RELATIVE_ERROR, 2e-3)):
         cfg = L.make_config((1, 96, 160), base_cr=40.0, error=err, residual_type=mode)
         got = {}
-        for name, env in (("device", {}), ("host", {"EBCC_HIP_HOST_SEARCH": "1"}), ("short", {"EBCC_HIP_SEARCH_ROUNDS": "3"})):
+        for name, env in (("device", {}), ("host", {"EBCC_HIP_HOST_SEARCH": "1"}), ("short", {"EBCC_HIP_SEARCH_ROUNDS": "3"}),
+                          ("plain", {"EBCC_HIP_NO_SPECULATION": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             with L.Context(len(frames), 96, 160) as ctx:
                 got[name] = ctx.encode_frames(frames, cfg)
             for k in env:
                 monkeypatch.delenv(k)
-        assert got["device"] == got["host"] == got["short"], mode
+        assert got["device"] == got["host"] == got["short"] == got["plain"], mode
         L.oracle().orc_set_j2k_backend(0)
         assert got["device"][3] == L.orc_encode(frames[3], cfg)
 

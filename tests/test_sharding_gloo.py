@@ -37,7 +37,15 @@ def _worker(rank, world, port, n_frames, q):
 
     out = sharding.encode_stack_sharded(frames, cfg, encode_fn)
     if rank == 0:
-        q.put(out)
+        # the host-thread budget of a rank (product library; no GPU needed): with LOCAL_WORLD_SIZE ranks on the node a rank
+        # keeps its compressing threads - all slices together - within its share of the CPUs
+        import ctypes
+        budget = None
+        if os.path.exists(L.PRODUCT_SO):
+            os.environ["LOCAL_WORLD_SIZE"] = "8"
+            os.environ.pop("EBCC_HOST_THREADS", None)
+            budget = (sharding.host_threads_per_rank(ctypes.CDLL(L.PRODUCT_SO), 4), len(os.sched_getaffinity(0)))
+        q.put((out, budget))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,7 +60,10 @@ def test_two_rank_sharded_container_equals_serial(n_frames):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, budget = q.get(timeout=120)
+    if budget is not None:
+        threads, cpus = budget
+        assert 4 <= threads <= max(4, cpus // 8), budget          # (at least one thread per slice)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

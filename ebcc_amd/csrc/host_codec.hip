@@ -625,7 +625,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
                 launch_j2k_rate_candidates(jb, (int) b.nt, b.d_active, s2);
                 EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
             }
-            launch_j2k_probe_decode(b.d_frames, jb, (int) b.nt, b.d_active, s, k == 0);     // (search 1 uses the statistics only: the field of search 0 stays)
+            launch_j2k_probe_decode(b.d_frames, jb, (int) b.nt, b.d_active, s, k == 0 ? 2 : 0);     // (the field is stored where the advance asked for it: search.hip keeps_field)
             if (speculate) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
             advance();
         }
@@ -1136,9 +1136,8 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));                       // frame states and the staged pieces are on the device
         EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
     }
-    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table, table_ints * sizeof(int), hipMemcpyHostToDevice, s));
-    launch_j2k_decode(jb, (int) n, s);
-    if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
+    // the residual stream is fed first: its one-wave-per-frame kernel has to find a wave slot on every CU, and once the
+    // tier-1 decoder's ~10^4 workgroups (longest code-blocks first) hold the slots none frees up for milliseconds
     if (any_resid) {
         const size_t slot = ctx->rb.stream_words * 4;
         for (size_t f = 0; f < n; f++) {
@@ -1151,10 +1150,13 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_active, ctx->h_active, n * sizeof(int), hipMemcpyHostToDevice, s2));
         launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n, ctx->d_active, s2);
         launch_synthesis_head(ctx->rb, (int) n, ctx->d_active, s2);
-        if (s2 != s) {
-            EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
-            EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
-        }
+        if (s2 != s) EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
+    }
+    EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table, table_ints * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_j2k_decode(jb, (int) n, s);
+    if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
+    if (any_resid) {
+        if (s2 != s) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
         launch_synthesis_tail_add(jb.DEC, ctx->rb, (int) n, ctx->d_active, s);       // last row pass: DEC += residual
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));

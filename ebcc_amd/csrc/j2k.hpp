@@ -97,6 +97,7 @@ struct J2kFrame {                 // per-frame scalars (device)
     unsigned long long nbad;      // count(|x - d| > target) of the last decode
     double err_sum;               // sum(x - d)
     int overflow;                 // bit 0: a code-block outgrew its byte slot; bit 1: a group's decisions outgrew its rows of SYM (retry: launch_j2k_tier1)
+    int keep;                     // probes launched with keep_field == 2 store their decoded field only where this is set (search.hip)
     float hdr_share;              // this tile's share of the main header in the byte budget (opj_j2k_update_rates:
                                   // main header bytes / number of tiles); 0 = a single tile = all 135 bytes
 };
@@ -145,6 +146,7 @@ struct J2kBuffers {
     size_t stream_cap;
     int32_t *V;                   // [frames][H*W] tier-1 decoder output (half units), decode path
     int *dec_table;               // [frames*nblocks][4]: offset, len, numbps, npasses (decode path)
+    int *dec_order;               // [frames*nblocks] code-blocks by falling segment length, then [128] counters (decode path)
     J2kFrame *jf;                 // [frames]
     FrameState *fs;               // [frames] (shared with the residual layer)
     double *partial;              // [frames][kPartials]
@@ -183,9 +185,9 @@ void launch_j2k_rate_publish(const J2kBuffers &jb, int n_frames, hipStream_t s);
 void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);
 // what opj_decode returns for the current layer assignment (decoded in place from the code-block
 // slots), mapped to fp32 as :1130 -> jb.DEC (keep_field; a probe that is only asked for the statistics leaves jb.DEC
-// as it is), and the error statistics against `data`
+// as it is; keep_field == 2: per frame, where jf[f].keep is set), and the error statistics against `data`
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s,
-                             bool keep_field = true);
+                             int keep_field = 1);
 // true decode of codestreams whose packet headers were parsed on the host into jb.dec_table
 // (fs[f].minv/maxv must hold the header's values); result in jb.DEC
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s);

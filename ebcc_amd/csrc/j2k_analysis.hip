@@ -370,6 +370,11 @@ struct J2kFinish {
     const J2kFrame *jf;
     double *partial;               // [frames][kPartials]
     unsigned long long *partial_u;
+    int per_frame;                 // DEC is written only for frames with jf[frame].keep set
+    __device__ float *field(int frame, size_t n_pix) const
+    {
+        return DEC && (!per_frame || jf[frame].keep) ? DEC + (size_t) frame * n_pix : nullptr;      // (null: statistics only)
+    }
 };
 
 // columns of the region [0,cols) x [0,n) at resolution r, CW columns per tile staged through LDS, in place.  The
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(kColT) void k_j2k_cols(float *__restrict__ B, const
             __shared__ unsigned int redu[kColT / 64];
             const size_t n_pix = (size_t) W * g.H;
             const float *x = fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
-            float *d = fin.DEC ? fin.DEC + (size_t) frame * n_pix : nullptr;     // (null: statistics only)
+            float *d = fin.field(frame, n_pix);
             const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
             const float target = x ? fin.jf[frame].target : 0.0f;
             double acc = 0;
@@ -485,7 +490,8 @@ __global__ __launch_bounds__(kFinT) void k_j2k_cols_fin(const float *__restrict_
     const bool live = col < cols;
     const float *lo = B + (size_t) frame * n_pix + (live ? col : 0), *hi = lo + (size_t) sn * W;
     const float *x = fin.data ? fin.data + (size_t) frame * n_pix + (live ? col : 0) : nullptr;
-    float *d = fin.DEC ? fin.DEC + (size_t) frame * n_pix + (live ? col : 0) : nullptr;       // (null: statistics only)
+    float *d = fin.field(frame, n_pix);
+    if (d && live) d += col;
     const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
     const float target = x ? fin.jf[frame].target : 0.0f;
     const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(const float *__restrict__
     const float s_hl = 0.5f * g.bands[3 * (r - 1) + 1].step_dec, s_lh = 0.5f * g.bands[3 * (r - 1) + 2].step_dec,
                 s_hh = 0.5f * g.bands[3 * (r - 1) + 3].step_dec;
     const float *x = fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
-    float *d = fin.DEC ? fin.DEC + (size_t) frame * n_pix : nullptr;             // (null: statistics only)
+    float *d = fin.field(frame, n_pix);
     const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
     const float target = x ? fin.jf[frame].target : 0.0f;
     const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
@@ -1413,7 +1419,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
 // field jb.DEC, with the error statistics against `data` (if given) left as partial sums per frame; used by both
 // decode flavours (j2k_rate.hip).  Returns the number of partials per frame.
 int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuffers &jb, int n_frames, const FrameState *fs,
-                    const int *active, hipStream_t s, bool keep_field)
+                    const int *active, hipStream_t s, int keep_field)
 {
     int partials = 0;
     // plain frames: the top level in one fused pass (k_j2k_level5_fin); EBCC_HIP_L5_SPLIT=1 keeps the separate row / column passes
@@ -1426,12 +1432,12 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
             const int pieces = std::max(1, std::min({4, kPartials / strips, jb.geom.rh[r - 1] / 16}));
             partials = strips * pieces;
             hipLaunchKernelGGL(k_j2k_level5_fin, dim3(strips, n_frames, pieces), dim3(64), 0, s, B, V, jb.d_geom, fs, active,
-                               J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u});
+                               J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2});
             break;
         }
         dwt_rows<false>(B, V, jb, r, n_frames, fs, active, s);
         if (r + 1 < kJ2kRes) dwt_cols<false>(B, jb, r, n_frames, fs, active, s);
-        else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u});
+        else partials = dwt_cols<false, true>(B, jb, r, n_frames, fs, active, s, J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2});
     }
     EBCC_HIP_LAUNCH_CHECK();
     return partials;

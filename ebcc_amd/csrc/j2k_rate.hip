@@ -19,7 +19,7 @@
 namespace ebcc {
 
 int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuffers &jb, int n_frames, const FrameState *fs,
-                    const int *active, hipStream_t s, bool keep_field);
+                    const int *active, hipStream_t s, int keep_field);
 
 namespace {
 
@@ -998,6 +998,112 @@ __global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const
 }
 
 
+// ---- the same decoder with its state next to the SIMD: the four row-mask arrays of a code-block (S, NEG, VIS, REF: 258
+// rows of 8 bytes) live in LDS, not in jb.T1S, and the segment's bytes come through a register window that is one
+// 16-byte chunk ahead of the decoder.  A stripe of a coding pass starts with 16-20 row loads and ends with 12 row stores:
+// from HBM/L2 every one of the ~500 stripe-passes of a code-block cost a round trip (and a load also waits for the value
+// scatter before it - loads and stores share the counter); the decoder was waiting, not computing (30% of its VALU slots).
+// The only global accesses left in the decision loops are the fire-and-forget value scatter and the byte prefetch.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+struct DecStoreLds {
+    uint32_t base;     // LDS byte address of this lane's row 0
+    uint32_t stride;   // bytes between rows (8 * lanes per wave)
+    int32_t *v;        // tile-buffer position of the block's (0,0)
+    int W;
+    __device__ lds_u64 &at(int row) const { return *(lds_u64 *) (uintptr_t) (base + (uint32_t) row * stride); }
+    __device__ lds_u64 &S(int y) { return at(y + 1); }
+    __device__ lds_u64 &NEG(int y) { return at(66 + y); }
+    __device__ lds_u64 &VIS(int y) { return at(130 + y); }
+    __device__ lds_u64 &REF(int y) { return at(194 + y); }
+    __device__ void set_sig(int x, int y, int neg, int plane)
+    {
+        int one = 1 << (plane + 1), val = one | (one >> 1);
+        v[y * W + x] = neg ? -val : val;
+    }
+    __device__ void refine(int x, int y, int bit, int plane, int neg)
+    {
+        const int half = 1 << plane;
+        atomicAdd(&v[y * W + x], (bit ^ neg) ? half : -half);
+    }
+};
+constexpr int kDecStateRows = 258;
+struct DecSrcAhead {
+    // 16-byte aligned chunks of the stream slot: `cur` holds chunk k, `nxt` chunk k + 1 (requested when the decoder
+    // entered chunk k, ~100 decisions before its first byte is wanted).  Chunks without a byte of the segment are not read.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint8_t *base;           // 16-byte aligned address at or before the segment's first byte
+    int a0, n, k = -2;             // offset of the first byte inside its chunk; segment bytes; chunk in `cur`
+    u32x4 cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
+    __device__ DecSrcAhead(const uint8_t *p, int len) : base((const uint8_t *) ((uintptr_t) p & ~(uintptr_t) 15)), a0((int) ((uintptr_t) p & 15)), n(len) {}
+    __device__ u32x4 chunk(int c) const
+    {
+        if (c * 16 >= a0 + n) return u32x4{0, 0, 0, 0};
+        return *(const __attribute__((address_space(1))) u32x4 *) (uintptr_t) (base + (size_t) c * 16);    // (a global, not a flat, load)
+    }
+    __device__ uint32_t get(int i)
+    {
+        if (i >= n) return 0xFFu;
+        const int o = i + a0, c = o >> 4;
+        if (c != k) {
+            cur = c == k + 1 ? nxt : chunk(c);
+            nxt = chunk(c + 1);
+            k = c;
+        }
+        const uint32_t w = (o & 8) ? ((o & 4) ? cur.w : cur.z) : ((o & 4) ? cur.y : cur.x);
+        return (w >> (8 * (o & 3))) & 0xFFu;
+    }
+};
+
+// Longest first: a code-block is one serial chain (a large one ~10 ms of dependent instructions), so the launch ends
+// when the last large block does.  The blocks are put in order of falling segment length (a counting sort over 64
+// length classes, k_dec_hist / k_dec_offsets / k_dec_place) and the waves take them in that order: the long chains start
+// at once, the short ones fill in behind them, and the lanes of a wave hold blocks of similar length.
+constexpr int kDecClasses = 64;
+__device__ inline int dec_class(const int *e) { return e[3] <= 0 || e[2] <= 0 ? 0 : min(kDecClasses - 1, 1 + (e[1] >> 6)); }
+__global__ void k_dec_hist(const int *dec_table, int *counters, int total)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < total) atomicAdd(&counters[dec_class(dec_table + (size_t) gid * 4)], 1);
+}
+__global__ void k_dec_offsets(int *counters)                         // [0,64) counts -> [64,128) first slot of every class
+{
+    const int c = threadIdx.x;
+    int before = 0;
+    for (int k = kDecClasses - 1; k > c; k--) before += counters[k];
+    counters[kDecClasses + c] = before;
+}
+__global__ void k_dec_place(const int *dec_table, int *counters, int *order, int total)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < total) order[atomicAdd(&counters[kDecClasses + dec_class(dec_table + (size_t) gid * 4)], 1)] = gid;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_t1_decode_lds(const uint8_t *bytes, size_t stream_cap, const int *dec_table, const int *order, int32_t *V,
+                                                       const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total, int lpw)
+{
+    extern __shared__ unsigned long long dec_state[];                  // [kDecStateRows][lpw]
+    EBCC_LDS_MQ_TABLE(tab);
+    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
+    const int slot = blockIdx.x * lpw + threadIdx.x;
+    if (slot >= total) return;
+    const int gid = order[slot];
+    const int nb = geom->stride;
+    const int frame = gid / nb, bi = gid - frame * nb;
+    if (fs[frame].const_field) return;
+    blocks = j2k_frame_blocks(geom, blocks, frame);
+    geom = &j2k_frame_geom(geom, frame);
+    const int *e = dec_table + (size_t) gid * 4;
+    const int len = e[1], P = e[2], np = e[3];
+    const uint8_t *src = bytes + (size_t) frame * stream_cap + e[0];
+    if (np <= 0 || P <= 0) return;
+    const J2kBlock blk = blocks[bi];
+    DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lpw * 8u,
+                   V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
+    for (int r = 0; r < kDecStateRows; r++) st.at(r) = 0ull;
+    t1::decode_block(st, DecSrcAhead(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
+}
+
+
 // ---- the same decode with the segment-locked decoder (t1_decode.hpp): one wave per group of 64 code-blocks, a
 // code-block per lane, every lane in the same (bit-plane, pass, stripe).  The bytes of a code-block's segment come
 // through a 256-byte ring per lane in LDS that the wave tops up at the start of every coding pass (and whenever a lane
@@ -1292,7 +1398,7 @@ void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, h
 }
 
 static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, bool stats, hipStream_t s,
-                        bool keep_field = true)
+                        int keep_field = 1)
 {
     // dequantisation happens in the row passes, the mapping to the fp32 field and the statistics in the last column pass
     const int partials = j2k_inverse_dwt(jb.B, jb.V, stats ? data : nullptr, jb, n_frames, jb.fs, d_active, s, keep_field);
@@ -1301,7 +1407,7 @@ static void decode_tail(const float *data, const J2kBuffers &jb, int n_frames, c
                            n_frames, partials, jb.fs, d_active);
 }
 
-void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, bool keep_field)
+void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, int keep_field)
 {
     const int total = n_frames * jb.geom.stride;
     void *ck = jb.ckpt;
@@ -1325,20 +1431,32 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
     const int total = n_frames * jb.geom.stride;
     const size_t groups = ((size_t) total + 63) / 64;
-    EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
+    static const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
+    static const bool global_state = getenv("EBCC_HIP_T1_DECODE_GLOBAL") != nullptr;         // (the decoder with its state in jb.T1S)
+    const int lpw = t1_lanes_per_wave(T1_DECODE);
+    const bool lds_state = !seg_decoder && !global_state && lpw <= 16;
+    if (!lds_state) EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_decode", s);
     // EBCC_HIP_T1_DECODE_SEG=1: the segment-locked decoder (t1_decode.hpp) - identical results, 64 code-blocks per wave;
     // measured 67 ms per 256 frames against 29 ms for the per-sample decoder at 4 code-blocks per wave (its decision loop
     // is still ~600 instructions), so it is not the default
-    static const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
     if (seg_decoder) {
         hipLaunchKernelGGL(k_t1_decode_seg, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap, jb.dec_table, jb.V,
                            jb.d_geom, jb.d_blocks, jb.fs, total);
     } else {
-        const int lpw = t1_lanes_per_wave(T1_DECODE);
-        hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
-                           jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
+        if (lds_state) {
+            int *counters = jb.dec_order + groups * 64;
+            EBCC_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * kDecClasses * sizeof(int), s));
+            hipLaunchKernelGGL(k_dec_hist, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, total);
+            hipLaunchKernelGGL(k_dec_offsets, dim3(1), dim3(kDecClasses), 0, s, counters);
+            hipLaunchKernelGGL(k_dec_place, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, jb.dec_order, total);
+            hipLaunchKernelGGL(k_t1_decode_lds, dim3((unsigned) ceil_div(total, lpw)), dim3(64), (size_t) kDecStateRows * lpw * 8, s, jb.stream,
+                               jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
+        }
+        else
+            hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
+                               jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
     }
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);

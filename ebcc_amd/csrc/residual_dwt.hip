@@ -398,16 +398,19 @@ __global__ __launch_bounds__(kStreamT) void k_cols_inv_stream(const float *__res
     // k depends on the inputs of positions k - 2 .. k + 2)
     const int per = (half + (int) gridDim.z - 1) / (int) gridDim.z, ka = (int) blockIdx.z * per, kb = min(half, ka + per);
     const int jstart = max(ka - 2, 0);
-    // raw inputs of a position: every lane loads all of them (no data-dependent control flow around the loads), the
-    // values are worked out when the position enters the pipeline, one step later
+    // raw inputs of a position, requested one step before the position enters the pipeline.  The ordinal of the
+    // significance bit is always read; coefficient and LSP slot only where that bit lies inside the prefix (at the usual
+    // cut points most coefficients are still insignificant: the frame is HBM-bound on these probes, not latency-bound)
     struct Raw { float ll; uint32_t eo, el; int ec; uint32_t oo, ol; int oc; };
     const bool left = col < hx;
     auto fetch = [&](int j, Raw &r) {
         const int jj = min(j, half - 1);
         const size_t ie = (size_t) jj * nx + col, io = (size_t) (half + jj) * nx + col;
         r.ll = left ? a[ie] : 0.0f;                                      // (rows above `half` of the left half: the LL quadrant)
-        r.eo = so[ie]; r.ec = C[ie]; r.el = li[ie];
-        r.oo = so[io]; r.oc = C[io]; r.ol = li[io];
+        r.eo = left ? 0xFFFFFFFFu : so[ie]; r.ec = 0; r.el = 0;
+        if (r.eo != 0xFFFFFFFFu && (unsigned long long) r.eo <= B) { r.ec = C[ie]; r.el = li[ie]; }
+        r.oo = so[io]; r.oc = 0; r.ol = 0;
+        if (r.oo != 0xFFFFFFFFu && (unsigned long long) r.oo <= B) { r.oc = C[io]; r.ol = li[io]; }
     };
     auto value = [&](const Raw &r, float &e, float &o) {
         e = left ? r.ll : prefix_value_of(r.eo, r.ec, r.el, B, rbase, rreach);

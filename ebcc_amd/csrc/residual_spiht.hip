@@ -477,6 +477,9 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
 {
     const int frame = blockIdx.x;
     if (active && !active[frame]) return;
+    // one wave, one long dependent chain: it runs beside the tier-1 decoder's thousands of waves (other stream), which
+    // keep every SIMD's issue slots busy - ask the arbiter to serve this wave first (10.6 ms alone, 25.7 ms without this)
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const uint8_t *S = streams + (size_t) frame * stream_stride;
     const unsigned long long size = sizes[frame];
@@ -517,6 +520,19 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
     unsigned long long cnt = 0;            // SPIHT bits consumed (bit_cnt of the reference)
     bool stop = false;
     const unsigned long long lanemask_lt = (1ull << lane) - 1;
+    // The stream window: word wbase + l of the stream in lane l (2048 bits).  A chunk of 64 list entries consumes at most
+    // 576 of them, so the window is kept across chunks and re-read only when the next chunk might run off its end -
+    // the kernel is one dependent chain per frame, and every load it has to wait for is ~1 us of that chain.
+    unsigned long long wbase = ~0ull;
+    unsigned int wreg = 0;
+    auto window = [&](unsigned long long pos, int need_words) -> int {   // window offset of stream bit `pos`
+        const unsigned long long w0 = pos >> 5;
+        if (wbase == ~0ull || w0 < wbase || w0 + (unsigned long long) need_words > wbase + kWave) {
+            wbase = w0;
+            wreg = load_be_word(S, size, wbase + lane);
+        }
+        return (int) (pos - (wbase << 5));
+    };
 
     for (int s = top; s >= 0 && !stop; --s) {
         const unsigned int n_old = nlsp;
@@ -524,14 +540,16 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
 
         // ---------------- LIP pass, spiht_re.c:331-343
         {
+            __threadfence_block();                                     // (entries the previous LIS pass appended)
             unsigned int wr = 0;
+            unsigned int p_next = lane < (int) nlip ? lip[lane] : 0u;
             for (unsigned int base = 0; base < nlip && !stop; base += kWave) {
                 int m = (int) min((unsigned int) kWave, nlip - base);
                 bool valid = lane < m;
-                unsigned int p = valid ? lip[base + lane] : 0;
-                unsigned long long pos = kHeaderBits + cnt;
-                unsigned int wreg = load_be_word(S, size, (pos >> 5) + lane);
-                int o0 = (int) (pos & 31), o = o0, myoff = 0;
+                const unsigned int p = p_next;
+                // the next chunk's entries are requested now: this chunk writes below base + 64 only
+                if (base + kWave < nlip) p_next = base + kWave + lane < nlip ? lip[base + kWave + lane] : 0u;
+                int o0 = window(kHeaderBits + cnt, 7), o = o0, myoff = 0;                // 64 * 2 bits, the offset inside the first word, one word of slack
                 for (int j = 0; j < m; j++) {
                     unsigned int b = win_bit(wreg, o);
                     if (lane == j) myoff = o;
@@ -553,7 +571,6 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 nlsp += (unsigned int) __popcll(msig);
                 wr += (unsigned int) __popcll(mkeep);
                 cnt += (unsigned long long) (o - o0);
-                __threadfence_block();
                 if (__ballot(overrun)) stop = true;
             }
             nlip = wr;
@@ -563,15 +580,21 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
         // ---------------- LIS pass, spiht_re.c:346-410
         {
             unsigned int ncur = nlis, nnext = 0, base = 0;
+            // entries appended to the list in this pass are read back further down the same pass: a fence before the
+            // first chunk that reaches beyond what the last fence covered (visible_end), not after every chunk
+            __threadfence_block();
+            unsigned int visible_end = ncur, e_next = 0;
+            bool have_next = false;
             while (base < ncur && !stop) {
                 int m = (int) min((unsigned int) kWave, ncur - base);
                 bool valid = lane < m;
-                unsigned int e = valid ? cur[base + lane] : 0;
+                if (base + (unsigned int) m > visible_end) { __threadfence_block(); visible_end = ncur; have_next = false; }
+                unsigned int e = have_next ? e_next : (valid ? cur[base + lane] : 0u);
+                have_next = base + (unsigned int) m + kWave <= visible_end;              // a whole chunk of visible entries follows
+                if (have_next) e_next = cur[base + (unsigned int) m + lane];
                 unsigned int p = e >> 1;
                 int isB = (int) (e & 1u);
-                unsigned long long pos = kHeaderBits + cnt;
-                unsigned int wreg = load_be_word(S, size, (pos >> 5) + lane);          // 64 words >= 64*9+31 bits
-                int o0 = (int) (pos & 31), o = o0, myoff = 0, mylen = 0;
+                int o0 = window(kHeaderBits + cnt, 22), o = o0, myoff = 0, mylen = 0;   // 64 * 9 bits, the offset inside the first word, one word of slack
                 for (int j = 0; j < m; j++) {
                     int tb = __builtin_amdgcn_readlane(isB, j);
                     int start = o;
@@ -671,7 +694,6 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                     }
                     if (surv) nxt[r_surv] = e;
                 }
-                __threadfence_block();
                 nlsp += (unsigned int) (tot & 0xFFFF);
                 nlip += (unsigned int) ((tot >> 16) & 0xFFFF);
                 ncur += (unsigned int) ((tot >> 32) & 0xFFFF);
@@ -685,23 +707,30 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
         }
         if (stop) break;
 
-        // ---------------- refinement pass, spiht_re.c:413-428
-        for (unsigned int base = 0; base < n_old && !stop; base += kWave) {
-            int m = (int) min((unsigned int) kWave, n_old - base);
-            bool valid = lane < m;
-            unsigned long long pos = kHeaderBits + cnt;
-            unsigned int wreg = load_be_word(S, size, (pos >> 5) + lane);
-            int o0 = (int) (pos & 31);
-            unsigned int bit = win_bits_lane(wreg, o0 + lane, 1);
-            unsigned long long k = cnt + lane + 1;                                     // ordinal of this bit
-            bool act = valid && k <= B + 1;                                            // applied, then checked (:418-426)
-            if (act && bit) {
-                unsigned int p = lsp[base + lane];
-                int c = C[p];
-                C[p] = c >= 0 ? (c | one) : -((-c) | one);
+        // ---------------- refinement pass, spiht_re.c:413-428: four bits per lane and round (the update of a coefficient is
+        // a dependent load / store pair: four of them in flight instead of one)
+        __threadfence_block();
+        constexpr unsigned int kRef = 4 * kWave;
+        for (unsigned int base = 0; base < n_old && !stop; base += kRef) {
+            const unsigned int m = min(kRef, n_old - base);
+            const int o0 = window(kHeaderBits + cnt, 11);
+            unsigned int pj[4];
+            int cj[4];
+            bool on[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned int i = (unsigned int) (j * kWave + lane);
+                const unsigned long long k = cnt + i + 1;                              // ordinal of this bit
+                const unsigned int bit = win_bits_lane(wreg, o0 + (int) i, 1);        // (a cross-lane read: every lane takes part)
+                on[j] = i < m && k <= B + 1 && bit;                                    // applied, then checked (:418-426)
+                pj[j] = on[j] ? lsp[base + i] : 0u;
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) cj[j] = on[j] ? C[pj[j]] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (on[j]) C[pj[j]] = cj[j] >= 0 ? (cj[j] | one) : -((-cj[j]) | one);
             cnt += (unsigned long long) m;
-            __threadfence_block();
             if (cnt > B) stop = true;
         }
     }
@@ -754,8 +783,10 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
 {
     // spiht_decode_init clears the coefficient grid, spiht_re.c:101
     EBCC_HIP_CHECK(hipMemsetAsync(rb.C, 0, (size_t) n_frames * rb.np * sizeof(int32_t), s));
+    timing_begin("spiht_decode", s);
     hipLaunchKernelGGL(k_spiht_decode, dim3(n_frames), dim3(kWave), 0, s, d_streams, stream_stride, d_sizes, d_num_bits,
                        rb.C, rb.lip, rb.lsp, rb.lis0, rb.lis1, rb.g, rb.np, rb.fs, d_active);
+    timing_end("spiht_decode", s);
     hipLaunchKernelGGL(k_int_to_float, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.A, rb.np, d_active);
     EBCC_HIP_LAUNCH_CHECK();
 }

@@ -41,6 +41,11 @@ __device__ const DevProbe *find_probe(const DevChunk &c, float cr)
     return nullptr;
 }
 
+// Only the probes the residual layer can be computed from store their decoded field: the final probe of search 0 (:590)
+// and the probe that restores it (phase 5); the others are asked for the statistics alone (J2kFrame::keep), which spares
+// the frame a full-field write per probe.
+__device__ bool keeps_field(int k, int phase) { return k == 0 && (phase == 3 || phase == 5); }
+
 // The rate the search would ask for next if the probe it is waiting for (at R.want_cr) came back with quantile q_hyp
 // (1.0: "feasible", 0.0: "not feasible" - the two ways a step of :545-596 can go); -1 if it would ask for none.  Works
 // on copies: a guess for the speculative rate allocation, the search itself is advanced by k_search_advance alone.
@@ -49,7 +54,7 @@ __device__ float next_rate_if(const DevChunk &C, const DevRateSearch &R, int k, 
     if (R.phase > 3) return -1.0f;                                      // (the probe restoring the decode is the last one)
     DevRateSearch T = R;
     rs_feed(T, q_hyp);
-    const float scr = k == 0 ? R.want_cr : C.state_cr;                   // the decode the engine will hold then
+    const float scr = k != 0 ? C.state_cr : (keeps_field(k, R.phase) ? R.want_cr : -1.0f);     // the state the engine will hold then
     while (T.phase < 4) {
         float cr;
         if (!rs_next(T, cr)) break;
@@ -100,7 +105,9 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
         int body = 0;
         for (int t = 0; t < tiles; t++) { rec.nbad += jf[t0 + t].nbad; rec.err_sum += jf[t0 + t].err_sum; body += jf[t0 + t].body_bytes; }
         rec.stream_bytes = kMainHeaderBytes + tiles * 14 + body + 2;     // main header, SOT + SOD per tile, EOC
-        if (k == 0) C.state_cr = rec.cr;                                 // (search 0's probes leave their decode in the engine)
+        // search 0's probes change the layer assignment the codestream is written from; only those that also stored
+        // their field leave the engine in the state of one rate (decode and assignment), the others in none
+        if (k == 0) C.state_cr = keeps_field(k, R.phase) ? rec.cr : -1.0f;
         if (!find_probe(C, rec.cr) && C.n_probes < kMaxProbes) C.probes[C.n_probes++] = rec;
         R.want = 0;
         if (R.phase == 5) { R.last = rec; R.phase = 6; set_active(0); return; }
@@ -126,7 +133,7 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
     }
     set_active(R.want);
     if (R.want) {
-        for (int t = 0; t < tiles; t++) jf[t0 + t].cr = R.want_cr;
+        for (int t = 0; t < tiles; t++) { jf[t0 + t].cr = R.want_cr; jf[t0 + t].keep = keeps_field(k, R.phase); }
         atomicAdd(unfinished, 1);
     }
 }

@@ -56,7 +56,15 @@ __device__ inline int first_child(const Grid &g, int x, int y)
     }
     return cx + cy * g.nx;
 }
-__device__ inline int first_child_of(const Grid &g, int p) { return first_child(g, p % g.nx, p / g.nx); }
+// (row, column) of grid position p: p < 2^24, so the float quotient is off by at most one - far fewer instructions than
+// the integer division by a run-time nx
+__device__ inline int first_child_of(const Grid &g, int p)
+{
+    int y = (int) ((float) p * (1.0f / (float) g.nx)), x = p - y * g.nx;
+    if (x < 0) { y -= 1; x += g.nx; }
+    if (x >= g.nx) { y += 1; x -= g.nx; }
+    return first_child(g, x, y);
+}
 
 __device__ inline unsigned long long shfl_up_u64(unsigned long long v, int d)
 {
@@ -468,15 +476,19 @@ __device__ inline unsigned int read_bits_uniform(const uint8_t *s, unsigned long
     return (unsigned int) ((x << (pos & 31)) >> (64 - n));
 }
 
+// EBCC_HIP_SPIHT_PROF=1: cycles and list entries of the three passes, summed over the frames of a launch
+__device__ unsigned long long g_spiht_prof[10];
+
 __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restrict__ streams, size_t stream_stride,
                                                         const unsigned long long *sizes,
                                                         const unsigned long long *num_bits_in, int32_t *Cb,
                                                         uint32_t *lipb, uint32_t *lspb, uint32_t *lis0b,
                                                         uint32_t *lis1b, Grid g, size_t np, FrameState *fsb,
-                                                        const int *active)
+                                                        const int *active, int prof)
 {
     const int frame = blockIdx.x;
     if (active && !active[frame]) return;
+    const unsigned long long prof_c0 = prof ? __builtin_readcyclecounter() : 0ull, prof_r0 = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // one wave, one long dependent chain: it runs beside the tier-1 decoder's thousands of waves (other stream), which
     // keep every SIMD's issue slots busy - ask the arbiter to serve this wave first (10.6 ms alone, 25.7 ms without this)
     __builtin_amdgcn_s_setprio(3);
@@ -520,9 +532,9 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
     unsigned long long cnt = 0;            // SPIHT bits consumed (bit_cnt of the reference)
     bool stop = false;
     const unsigned long long lanemask_lt = (1ull << lane) - 1;
-    // The stream window: word wbase + l of the stream in lane l (2048 bits).  A chunk of 64 list entries consumes at most
-    // 576 of them, so the window is kept across chunks and re-read only when the next chunk might run off its end -
-    // the kernel is one dependent chain per frame, and every load it has to wait for is ~1 us of that chain.
+    // The stream window: word wbase + l of the stream in lane l (2048 bits), kept across chunks and re-read only when the
+    // next chunk might run off its end - the kernel is one dependent chain per frame, and every load it has to wait for
+    // is ~1 us of that chain.
     unsigned long long wbase = ~0ull;
     unsigned int wreg = 0;
     auto window = [&](unsigned long long pos, int need_words) -> int {   // window offset of stream bit `pos`
@@ -533,83 +545,143 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
         }
         return (int) (pos - (wbase << 5));
     };
+    // the 64 stream bits from `pos` on, first bit in bit 63 (uniform: scalar registers)
+    auto stream64 = [&](unsigned long long pos) -> unsigned long long {
+        const int o = window(pos, 4), wi = __builtin_amdgcn_readfirstlane(o >> 5), sh = __builtin_amdgcn_readfirstlane(o & 31);
+        // (the builtin returns int: through unsigned, or the sign extends into the upper word)
+        const unsigned int w0 = (unsigned int) __builtin_amdgcn_readlane(wreg, wi), w1 = (unsigned int) __builtin_amdgcn_readlane(wreg, wi + 1),
+                           w2 = (unsigned int) __builtin_amdgcn_readlane(wreg, wi + 2);
+        const unsigned long long hi = ((unsigned long long) w0 << 32) | w1, lo = (unsigned long long) w2 << 32;
+        return sh ? (hi << sh) | (lo >> (64 - sh)) : hi;
+    };
+    // A list is read through two registers per lane holding 128 consecutive entries (entry wb + l in w0 of lane l, entry
+    // wb + 64 + l in w1); the second is requested a chunk before it is needed.  `limit`: entries below it were visible
+    // when the registers were loaded.
+    struct ListWindow {
+        const uint32_t *list;
+        unsigned int wb, limit;
+        uint32_t w0, w1;
+        __device__ void reset(const uint32_t *l, unsigned int base, unsigned int n, int lane)
+        {
+            list = l; wb = base; limit = n;
+            w0 = wb + lane < n ? list[wb + lane] : 0u;
+            w1 = wb + kWave + lane < n ? list[wb + kWave + lane] : 0u;
+        }
+        // entry base + i for the lane that asks for i (0 <= i < 64, base - wb <= 64); every lane takes part
+        __device__ uint32_t get(unsigned int base, int i) const
+        {
+            const int idx = (int) (base - wb) + i;
+            const uint32_t a = __shfl(w0, idx & 63), b = __shfl(w1, idx & 63);
+            return idx < kWave ? a : b;
+        }
+        __device__ void advance(unsigned int base, int lane)
+        {
+            if (base - wb >= (unsigned int) kWave) {
+                w0 = w1; wb += kWave;
+                w1 = wb + kWave + lane < limit ? list[wb + kWave + lane] : 0u;
+            }
+        }
+    };
 
     for (int s = top; s >= 0 && !stop; --s) {
         const unsigned int n_old = nlsp;
         const int one = 1 << s;
 
-        // ---------------- LIP pass, spiht_re.c:331-343
+        // ---------------- LIP pass, spiht_re.c:331-343.  An entry is one bit, or two when the first is set (significant +
+        // sign): where the entries start in the next 64 stream bits has a closed form - a set bit at an entry start
+        // "escapes" the bit after it, the odd/even run-of-ones argument of simdjson's backslash scanner - so a chunk is
+        // all the entries that start in those 64 bits, lane x looking at bit x, and nothing in the pass is a serial loop.
+        unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
+        if (prof && lane == 0) atomicAdd(&g_spiht_prof[1], (unsigned long long) nlip);
         {
             __threadfence_block();                                     // (entries the previous LIS pass appended)
-            unsigned int wr = 0;
-            unsigned int p_next = lane < (int) nlip ? lip[lane] : 0u;
-            for (unsigned int base = 0; base < nlip && !stop; base += kWave) {
-                int m = (int) min((unsigned int) kWave, nlip - base);
-                bool valid = lane < m;
-                const unsigned int p = p_next;
-                // the next chunk's entries are requested now: this chunk writes below base + 64 only
-                if (base + kWave < nlip) p_next = base + kWave + lane < nlip ? lip[base + kWave + lane] : 0u;
-                int o0 = window(kHeaderBits + cnt, 7), o = o0, myoff = 0;                // 64 * 2 bits, the offset inside the first word, one word of slack
-                for (int j = 0; j < m; j++) {
-                    unsigned int b = win_bit(wreg, o);
-                    if (lane == j) myoff = o;
-                    o = __builtin_amdgcn_readfirstlane(o + 1 + (int) b);
-                }
-                unsigned int bits2 = win_bits_lane(wreg, myoff, 2);
-                bool sig = valid && (bits2 & 2u);
-                bool neg = bits2 & 1u;
-                unsigned long long k1 = cnt + (unsigned long long) (myoff - o0) + 1;   // ordinal of the significance bit
-                bool act = valid && k1 <= B;                                           // :334
-                bool overrun = valid && (k1 > B || (sig && k1 + 1 > B));               // :334,:339
-                unsigned long long msig = __ballot(act && sig), mkeep = __ballot(valid && !(act && sig));
+            unsigned int wr = 0, base = 0;
+            ListWindow lw;
+            lw.reset(lip, 0, nlip, lane);
+            while (base < nlip && !stop) {
+                const unsigned long long X = __builtin_bitreverse64(stream64(kHeaderBits + cnt));   // bit x = stream bit cnt + x
+                const unsigned long long even = 0x5555555555555555ull, follows = X << 1;
+                const unsigned long long odd_starts = X & ~even & ~follows;
+                const unsigned long long signs = (even ^ ((odd_starts + X) << 1)) & follows;        // bits that are sign bits
+                const unsigned long long starts = ~signs;
+                // a significant entry starting at bit 63 has its sign in the next chunk: it waits for that chunk
+                int limit = ((starts & X) >> 63) ? 63 : 64;
+                const unsigned int n_rem = nlip - base;
+                const int idx = __popcll(starts & lanemask_lt);                                    // entry of the chunk that starts at bit `lane`
+                const bool isstart = ((starts >> lane) & 1ull) && lane < limit;
+                const unsigned long long mover = __ballot(isstart && (unsigned int) idx >= n_rem);  // starts beyond the end of the list
+                if (mover) limit = __builtin_ctzll(mover);
+                const bool valid = isstart && lane < limit;
+                const unsigned int p = lw.get(base, valid ? idx : 0);
+                const bool sig = valid && ((X >> lane) & 1ull);
+                const bool neg = (X >> ((lane + 1) & 63)) & 1ull;
+                const unsigned long long k1 = cnt + (unsigned long long) lane + 1;                 // ordinal of the significance bit
+                const bool act = valid && k1 <= B;                                                 // :334
+                const bool overrun = valid && (k1 > B || (sig && k1 + 1 > B));                     // :334,:339
+                const unsigned long long msig = __ballot(act && sig), mkeep = __ballot(valid && !(act && sig));
                 if (act && sig) {
                     lsp[nlsp + __popcll(msig & lanemask_lt)] = p;
-                    C[p] = neg ? -one : one;                                           // :338
+                    C[p] = neg ? -one : one;                                                       // :338
                 } else if (valid) {
-                    lip[wr + __popcll(mkeep & lanemask_lt)] = p;
+                    lip[wr + __popcll(mkeep & lanemask_lt)] = p;                                   // (at or below the entry's own slot)
                 }
                 nlsp += (unsigned int) __popcll(msig);
                 wr += (unsigned int) __popcll(mkeep);
-                cnt += (unsigned long long) (o - o0);
+                cnt += (unsigned long long) limit;
+                base += (unsigned int) __popcll(__ballot(valid));
+                lw.advance(base, lane);
                 if (__ballot(overrun)) stop = true;
             }
             nlip = wr;
         }
         if (stop) break;
 
-        // ---------------- LIS pass, spiht_re.c:346-410
+        if (prof && lane == 0) { const unsigned long long t1 = __builtin_readcyclecounter(); atomicAdd(&g_spiht_prof[0], t1 - t0); t0 = t1; }
+        // ---------------- LIS pass, spiht_re.c:346-410.  An entry takes 1 bit, or 5 to 9 when a type-A entry's set is
+        // significant, so where an entry starts depends on every entry before it: a scalar loop walks the next 64 stream
+        // bits (registers only, ~10 scalar instructions per entry) and marks the starts; a chunk is the entries that start
+        // in the first 55 of those bits, lane x again looking at bit x.
         {
             unsigned int ncur = nlis, nnext = 0, base = 0;
             // entries appended to the list in this pass are read back further down the same pass: a fence before the
-            // first chunk that reaches beyond what the last fence covered (visible_end), not after every chunk
+            // list registers are loaded with entries written since the last one
             __threadfence_block();
-            unsigned int visible_end = ncur, e_next = 0;
-            bool have_next = false;
+            ListWindow lw;
+            lw.reset(cur, 0, ncur, lane);
             while (base < ncur && !stop) {
-                int m = (int) min((unsigned int) kWave, ncur - base);
-                bool valid = lane < m;
-                if (base + (unsigned int) m > visible_end) { __threadfence_block(); visible_end = ncur; have_next = false; }
-                unsigned int e = have_next ? e_next : (valid ? cur[base + lane] : 0u);
-                have_next = base + (unsigned int) m + kWave <= visible_end;              // a whole chunk of visible entries follows
-                if (have_next) e_next = cur[base + (unsigned int) m + lane];
-                unsigned int p = e >> 1;
-                int isB = (int) (e & 1u);
-                int o0 = window(kHeaderBits + cnt, 22), o = o0, myoff = 0, mylen = 0;   // 64 * 9 bits, the offset inside the first word, one word of slack
-                for (int j = 0; j < m; j++) {
-                    int tb = __builtin_amdgcn_readlane(isB, j);
-                    int start = o;
-                    unsigned int sb = win_bit(wreg, o);
-                    o = __builtin_amdgcn_readfirstlane(o + 1);
-                    if (!tb && sb) {
-                        for (int k = 0; k < 4; k++) {
-                            unsigned int cb = win_bit(wreg, o);
-                            o = __builtin_amdgcn_readfirstlane(o + 1 + (int) cb);
-                        }
-                    }
-                    if (lane == j) { myoff = start; mylen = o - start; }
+                const int m = (int) min((unsigned int) kWave, ncur - base);
+                if (base + (unsigned int) m > lw.limit) { __threadfence_block(); lw.reset(cur, base, ncur, lane); }
+                const unsigned int el = lw.get(base, lane);                              // list entry base + lane
+                const unsigned long long typemask = __ballot(lane < m && (el & 1u));
+                const unsigned long long X = stream64(kHeaderBits + cnt);                // first bit in bit 63
+                // what a type-A entry starting at bit `lane` would take (every lane works its own position out: 1 bit, or the
+                // set bit and four children of 1 or 2 bits); the scalar walk then only adds lengths up
+                int len_a = 1;
+                if (lane < 55 && ((X >> (63 - lane)) & 1ull)) {
+                    int q = lane + 1;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) q += 1 + (int) ((X >> (63 - q)) & 1ull);
+                    len_a = q - lane;
                 }
-                unsigned int mybits = win_bits_lane(wreg, myoff, mylen);               // MSB-first, mylen <= 9
-                unsigned long long k = cnt + (unsigned long long) (myoff - o0);        // bits consumed before this entry
+                unsigned long long starts = 0, types = typemask;
+                int rel = 0, n_ent = 0;
+                const int m_s = __builtin_amdgcn_readfirstlane(m);                  // (uniform anyway; this way the loop is scalar code)
+                while (n_ent < m_s && rel < 55) {
+                    starts |= 1ull << rel;
+                    const int la = __builtin_amdgcn_readlane(len_a, rel);
+                    rel += (types & 1ull) ? 1 : la;
+                    types >>= 1;
+                    n_ent++;
+                }
+                const bool valid = (starts >> lane) & 1ull;
+                const int idx = __popcll(starts & lanemask_lt);
+                const unsigned int e = lw.get(base, valid ? idx : 0);
+                const unsigned int p = e >> 1;
+                const int isB = (int) (e & 1u);
+                const unsigned long long later = lane < 63 ? starts >> (lane + 1) : 0ull;
+                const int mylen = valid ? (later ? __builtin_ctzll(later) + 1 : rel - lane) : 0;
+                const unsigned int mybits = mylen ? (unsigned int) ((X << lane) >> (64 - mylen)) : 0u;   // MSB-first, mylen <= 9
+                const unsigned long long k = cnt + (unsigned long long) lane;          // bits consumed before this entry
                 bool setbit = valid && mylen > 0 && ((mybits >> (mylen - 1)) & 1u);
                 bool act = valid && (k + 1 <= B);                                      // :358 / :394
                 bool overrun = valid && !act;
@@ -698,14 +770,18 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 nlip += (unsigned int) ((tot >> 16) & 0xFFFF);
                 ncur += (unsigned int) ((tot >> 32) & 0xFFFF);
                 nnext += (unsigned int) ((tot >> 48) & 0xFFFF);
-                cnt += (unsigned long long) (o - o0);
-                base += (unsigned int) m;
+                cnt += (unsigned long long) rel;
+                base += (unsigned int) n_ent;
+                lw.advance(base, lane);
                 if (__ballot(overrun)) stop = true;
             }
+            if (prof && lane == 0) atomicAdd(&g_spiht_prof[3], (unsigned long long) ncur);
             uint32_t *t = cur; cur = nxt; nxt = t;
             nlis = nnext;
         }
+        if (prof && lane == 0) { const unsigned long long t1 = __builtin_readcyclecounter(); atomicAdd(&g_spiht_prof[2], t1 - t0); t0 = t1; }
         if (stop) break;
+
 
         // ---------------- refinement pass, spiht_re.c:413-428: four bits per lane and round (the update of a coefficient is
         // a dependent load / store pair: four of them in flight instead of one)
@@ -733,6 +809,11 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
             cnt += (unsigned long long) m;
             if (cnt > B) stop = true;
         }
+        if (prof && lane == 0) { atomicAdd(&g_spiht_prof[4], __builtin_readcyclecounter() - t0); atomicAdd(&g_spiht_prof[5], (unsigned long long) n_old); }
+    }
+    if (prof && lane == 0) {
+        atomicAdd(&g_spiht_prof[6], cnt); atomicMax(&g_spiht_prof[7], cnt);
+        atomicMax(&g_spiht_prof[8], __builtin_readcyclecounter() - prof_c0); atomicMax(&g_spiht_prof[9], __builtin_amdgcn_s_memrealtime() - prof_r0);
     }
 }
 
@@ -783,10 +864,19 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
 {
     // spiht_decode_init clears the coefficient grid, spiht_re.c:101
     EBCC_HIP_CHECK(hipMemsetAsync(rb.C, 0, (size_t) n_frames * rb.np * sizeof(int32_t), s));
+    static const bool prof = getenv("EBCC_HIP_SPIHT_PROF") != nullptr;
+    if (prof) { unsigned long long z[10] = {}; EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_spiht_prof), z, sizeof z)); }
     timing_begin("spiht_decode", s);
     hipLaunchKernelGGL(k_spiht_decode, dim3(n_frames), dim3(kWave), 0, s, d_streams, stream_stride, d_sizes, d_num_bits,
-                       rb.C, rb.lip, rb.lsp, rb.lis0, rb.lis1, rb.g, rb.np, rb.fs, d_active);
+                       rb.C, rb.lip, rb.lsp, rb.lis0, rb.lis1, rb.g, rb.np, rb.fs, d_active, prof ? 1 : 0);
     timing_end("spiht_decode", s);
+    if (prof) {
+        unsigned long long v[10];
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        EBCC_HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_spiht_prof), sizeof v));
+        fprintf(stderr, "spiht_decode profile (%d frames): LIP %.1f Mcycles %llu entries | LIS %.1f Mcycles %llu entries | refinement %.1f Mcycles %llu bits | %llu stream bits, longest %llu | slowest frame: %llu cycle-counter ticks in %.1f us (100 MHz clock)\n",
+                n_frames, v[0] / 1e6, v[1], v[2] / 1e6, v[3], v[4] / 1e6, v[5], v[6], v[7], v[8], v[9] / 100.0);
+    }
     hipLaunchKernelGGL(k_int_to_float, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.A, rb.np, d_active);
     EBCC_HIP_LAUNCH_CHECK();
 }

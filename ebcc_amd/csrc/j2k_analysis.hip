@@ -740,33 +740,61 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
 {
     __shared__ unsigned long long m[kQuantMasks][64];                   // [mask][code-block of the group]
     __shared__ int smax[64];
+    // the 64 code-blocks of the group: element offset of (0, 0) in B / Q6 (-1: none), extent, row pitch, step size
+    __shared__ long long s_base[64];
+    __shared__ int s_w[64], s_h[64], s_pitch[64];
+    __shared__ float s_step[64];
     const size_t grp = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = geom->stride;
-    if (threadIdx.x < 64) smax[threadIdx.x] = 0;
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x, gid = (int) (grp * 64) + k;
+        smax[k] = 0;
+        s_base[k] = -1; s_w[k] = 0; s_h[k] = 0; s_pitch[k] = 0; s_step[k] = 1.0f;
+        if (gid < total) {
+            const int frame = gid / nb;
+            if (!fs[frame].const_field) {
+                const J2kBlock blk = j2k_frame_blocks(geom, blocks, frame)[gid - frame * nb];   // (slots past the tile's last code-block hold empty ones)
+                const J2kGeom &g = j2k_frame_geom(geom, frame);
+                s_base[k] = (long long) ((size_t) frame * ((size_t) g.W * g.H) + (size_t) blk.y * g.W + blk.x);
+                s_w[k] = blk.w; s_h[k] = blk.h; s_pitch[k] = g.W; s_step[k] = g.bands[blk.band].step_enc;
+            }
+        }
+    }
     __syncthreads();
     unsigned long long *bp = BP + grp * kJ2kMaxPlanes * 64 * 64, *sg = SGN + grp * 64 * 64, *su = SUF + grp * (kJ2kMaxPlanes + 2) * 64 * 64;
+    // a wave owns code-blocks wave, wave + 4, ...: their 16 row segments of the next row are requested before the current
+    // row is worked on (the kernel used to wait for every 256-byte segment in turn: 14 % of the HBM roof)
+    constexpr int kPer = 16;
+    float cur[kPer], nxt[kPer];
+    auto fetch = [&](int row, float (&v)[kPer]) {
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) {
+            const int k = wave + 4 * jj;
+            const bool in = s_base[k] >= 0 && row < s_h[k] && lane < s_w[k];
+            v[jj] = in ? B[s_base[k] + (long long) row * s_pitch[k] + lane] : 0.0f;
+        }
+    };
+    fetch(0, cur);
     for (int row = 0; row < 64; row++) {
-        for (int k = wave; k < 64; k += 4) {                             // the code-blocks of the group, 16 per wave
-            const int gid = (int) (grp * 64) + k;
+        if (row + 1 < 64) fetch(row + 1, nxt);
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) {
+            const int k = wave + 4 * jj;
+            const bool in = s_base[k] >= 0 && row < s_h[k] && lane < s_w[k];
             int q6 = 0;
-            if (gid < total) {
-                const int frame = gid / nb;
-                if (!fs[frame].const_field) {
-                    const J2kBlock blk = j2k_frame_blocks(geom, blocks, frame)[gid - frame * nb];   // (slots past the tile's last code-block hold empty ones)
-                    const J2kGeom &g = j2k_frame_geom(geom, frame);
-                    if (row < blk.h && lane < blk.w) {
-                        const size_t p = (size_t) frame * ((size_t) g.W * g.H) + (size_t) (blk.y + row) * g.W + blk.x + lane;
-                        q6 = __float2int_rn((B[p] / g.bands[blk.band].step_enc) * 64.0f);      // lrintf((c / stepsize) * 64), opj_t1_encode_cblks
-                        Q6[p] = q6;
-                    }
-                }
+            if (in) {
+                q6 = __float2int_rn((cur[jj] / s_step[k]) * 64.0f);     // lrintf((c / stepsize) * 64), opj_t1_encode_cblks
+                Q6[s_base[k] + (long long) row * s_pitch[k] + lane] = q6;
             }
             const int a6 = q6 < 0 ? -q6 : q6;
             int mx = a6;
             for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
             const unsigned long long sgn = __ballot(q6 < 0);
             const int a = a6 >> 6;
+            // planes above the row's top magnitude bit are empty: no ballots for them
+            const int top = __builtin_amdgcn_readfirstlane(mx) >> 6, p_top = top ? 32 - __builtin_clz(top) : 0;
+            if (lane < kJ2kMaxPlanes && lane >= p_top) { m[lane][k] = 0; m[kJ2kMaxPlanes + 1 + lane][k] = 0; }
             unsigned long long suf = 0;                                  // OR of the planes >= p: "some bit at or above p"
             if (lane == 0) {
                 if (mx > smax[k]) smax[k] = mx;                          // (this wave owns code-block k)
@@ -774,7 +802,7 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
                 m[kJ2kMaxPlanes + 1 + kJ2kMaxPlanes + 1][k] = 0;
                 m[kJ2kMaxPlanes + 1 + kJ2kMaxPlanes][k] = 0;
             }
-            for (int p = kJ2kMaxPlanes - 1; p >= 0; p--) {
+            for (int p = p_top - 1; p >= 0; p--) {
                 const unsigned long long bits = __ballot((a >> p) & 1);
                 suf |= bits;
                 if (lane == 0) { m[p][k] = bits; m[kJ2kMaxPlanes + 1 + p][k] = suf; }
@@ -789,6 +817,8 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
             else su[((size_t) (i - kJ2kMaxPlanes - 1) * 64 + row) * 64 + k] = v;
         }
         __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) cur[jj] = nxt[jj];
     }
     if (threadIdx.x < 64) {
         const int gid = (int) (grp * 64) + (int) threadIdx.x;

@@ -596,7 +596,11 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
     // step of the search can go two ways, so the layers of both rates it may ask for next are worked out on the engine's
     // second stream while the first stream decodes the current probe; the advance then takes the matching one over
     // (k_rate_publish) and the round's own k_rate only runs for the frames whose rate was not among the guesses.
-    static const bool speculate = getenv("EBCC_HIP_NO_SPECULATION") == nullptr;
+    // It shortens a slice's chain (search #1 of 256 frames in one slice: 33 -> 29 ms) at the price of two more k_rate per
+    // round; with several slices in flight the chip has no idle issue slots left to pay with (four slices: encode 7.7 GB/s
+    // without, 6.7 with) - so it is on for a batch that runs as one slice, off otherwise; EBCC_HIP_SPECULATION=1 / 0 forces it.
+    static const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
+    const bool speculate = forced >= 0 ? forced != 0 : g_slices.load() <= 1;
     hipStream_t s2 = nullptr;
     J2kBuffers &jb = b.jb;
     if (speculate) {

@@ -37,6 +37,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->d_blocks = (J2kBlock *) ctx_alloc<uint8_t>(ctx, sizeof(J2kBlock) * (size_t) period * (size_t) stride)) != nullptr;
     ok &= (jb->d_blkmap = ctx_alloc<uint16_t>(ctx, (size_t) period * n_pix)) != nullptr;
     ok &= (jb->B = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
+    ok &= (jb->B2 = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
     ok &= (jb->Q6 = ctx_alloc<int32_t>(ctx, F * n_pix)) != nullptr;
     ok &= (jb->DEC = ctx_alloc<float>(ctx, F * n_pix)) != nullptr;
     ok &= (jb->V = ctx_alloc<int32_t>(ctx, F * n_pix)) != nullptr;

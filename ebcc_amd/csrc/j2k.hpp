@@ -110,6 +110,7 @@ struct J2kBuffers {
     std::uint16_t *d_blkmap;      // [period][H*W] code-block id of every tile-buffer position
     int max_frames;
     float *B;                     // [frames][H*W] tile buffer (coefficients / samples)
+    float *B2;                    // [frames][H*W] second tile buffer: the fused inverse levels alternate between the two
     int32_t *Q6;                  // [frames][H*W] quantised coefficients with 6 fractional bits
     float *DEC;                   // [frames][H*W] last decoded field (fp32, de-normalised)
     unsigned long long *BP;       // [groups][planes][64][64] bit-plane row masks, lane-interleaved

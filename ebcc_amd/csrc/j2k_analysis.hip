@@ -587,25 +587,36 @@ struct ColPipe {
 // column of the pair.  Nothing is written but the fp32 field (if wanted) and the statistics: against the separate
 // row and column passes this saves one write and one read of the frame per probe.  cas == 0 frames only.
 constexpr int kL5Pairs = 60;
-__global__ __launch_bounds__(64) void k_j2k_level5_fin(const float *__restrict__ B, const int32_t *__restrict__ V, const J2kGeom *geom,
+// FIN = false: the same pass for a lower level r - the synthesised samples go to `out` (pitch out_pitch) as they are, the
+// next level's low-pass band.  Out of place: the level's output region covers its own LL input, so the levels alternate
+// between two buffers.  LL comes from `ll` (pitch ll_pitch), or for level 1 from the decoder's output like the other bands.
+struct J2kLevelIO {
+    const float *ll; int ll_pitch; size_t ll_frame;      // low-pass input (null: from V, level 1)
+    float *out; int out_pitch; size_t out_frame;         // FIN = false only
+    int r;
+};
+template <bool FIN>
+__global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int32_t *__restrict__ V, const J2kGeom *geom,
                                                         const FrameState *fs, const int *active, J2kFinish fin)
 {
     const int frame = blockIdx.y;
     if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
     const J2kGeom &g = j2k_frame_geom(geom, frame);
-    constexpr int r = kJ2kRes - 1;
+    const int r = FIN ? kJ2kRes - 1 : io.r;
     const int W = g.W, nh = g.rw[r], snh = g.rw[r - 1], dnh = nh - snh;          // horizontal: samples, low-pass, high-pass
     const int nv = g.rh[r], snv = g.rh[r - 1], dnv = nv - snv;                   // vertical
     const size_t n_pix = (size_t) W * g.H;
     const int i = (int) blockIdx.x * kL5Pairs + (int) threadIdx.x - 2;           // this lane's pair
     const bool has_e = i >= 0 && i < snh, has_o = i >= 0 && i < dnh;
     const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kL5Pairs && has_e;    // (halo lanes compute, owners put out)
-    const float *b = B + (size_t) frame * n_pix;
+    const float *b = io.ll ? io.ll + (size_t) frame * io.ll_frame : nullptr;
+    const size_t lp = (size_t) io.ll_pitch;
     const int32_t *v = V + (size_t) frame * n_pix;
-    const float s_hl = 0.5f * g.bands[3 * (r - 1) + 1].step_dec, s_lh = 0.5f * g.bands[3 * (r - 1) + 2].step_dec,
+    const float s_ll = 0.5f * g.bands[0].step_dec, s_hl = 0.5f * g.bands[3 * (r - 1) + 1].step_dec, s_lh = 0.5f * g.bands[3 * (r - 1) + 2].step_dec,
                 s_hh = 0.5f * g.bands[3 * (r - 1) + 3].step_dec;
-    const float *x = fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
-    float *d = fin.field(frame, n_pix);
+    const float *x = FIN && fin.data ? fin.data + (size_t) frame * n_pix : nullptr;
+    float *d = FIN ? fin.field(frame, n_pix) : nullptr;
+    float *o = FIN ? nullptr : io.out + (size_t) frame * io.out_frame;
     const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
     const float target = x ? fin.jf[frame].target : 0.0f;
     const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
@@ -633,7 +644,7 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(const float *__restrict__
     float in_ll, in_hl, in_lh, in_hh;
     auto fetch = [&](int j, float &ll, float &hl, float &lh, float &hh) {
         const size_t rl = (size_t) min(j, snv - 1) * W, rh = (size_t) (snv + min(j, max(dnv - 1, 0))) * W;
-        ll = b[rl + c_lo];
+        ll = b ? b[(size_t) min(j, snv - 1) * lp + c_lo] : (float) v[rl + c_lo] * s_ll;
         hl = (float) v[rl + c_hi] * s_hl;
         lh = (float) v[rh + c_lo] * s_lh;
         hh = (float) v[rh + c_hi] * s_hh;
@@ -654,6 +665,10 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(const float *__restrict__
         if (j < snv) hsynth(in_ll, in_hl, lo_even, lo_odd);              // (uniform) low-pass row j: LL from the previous level, HL from the decoder
         if (j < dnv) hsynth(in_lh, in_hh, hi_even, hi_odd);              // high-pass row j: LH, HH
         auto put = [&](bool mine, int col, int y, float val, float xv) {
+            if constexpr (!FIN) {
+                if (mine) o[(size_t) y * (size_t) io.out_pitch + (size_t) col] = val;
+                return;
+            }
             const float dv = fin_map(val, rng, mn);
             if (d && mine) d[(size_t) y * W + (size_t) col] = dv;
             if (x) {
@@ -1452,18 +1467,37 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
                     const int *active, hipStream_t s, int keep_field)
 {
     int partials = 0;
-    // plain frames: the top level in one fused pass (k_j2k_level5_fin); EBCC_HIP_L5_SPLIT=1 keeps the separate row / column passes
-    static const bool split5 = getenv("EBCC_HIP_L5_SPLIT") != nullptr;
-    const bool fuse5 = !split5 && V && jb.geom.period == 1 && jb.geom.ry0[kJ2kRes - 1] % 2 == 0 && jb.geom.rw[kJ2kRes - 2] >= 2 && jb.geom.rh[kJ2kRes - 2] >= 1 &&
-                       ceil_div(jb.geom.rw[kJ2kRes - 2], kL5Pairs) <= kPartials;
+    // plain frames: every level in one fused pass (k_j2k_level5_fin: horizontal synthesis in registers, vertical register
+    // pipeline), alternating between the tile buffer and jb.B2 from the first level that is large enough; the levels
+    // below it, tiles at odd offsets and EBCC_HIP_L5_SPLIT=1 use the separate LDS-staged row / column passes in place.
+    // EBCC_HIP_LEVELS_SPLIT=1: only the top level fused (round 2's first state).
+    static const bool split5 = getenv("EBCC_HIP_L5_SPLIT") != nullptr, split_low = getenv("EBCC_HIP_LEVELS_SPLIT") != nullptr;
+    const J2kGeom &g = jb.geom;
+    const size_t n_pix = (size_t) g.W * g.H;
+    auto fusable = [&](int r) {
+        return !split5 && V && g.period == 1 && g.ry0[r] % 2 == 0 && g.rw[r - 1] >= 2 && g.rh[r - 1] >= 1 &&
+               (r == kJ2kRes - 1 ? ceil_div(g.rw[r - 1], kL5Pairs) <= kPartials : (!split_low && jb.B2 != nullptr));
+    };
+    int first_fused = kJ2kRes;                                          // levels first_fused .. top are fused (sizes grow with r)
+    for (int r = kJ2kRes - 1; r >= 1 && fusable(r); r--) first_fused = r;
+    const float *ll = nullptr;                                          // low-pass input of the next fused level (null: from V)
+    float *spare = jb.B2;
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
-        if (fuse5 && r == kJ2kRes - 1) {
-            const int strips = ceil_div(jb.geom.rw[r - 1], kL5Pairs);
-            const int pieces = std::max(1, std::min({4, kPartials / strips, jb.geom.rh[r - 1] / 16}));
-            partials = strips * pieces;
-            hipLaunchKernelGGL(k_j2k_level5_fin, dim3(strips, n_frames, pieces), dim3(64), 0, s, B, V, jb.d_geom, fs, active,
-                               J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2});
-            break;
+        if (r >= first_fused) {
+            const int strips = ceil_div(g.rw[r - 1], kL5Pairs);
+            const int pieces = std::max(1, std::min({4, kPartials / strips, g.rh[r - 1] / 16}));
+            if (r > 1 && !ll) ll = B;                                   // (the separate passes below left their result in B)
+            J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};
+            if (r == kJ2kRes - 1) {
+                partials = strips * pieces;
+                hipLaunchKernelGGL(k_j2k_level5_fin<true>, dim3(strips, n_frames, pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active,
+                                   J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2});
+            } else {
+                io.out = ll == spare ? B : spare;                         // never the buffer the level reads from
+                hipLaunchKernelGGL(k_j2k_level5_fin<false>, dim3(strips, n_frames, pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active, J2kFinish{});
+                ll = io.out;
+            }
+            continue;
         }
         dwt_rows<false>(B, V, jb, r, n_frames, fs, active, s);
         if (r + 1 < kJ2kRes) dwt_cols<false>(B, jb, r, n_frames, fs, active, s);

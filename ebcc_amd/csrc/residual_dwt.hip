@@ -435,6 +435,109 @@ __global__ __launch_bounds__(kStreamT) void k_cols_inv_stream(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// The finest level of the probes WHOLE - vertical synthesis (two RPipes per lane: low-pass column k and high-pass column
+// hx + k, inputs as in k_cols_inv_stream), then the horizontal synthesis of the two finished rows in registers
+// (neighbours through wave shuffles: 60 pairs + 2 of halo either side per wave, lift_inverse_tile's expressions and
+// boundary forms), then what k_rows_inv_use does with a row (residual_value, statistics against the frame).  Neither the
+// column pass's result nor the grid is written: one write and one read of the padded frame less per probe.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFusePairs = 60;
+__global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__ src, Grid g, size_t np, const int32_t *__restrict__ Cb,
+                                                        const uint32_t *__restrict__ sigordb, const uint32_t *__restrict__ lspidxb,
+                                                        const unsigned long long *trunc_bits, const int *active, RowUse u)
+{
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    const FrameState &fs = u.fs[frame];
+    unsigned long long nb = trunc_bits[frame], bits0 = fs.budget + 128;   // spiht_decode: num_bits = min(num_bits, bits0) - 128 (spiht_re.c:495-500)
+    if (nb > bits0) nb = bits0;
+    const unsigned long long B = nb - 128;
+    __shared__ unsigned int rbase[32], rreach[32];
+    if (threadIdx.x < 32) { rbase[threadIdx.x] = fs.refine_base[threadIdx.x]; rreach[threadIdx.x] = fs.step_reached[threadIdx.x]; }
+    __syncthreads();
+    const int nx = g.nx, ny = g.ny, half = ny >> 1, hx = nx >> 1;
+    const int k = (int) blockIdx.x * kFusePairs + (int) threadIdx.x - 2;   // this lane's pair of output columns (2k, 2k + 1)
+    const bool in_range = k >= 0 && k < hx;
+    const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kFusePairs && in_range;
+    const int kc = min(max(k, 0), hx - 1);
+    const float *a = src + (size_t) frame * np;
+    const int32_t *C = Cb + (size_t) frame * np;
+    const uint32_t *so = sigordb + (size_t) frame * np, *li = lspidxb + (size_t) frame * np;
+    const float *x = u.data + (size_t) frame * u.n_pix, *d = u.decoded + (size_t) frame * u.n_pix;
+    const float dc = fs.dc, rmin = fs.rmin, rng = fs.rmax - fs.rmin;
+    const int per = (half + (int) gridDim.z - 1) / (int) gridDim.z, ka = (int) blockIdx.z * per, kb = min(half, ka + per);
+    const int jstart = max(ka - 2, 0);
+    // the three detail coefficients of a vertical position (ordinal always, value and slot only inside the prefix) + LL
+    struct Det { uint32_t o, l; int c; };
+    struct Raw { float ll; Det lh, hl, hh; };
+    auto det = [&](size_t i, Det &t) {
+        t.o = so[i]; t.c = 0; t.l = 0;
+        if (t.o != 0xFFFFFFFFu && (unsigned long long) t.o <= B) { t.c = C[i]; t.l = li[i]; }
+    };
+    auto fetch = [&](int j, Raw &r) {
+        const int jj = min(j, half - 1);
+        const size_t top = (size_t) jj * nx, bot = (size_t) (half + jj) * nx;
+        r.ll = a[top + kc];
+        det(bot + kc, r.lh);
+        det(top + hx + kc, r.hl);
+        det(bot + hx + kc, r.hh);
+    };
+    auto val = [&](const Det &t) { return prefix_value_of(t.o, t.c, t.l, B, rbase, rreach); };
+    // horizontal synthesis of one finished row: this pair's low-/high-pass samples -> its two output samples
+    auto hsynth = [&](float e_raw, float o_raw, float &even, float &odd) {
+        const float E0 = e_raw / kXi, O0 = o_raw * kXi;
+        const float Ol = __shfl_up(O0, 1), Or = __shfl_down(O0, 1);
+        const float e1 = E0 - kDelta * (O0 + (k > 0 ? Ol : Or));
+        const float e1l = __shfl_up(e1, 1), e1r = __shfl_down(e1, 1);
+        const float o1 = O0 - kGamma * (e1 + (k + 1 < hx ? e1r : e1l));
+        const float o1l = __shfl_up(o1, 1), o1r = __shfl_down(o1, 1);
+        const float e2 = e1 - kBeta * (o1 + (k > 0 ? o1l : o1r));
+        const float e2r = __shfl_down(e2, 1);
+        even = e2;
+        odd = (k + 1 < hx) ? o1 - kAlpha * (e2 + e2r) : o1 - (2 * kAlpha) * e2;
+    };
+    double acc = 0;
+    float mx = 0;
+    auto use = [&](bool mine, int y, int c, float v, float xv, float dv) {
+        if (!(mine && y < u.size_y && c < u.size_x)) return;
+        const float r = residual_value(v, dc, rmin, rng);
+        const float t = xv - (dv + r);
+        acc += (double) t;
+        const float e = fabsf(t);
+        mx = e > mx ? e : mx;
+    };
+    RPipe pl, ph;
+    Raw cur;
+    fetch(jstart, cur);
+    const int c0 = min(2 * kc, u.size_x - 1), c1 = min(2 * kc + 1, u.size_x - 1);
+    for (int j = jstart; j < kb + 4; j++) {
+        Raw nxt;
+        fetch(j + 1, nxt);
+        // the frame's and the base layer's samples at the four positions this step finishes (clamped: dropped when outside)
+        const int kk = j - 4, y0 = min(max(2 * kk, 0), u.size_y - 1), y1 = min(max(2 * kk + 1, 0), u.size_y - 1);
+        const size_t i00 = (size_t) y0 * u.size_x + c0, i01 = (size_t) y0 * u.size_x + c1, i10 = (size_t) y1 * u.size_x + c0, i11 = (size_t) y1 * u.size_x + c1;
+        const float x00 = x[i00], x01 = x[i01], x10 = x[i10], x11 = x[i11], d00 = d[i00], d01 = d[i01], d10 = d[i10], d11 = d[i11];
+        float le, lo, he, ho;
+        pl.step(j, half, cur.ll, val(cur.lh), le, lo);                   // low-pass column k: rows 2 kk, 2 kk + 1
+        ph.step(j, half, val(cur.hl), val(cur.hh), he, ho);              // high-pass column hx + k
+        float s00, s01, s10, s11;
+        hsynth(le, he, s00, s01);
+        hsynth(lo, ho, s10, s11);
+        const bool mine = owner && kk >= ka && kk < kb;
+        use(mine, 2 * kk, 2 * k, s00, x00, d00);
+        use(mine, 2 * kk, 2 * k + 1, s01, x01, d01);
+        use(mine, 2 * kk + 1, 2 * k, s10, x10, d10);
+        use(mine, 2 * kk + 1, 2 * k + 1, s11, x11, d11);
+        cur = nxt;
+    }
+    for (int q = 32; q >= 1; q >>= 1) { acc += __shfl_xor(acc, q); mx = fmaxf(mx, __shfl_xor(mx, q)); }
+    if (threadIdx.x == 0) {
+        u.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = acc;
+        atomicMax(&u.fs[frame].maxerr_bits, __float_as_uint(mx));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // residual min/max with "first occurrence wins" tie-break (reference findMinMaxf, ebcc_codec.c:515-533)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_minmax_init(FrameState *fs, int n_frames)
@@ -905,11 +1008,21 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
         rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
     }
     const int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
-    hipLaunchKernelGGL(k_cols_inv_stream, dim3(ceil_div(g.nx, kStreamT), n_frames, pieces), dim3(kStreamT), 0, s, rb.A, rb.T, g, rb.np, rb.C,
-                       rb.sigord, rb.lspidx, rb.fs, d_trunc_bits, d_active);
     RowUse u{};
     u.data = data; u.decoded = decoded;
-    const int partials = synthesis_tail(rb, n_frames, d_active, s, u);
+    int partials;
+    static const bool unfused = getenv("EBCC_HIP_RESIDUAL_UNFUSED") != nullptr;  // (column stream + consuming row pass as two kernels)
+    const int strips = ceil_div(g.nx >> 1, kFusePairs);
+    if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
+        u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
+        hipLaunchKernelGGL(k_finest_inv_use, dim3(strips, n_frames, pieces), dim3(64), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
+                           d_trunc_bits, d_active, u);
+        partials = strips * pieces;
+    } else {
+        hipLaunchKernelGGL(k_cols_inv_stream, dim3(ceil_div(g.nx, kStreamT), n_frames, pieces), dim3(kStreamT), 0, s, rb.A, rb.T, g, rb.np, rb.C,
+                           rb.sigord, rb.lspidx, rb.fs, d_trunc_bits, d_active);
+        partials = synthesis_tail(rb, n_frames, d_active, s, u);
+    }
     hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, partials, rb.fs, n_frames, d_active);
     EBCC_HIP_LAUNCH_CHECK();
 }

@@ -599,7 +599,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
     // It shortens a slice's chain (search #1 of 256 frames in one slice: 33 -> 29 ms) at the price of two more k_rate per
     // round; with several slices in flight the chip has no idle issue slots left to pay with (four slices: encode 7.7 GB/s
     // without, 6.7 with) - so it is on for a batch that runs as one slice, off otherwise; EBCC_HIP_SPECULATION=1 / 0 forces it.
-    static const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
+    const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
     const bool speculate = forced >= 0 ? forced != 0 : g_slices.load() <= 1;
     hipStream_t s2 = nullptr;
     J2kBuffers &jb = b.jb;
@@ -660,7 +660,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
 template <class Jobs>
 void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
 {
-    static const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
+    const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
     if (host_loop) run_search(b, k, jobs, n_pix); else device_rate_search(b, k, jobs, n_pix);
 }
 
@@ -834,7 +834,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 }
             }
             // ---- truncation bisection (:777-795): all frames advance one cut per round
-            static const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
+            const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
             if (!host_loop) {
                 // state machine on the device (search.hpp): advance, reconstruct the decoder state at the cut, synthesis +
                 // statistics - enqueued back to back, one look at the states after `rounds` of them

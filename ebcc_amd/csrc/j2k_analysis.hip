@@ -716,7 +716,7 @@ int dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameSta
     if (n <= 1) return 0;
     if constexpr (FIN && !FWD) {
         // plain frames (every column starts with a low-pass sample): the streaming form; EBCC_HIP_FIN_LDS=1 keeps the LDS tiles
-        static const bool lds_form = getenv("EBCC_HIP_FIN_LDS") != nullptr;
+        const bool lds_form = getenv("EBCC_HIP_FIN_LDS") != nullptr;
         if (jb.geom.period == 1 && jb.geom.ry0[r] % 2 == 0 && !lds_form) {
             hipLaunchKernelGGL(k_j2k_cols_fin, dim3(ceil_div(cols, kFinT), n_frames), dim3(kFinT), 0, s, B, jb.d_geom, r, fs, active, fin);
             return ceil_div(cols, kFinT);
@@ -1471,7 +1471,7 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
     // pipeline), alternating between the tile buffer and jb.B2 from the first level that is large enough; the levels
     // below it, tiles at odd offsets and EBCC_HIP_L5_SPLIT=1 use the separate LDS-staged row / column passes in place.
     // EBCC_HIP_LEVELS_SPLIT=1: only the top level fused (round 2's first state).
-    static const bool split5 = getenv("EBCC_HIP_L5_SPLIT") != nullptr, split_low = getenv("EBCC_HIP_LEVELS_SPLIT") != nullptr;
+    const bool split5 = getenv("EBCC_HIP_L5_SPLIT") != nullptr, split_low = getenv("EBCC_HIP_LEVELS_SPLIT") != nullptr;
     const J2kGeom &g = jb.geom;
     const size_t n_pix = (size_t) g.W * g.H;
     auto fusable = [&](int r) {

@@ -1432,8 +1432,8 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     const int total = n_frames * jb.geom.stride;
     const size_t groups = ((size_t) total + 63) / 64;
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
-    static const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
-    static const bool global_state = getenv("EBCC_HIP_T1_DECODE_GLOBAL") != nullptr;         // (the decoder with its state in jb.T1S)
+    const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
+    const bool global_state = getenv("EBCC_HIP_T1_DECODE_GLOBAL") != nullptr;         // (the decoder with its state in jb.T1S)
     const int lpw = t1_lanes_per_wave(T1_DECODE);
     const bool lds_state = !seg_decoder && !global_state && lpw <= 16;
     if (!lds_state) EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));

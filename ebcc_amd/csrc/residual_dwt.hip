@@ -993,7 +993,7 @@ void launch_synthesis_stats(const float *data, const float *decoded, const Resid
 void launch_prefix_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
                                    const unsigned long long *d_trunc_bits, const int *d_active, hipStream_t s)
 {
-    static const bool split = getenv("EBCC_HIP_RESIDUAL_SPLIT") != nullptr;
+    const bool split = getenv("EBCC_HIP_RESIDUAL_SPLIT") != nullptr;
     const Grid &g = rb.g;
     if (split || g.stages < 2 || g.ny < 32) {
         launch_reconstruct(rb, n_frames, d_trunc_bits, d_active, s);
@@ -1011,7 +1011,7 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     RowUse u{};
     u.data = data; u.decoded = decoded;
     int partials;
-    static const bool unfused = getenv("EBCC_HIP_RESIDUAL_UNFUSED") != nullptr;  // (column stream + consuming row pass as two kernels)
+    const bool unfused = getenv("EBCC_HIP_RESIDUAL_UNFUSED") != nullptr;  // (column stream + consuming row pass as two kernels)
     const int strips = ceil_div(g.nx >> 1, kFusePairs);
     if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
         u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;

@@ -222,8 +222,8 @@ def test_sliced_batches_equal_single_engine(monkeypatch):
 
 
 def test_tuning_knobs_do_not_change_results(monkeypatch):
-    """ebcc_hip_prepare (slice engines made ahead of time), EBCC_HOST_THREADS (entropy-stage threads) and
-    EBCC_T1_LPW leave streams and fields as they are; EBCC_ZSTD_LEVEL changes the bytes of the zstd payload only -
+    """ebcc_hip_prepare (slice engines made ahead of time), EBCC_HOST_THREADS (entropy-stage threads), EBCC_T1_LPW and the
+    kernel-selection switches (read at every call) leave streams and fields as they are; EBCC_ZSTD_LEVEL changes the bytes of the zstd payload only -
     the decoded field stays the same and the reference's decoder (the oracle here) reads the stream."""
     frames = np.stack([L.era5_like(96, 160, 500 + s, 1.2, 0.8) for s in range(17)])
     cfg = L.make_config((1, 96, 160), base_cr=25.0, error=0.02, residual_type=L.MAX_ERROR)
@@ -238,7 +238,9 @@ def test_tuning_knobs_do_not_change_results(monkeypatch):
     L.oracle().orc_set_j2k_backend(0)
     assert base[0] == L.orc_encode(frames[0], cfg) and base[16] == L.orc_encode(frames[16], cfg)
     for env in ({"EBCC_HOST_THREADS": "3"}, {"EBCC_T1_LPW": "8"}, {"EBCC_T1_LPW": "16,32,1,2"}, {"EBCC_HIP_SLICES": "3", "EBCC_HIP_DECODE_SLICES": "3"},
-                {"EBCC_HIP_T1_DECODE_SEG": "1"}, {"EBCC_HIP_FIN_LDS": "1"}, {"EBCC_HIP_L5_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_SPLIT": "1"}):
+                {"EBCC_HIP_T1_DECODE_SEG": "1"}, {"EBCC_HIP_T1_DECODE_GLOBAL": "1"}, {"EBCC_HIP_FIN_LDS": "1"}, {"EBCC_HIP_L5_SPLIT": "1"},
+                {"EBCC_HIP_LEVELS_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_UNFUSED": "1"}, {"EBCC_HIP_HOST_SEARCH": "1"},
+                {"EBCC_HIP_SLICES": "2", "EBCC_HIP_SPECULATION": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with L.Context(len(frames), 96, 160) as ctx:

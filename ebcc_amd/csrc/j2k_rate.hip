@@ -1060,10 +1060,15 @@ struct DecSrcAhead {
 // at once, the short ones fill in behind them, and the lanes of a wave hold blocks of similar length.
 constexpr int kDecClasses = 64;
 __device__ inline int dec_class(const int *e) { return e[3] <= 0 || e[2] <= 0 ? 0 : min(kDecClasses - 1, 1 + (e[1] >> 6)); }
-__global__ void k_dec_hist(const int *dec_table, int *counters, int total)
+__global__ __launch_bounds__(256) void k_dec_hist(const int *dec_table, int *counters, int total)
 {
+    __shared__ int h[kDecClasses];                                      // (a histogram per workgroup: 64 global counters cannot take 10^5 atomics)
+    if (threadIdx.x < kDecClasses) h[threadIdx.x] = 0;
+    __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < total) atomicAdd(&counters[dec_class(dec_table + (size_t) gid * 4)], 1);
+    if (gid < total) atomicAdd(&h[dec_class(dec_table + (size_t) gid * 4)], 1);
+    __syncthreads();
+    if (threadIdx.x < kDecClasses && h[threadIdx.x]) atomicAdd(&counters[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void k_dec_offsets(int *counters)                         // [0,64) counts -> [64,128) first slot of every class
 {
@@ -1072,10 +1077,18 @@ __global__ void k_dec_offsets(int *counters)                         // [0,64) c
     for (int k = kDecClasses - 1; k > c; k--) before += counters[k];
     counters[kDecClasses + c] = before;
 }
-__global__ void k_dec_place(const int *dec_table, int *counters, int *order, int total)
+__global__ __launch_bounds__(256) void k_dec_place(const int *dec_table, int *counters, int *order, int total)
 {
+    __shared__ int h[kDecClasses], base[kDecClasses];
+    if (threadIdx.x < kDecClasses) h[threadIdx.x] = 0;
+    __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < total) order[atomicAdd(&counters[kDecClasses + dec_class(dec_table + (size_t) gid * 4)], 1)] = gid;
+    int cls = 0, rank = 0;
+    if (gid < total) { cls = dec_class(dec_table + (size_t) gid * 4); rank = atomicAdd(&h[cls], 1); }
+    __syncthreads();
+    if (threadIdx.x < kDecClasses && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&counters[kDecClasses + threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (gid < total) order[base[cls] + rank] = gid;
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_t1_decode_lds(const uint8_t *bytes, size_t stream_cap, const int *dec_table, const int *order, int32_t *V,

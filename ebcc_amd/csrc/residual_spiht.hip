@@ -817,15 +817,29 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
     }
 }
 
+__global__ __launch_bounds__(256) void k_zero_active(int32_t *__restrict__ C, size_t np, const int *active)
+{
+    const int frame = blockIdx.y;
+    if (active && !active[frame]) return;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 *c = reinterpret_cast<i32x4 *>(C + (size_t) frame * np);
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np / 4; i += (size_t) gridDim.x * blockDim.x) c[i] = i32x4{0, 0, 0, 0};
+}
+
 __global__ __launch_bounds__(256) void k_int_to_float(const int32_t *__restrict__ C, float *__restrict__ A, size_t np,
                                                        const int *active)
 {
     const int frame = blockIdx.y;
     if (active && !active[frame]) return;
-    const int32_t *c = C + (size_t) frame * np;
-    float *a = A + (size_t) frame * np;
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (size_t) gridDim.x * blockDim.x)
-        a[i] = (float) c[i];
+    // four coefficients per lane and step (np is a multiple of 4: the grid is padded to multiples of 8 both ways)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 *c = reinterpret_cast<const i32x4 *>(C + (size_t) frame * np);
+    f32x4 *a = reinterpret_cast<f32x4 *>(A + (size_t) frame * np);
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < np / 4; i += (size_t) gridDim.x * blockDim.x) {
+        const i32x4 v = c[i];
+        a[i] = f32x4{(float) v.x, (float) v.y, (float) v.z, (float) v.w};
+    }
 }
 
 }  // namespace
@@ -862,8 +876,8 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
                          const unsigned long long *d_num_bits, const ResidualBuffers &rb, int n_frames,
                          const int *d_active, hipStream_t s)
 {
-    // spiht_decode_init clears the coefficient grid, spiht_re.c:101
-    EBCC_HIP_CHECK(hipMemsetAsync(rb.C, 0, (size_t) n_frames * rb.np * sizeof(int32_t), s));
+    // spiht_decode_init clears the coefficient grid, spiht_re.c:101 (of the frames that are decoded)
+    hipLaunchKernelGGL(k_zero_active, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.np, d_active);
     static const bool prof = getenv("EBCC_HIP_SPIHT_PROF") != nullptr;
     if (prof) { unsigned long long z[10] = {}; EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_spiht_prof), z, sizeof z)); }
     timing_begin("spiht_decode", s);

@@ -33,7 +33,12 @@ def algo_bytes(kernel, rank, nkeys):
     if k.startswith("k_scale_shift"): return 2 * 4 * PIX, "read fp32 frame, write shifted fp32 samples"
     if k.startswith("k_in_minmax"): return 4 * PIX, "read fp32 frame"
     if k.startswith("k_quantize"): return 4 * PIX + 4 * PIX + PIX * 55 // 8, "read coefficients, write Q6 + 26 plane + sign + 28 suffix masks (1 bit each per sample)"
-    if k.startswith("k_j2k_level5_fin"): return 8 * PIX, "whole top level: read the four bands (LL fp32, rest int32) and the fp32 frame for the statistics (field kept: + 4 B/sample write)"
+    if k.startswith("k_j2k_level5_fin<true"): return 8 * PIX, "whole top level: read the four bands (LL fp32, rest int32) and the fp32 frame for the statistics (field kept: + 4 B/sample write)"
+    if k.startswith("k_j2k_level5_fin<false"):
+        lv = 4 - rank if rank < 4 else 1                 # geometries of levels 4, 3, 2, 1 - largest first
+        w, h = RES[lv]
+        return 8 * w * h, f"whole level {lv}: read the four bands, write {w}x{h} fp32"
+    if k.startswith("k_finest_inv_use"): return 4 * (NX * NY // 4) + 4 * 3 * (NX * NY // 4) + 8 * PIX, "finest residual level whole: LL read, the ordinals of three detail bands (+ coefficient and slot inside the prefix), frame and decoded field for the statistics"
     if k.startswith("k_j2k_cols_fin"): return 8 * PIX, "level 5 columns: read the level and the fp32 frame (field kept: + 4 B/sample write)"
     if k.startswith("k_rate"): return 300000, "per-pass rate / distortion tables (latency-bound: bisection)"
     if k.startswith("k_t1_resume"): return 4 * PIX // 8, "a stripe or two of one coding pass per changed code-block (latency-bound)"

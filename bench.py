@@ -358,7 +358,10 @@ def main():
         }
         try:                                                    # HBM-bound kernels, measured alone (tools/gpu/hbm_table.sh): best and worst of the table
             hk = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_kernels.json")))
-            rows = [r for r in hk["kernels"] if r.get("frac_of_6290") is not None]
+            # rows that are HBM measurements: at least 1 MB per frame to move by role, counter traffic within 2x of it either
+            # way (below: the input was still in the Infinity Cache; above: re-reads), and not latency-bound by design
+            rows = [r for r in hk["kernels"] if r.get("frac_of_6290") is not None and r["algorithmic_bytes"] >= hk["frames_per_dispatch"] * (1 << 20)
+                    and 0.5 <= r["counter_over_algorithmic"] <= 2.5 and "latency-bound" not in r.get("what", "")]
             if rows:
                 line["hbm_kernels"] = {"source": "profiles/r02_hbm_kernels.json@" + hk.get("kernel_sources_sha", "?"),
                                        "best": max(rows, key=lambda r: r["frac_of_6290"]), "worst": min(rows, key=lambda r: r["frac_of_6290"])}

@@ -1082,48 +1082,65 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     std::vector<ParsedFrame> heads(n);
     PhaseTimer pt;
     fetch_frame_states(ctx, n);
-    bool any_resid = false;
-    for (size_t f = 0; f < n; f++) {
+    // the host side of a batch - frame headers, packet headers, zstd of the residual streams - is per frame and runs on a
+    // few host threads (decode is one slice: nothing else hides it); a frame's failure fails the batch
+    std::atomic<bool> failed{false}, resid{false};
+    auto for_frames = [&](auto body) {
+        const size_t nthreads = std::min<size_t>({(size_t) 16, (size_t) std::max(1u, (unsigned) entropy_threads(1)), (n + 7) / 8});
+        std::atomic<size_t> next_frame{0};
+        auto worker = [&]() {
+            for (size_t f = next_frame++; f < n && !failed.load(std::memory_order_relaxed); f = next_frame++)
+                if (!body(f)) failed = true;
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    };
+    for_frames([&](size_t f) -> bool {
         const uint8_t *d = streams[f];
         const size_t len = sizes[f];
         ctx->h_active[f] = 0;
         ParsedFrame &hd = heads[f];
-        if (!parse_frame(d, len, hd)) return 1;
+        if (!parse_frame(d, len, hd)) return false;
         FrameState &fs = ctx->h_fs[f];
         fs.minv = hd.minv; fs.maxv = hd.maxv;
         fs.rmin = hd.rmin; fs.rmax = hd.rmax;
         fs.const_field = hd.const_field ? 1 : 0;
-        const uint8_t *z = hd.z, *tail = hd.tail;
         if (fs.const_field) {
             uint64_t cnt = 0;
-            memcpy(&cnt, tail, 8);
-            if (cnt != n_pix) { log_fatal("const-field length %llu does not match the frame", (unsigned long long) cnt); return 1; }
+            memcpy(&cnt, hd.tail, 8);
+            if (cnt != n_pix) { log_fatal("const-field length %llu does not match the frame", (unsigned long long) cnt); return false; }
         } else {
-            if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return 1; }
-            if (!j2k_parse_codestream(tail, hd.tail_size, g, table + f * g.stride * 4)) return 1;
+            if (hd.tail_size > jb.stream_cap) { log_fatal("codestream larger than the device slot"); return false; }
+            if (!j2k_parse_codestream(hd.tail, hd.tail_size, g, table + f * g.stride * 4)) return false;
             piece[f] = hd.tail_size;
             if (hd.compressed_size > 0 && hd.coeffs_size > 0) {                                                    // :1294-1304
-                if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-                if (hd.coeffs_size > ctx->rb.stream_words * 4 - 64) { log_fatal("residual stream larger than the device slot"); return 1; }
+                if (!zstd().ok) { log_fatal("libzstd not available"); return false; }
+                if (hd.coeffs_size > ctx->rb.stream_words * 4 - 64) { log_fatal("residual stream larger than the device slot"); return false; }
                 piece[n + f] = hd.coeffs_size;
                 ctx->h_active[f] = 1;
-                any_resid = true;
+                resid = true;
             }
         }
-        (void) z;
-    }
+        return true;
+    });
+    if (failed) return 1;
+    const bool any_resid = resid;
     stage_reserve(ctx, piece.data(), piece_off.data(), 2 * n);
-    for (size_t f = 0; f < n; f++) {
+    for_frames([&](size_t f) -> bool {
         const ParsedFrame &hd = heads[f];
         if (piece[f]) memcpy(ctx->h_stage + piece_off[f], hd.tail, hd.tail_size);
         if (piece[n + f]) {
             // the residual stream: exactly coeffs_size bytes (the staging buffer holds whatever an earlier call left),
             // a SPIHT header for this grid and a bit budget the decoder can work with (:1294-1304)
             const size_t got = zstd().decompress(ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.z, hd.compressed_size);
-            if ((zstd().is_error && zstd().is_error(got)) || got != hd.coeffs_size) { log_fatal("Invalid encoded data: residual payload does not decompress to %zu bytes", hd.coeffs_size); return 1; }
-            if (check_ims_header(ctx, ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.coeffs_size * 8)) { log_fatal("Invalid encoded data: %s", ebcc_hip_last_error()); return 1; }
+            if ((zstd().is_error && zstd().is_error(got)) || got != hd.coeffs_size) { log_fatal("Invalid encoded data: residual payload does not decompress to %zu bytes", hd.coeffs_size); return false; }
+            if (check_ims_header(ctx, ctx->h_stage + piece_off[n + f], hd.coeffs_size, hd.coeffs_size * 8)) { log_fatal("Invalid encoded data: %s", ebcc_hip_last_error()); return false; }
         }
-    }
+        return true;
+    });
+    if (failed) return 1;
     stage_send(ctx, 2 * n, s);
     stage_scatter(ctx, jb.stream, jb.stream_cap, 0, n, s);
     pt.mark("decode: parse, zstd, uploads");
@@ -1388,6 +1405,10 @@ int run_on_devices(size_t n_chunks, Fn fn)
 // application's streams; it is read when the runtime starts, so the application sets it): streams that share a
 // queue run one after the other.  Default for encode: 4 slices when the process runs with GPU_MAX_HW_QUEUES >= 8
 // (measured best on MI355X: the host-side zstd of one slice hides behind the GPU phases of the others), else 2.
+// Decode runs as ONE slice since round 2: its launch is as long as the longest SPIHT stream of the batch whatever the
+// batch size, and the tier-1 decoder is bound by vector issue slots - two half batches side by side only shared them
+// (A/B on one box, tools/gpu/ab_dec.sh: 33 GB/s with one slice, 27 with two).
+constexpr size_t kDefaultDecodeSlices = 1;
 static size_t default_encode_slices()
 {
     const char *e = getenv("GPU_MAX_HW_QUEUES");
@@ -1468,7 +1489,7 @@ int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const si
     const size_t n_pix = ctx->n_pix;
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
         return decode_batch(c, streams + lo, sizes + lo, cnt, d_out + lo * n_pix, next);
-    }, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);
+    }, "EBCC_HIP_DECODE_SLICES", kDefaultDecodeSlices);
 }
 
 }  // namespace
@@ -1508,7 +1529,7 @@ int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
     if (!ctx || n_frames < 1 || n_frames > ctx->max_frames) { set_error("ebcc_hip_prepare: bad batch"); return 1; }
     std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
     DeviceScope scope(ctx->device);
-    slice_engines(ctx, n_frames, "EBCC_HIP_DECODE_SLICES", default_encode_slices() >= 4 ? 2 : 1);   // (the coarser slicing first:
+    slice_engines(ctx, n_frames, "EBCC_HIP_DECODE_SLICES", kDefaultDecodeSlices);                     // (the coarser slicing first:
     slice_engines(ctx, n_frames, "EBCC_HIP_SLICES", default_encode_slices());                        //  its lanes serve both)
     second_stream(ctx);
     for (ebcc_hip_ctx *c : ctx->lanes) second_stream(c);

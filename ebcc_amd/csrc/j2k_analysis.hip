@@ -1275,7 +1275,10 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
                                                      double *__restrict__ disto, const short *__restrict__ luts,
                                                      const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs)
 {
-    __shared__ int nms[kJ2kMaxPasses];
+    // 32 copies of every pass's sum, a lane adds to copy lane % 32 (one LDS bank each): the samples of a wave mostly hit the
+    // same few passes, and 64 atomics on one address are served one after the other (5.8 % of the HBM roof before)
+    constexpr int kCopies = 32;
+    __shared__ int nms[kJ2kMaxPasses * kCopies];
     __shared__ short lut[4 * 128];
     const int frame = blockIdx.y, bi = blockIdx.x;
     if (fs[frame].const_field) return;
@@ -1284,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
     geom = &j2k_frame_geom(geom, frame);
     const int P = numbps[gid], np = totalpasses[gid];
     if (np <= 0) return;
-    for (int i = threadIdx.x; i < kJ2kMaxPasses; i += 256) nms[i] = 0;
+    for (int i = threadIdx.x; i < kJ2kMaxPasses * kCopies; i += 256) nms[i] = 0;
     for (int i = threadIdx.x; i < 4 * 128; i += 256) lut[i] = luts[i];
     __syncthreads();
     const J2kBlock blk = blocks[bi];
@@ -1293,6 +1296,7 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
     const size_t grp = (size_t) (gid >> 6);
     const int gl = gid & 63;
     const unsigned long long *sps = SPS + grp * 64 * 64 + gl;
+    const int copy = threadIdx.x & (kCopies - 1);
     for (int t = threadIdx.x; t < blk.w * blk.h; t += 256) {
         int y = t / blk.w, x = t - y * blk.w;
         int q6 = q[(size_t) (blk.y + y) * W + blk.x + x];
@@ -1303,11 +1307,17 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
         int ps = bs == P - 1 ? 0 : 3 * (P - 1 - bs) - (from_sp ? 2 : 0);
         // opj_t1_getnmsedec_sig / _ref: 7-bit index around the coded bit, separate tables for plane 0
         int v = bs > 0 ? lut[0 * 128 + ((a6 >> bs) & 127)] : lut[1 * 128 + (a6 & 127)];
-        atomicAdd(&nms[ps], v);
+        atomicAdd(&nms[ps * kCopies + copy], v);
         for (int b = bs - 1; b >= 0; b--) {
             int r = b > 0 ? lut[2 * 128 + ((a6 >> b) & 127)] : lut[3 * 128 + (a6 & 127)];
-            atomicAdd(&nms[3 * (P - 1 - b) - 1], r);
+            atomicAdd(&nms[(3 * (P - 1 - b) - 1) * kCopies + copy], r);
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < kJ2kMaxPasses) {                                  // (integers: the order of the additions does not matter)
+        int sum = 0;
+        for (int c = 0; c < kCopies; c++) sum += nms[threadIdx.x * kCopies + ((c + threadIdx.x) & (kCopies - 1))];
+        nms[threadIdx.x * kCopies] = sum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1318,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
         int bp = P - 1, passtype = 2;
         for (int p = 0; p < np; p++) {
             double wm = ((1.0 * bd.norm) * st) * (double) (1 << bp);
-            wm = wm * ((wm * (double) nms[p]) / 8192.0);
+            wm = wm * ((wm * (double) nms[p * kCopies]) / 8192.0);
             cum += wm;
             disto[(size_t) gid * kJ2kMaxPasses + p] = cum;
             if (++passtype == 3) { passtype = 0; bp--; }

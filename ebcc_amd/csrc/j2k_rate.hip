@@ -1092,13 +1092,19 @@ __global__ __launch_bounds__(256) void k_dec_place(const int *dec_table, int *co
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_t1_decode_lds(const uint8_t *bytes, size_t stream_cap, const int *dec_table, const int *order, int32_t *V,
-                                                       const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total, int lpw)
+                                                       const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total, int lpw, int n_big, int lpw_small)
 {
-    extern __shared__ unsigned long long dec_state[];                  // [kDecStateRows][lpw]
+    extern __shared__ unsigned long long dec_state[];                  // [kDecStateRows][lanes of this wave]
     EBCC_LDS_MQ_TABLE(tab);
-    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int slot = blockIdx.x * lpw + threadIdx.x;
-    if (slot >= total) return;
+    // the first n_big code-blocks of the order (the long chains) go `lpw` to a wave, the rest `lpw_small` to a wave: the
+    // kernel is bound by vector issue slots, diverged lanes share most of their instructions (4 lanes: 1.8x fewer wave
+    // instructions than 2), but a wave lasts as long as its lanes together - affordable only for short code-blocks
+    const int big_waves = (n_big + lpw - 1) / lpw;
+    const bool small = (int) blockIdx.x >= big_waves;
+    const int lanes = small ? lpw_small : lpw;
+    if ((int) threadIdx.x >= lanes) return;                            // see t1_lanes_per_wave()
+    const int slot = small ? n_big + ((int) blockIdx.x - big_waves) * lpw_small + (int) threadIdx.x : (int) blockIdx.x * lpw + (int) threadIdx.x;
+    if (slot >= total || (!small && slot >= n_big)) return;
     const int gid = order[slot];
     const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -1110,7 +1116,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const uint8_t *src = bytes + (size_t) frame * stream_cap + e[0];
     if (np <= 0 || P <= 0) return;
     const J2kBlock blk = blocks[bi];
-    DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lpw * 8u,
+    DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lanes * 8u,
                    V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
     for (int r = 0; r < kDecStateRows; r++) st.at(r) = 0ull;
     t1::decode_block(st, DecSrcAhead(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
@@ -1464,8 +1470,15 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
             hipLaunchKernelGGL(k_dec_hist, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, total);
             hipLaunchKernelGGL(k_dec_offsets, dim3(1), dim3(kDecClasses), 0, s, counters);
             hipLaunchKernelGGL(k_dec_place, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, jb.dec_order, total);
-            hipLaunchKernelGGL(k_t1_decode_lds, dim3((unsigned) ceil_div(total, lpw)), dim3(64), (size_t) kDecStateRows * lpw * 8, s, jb.stream,
-                               jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
+            // EBCC_T1_DEC_MIX = "<d>,<n>": the longest 1/d of the code-blocks at `lpw` lanes per wave, the rest at n (default 32,4;
+            // 256 frames: 27.3 ms all at 2 lanes, 23.5 ms with 32,4, 34 ms with 16,8 - tools/gpu/dec_mix.sh)
+            int den = 32, lpw_small = 4;
+            if (const char *e = getenv("EBCC_T1_DEC_MIX")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && (b == 1 || b == 2 || b == 4 || b == 8 || b == 16)) { den = a; lpw_small = b; } }
+            if (lpw_small < lpw) lpw_small = lpw;
+            const int n_big = lpw_small == lpw ? total : std::min(total, ceil_div(ceil_div(total, den), lpw) * lpw);
+            const unsigned waves = (unsigned) (ceil_div(n_big, lpw) + ceil_div(total - n_big, lpw_small));
+            hipLaunchKernelGGL(k_t1_decode_lds, dim3(waves), dim3(64), (size_t) kDecStateRows * std::max(lpw, lpw_small) * 8, s, jb.stream,
+                               jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw, n_big, lpw_small);
         }
         else
             hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,

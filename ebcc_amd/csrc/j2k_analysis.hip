@@ -1448,6 +1448,62 @@ bool j2k_tier1_retry(const J2kBuffers &jb, int n_frames, const J2kFrame *host_jf
     return true;
 }
 
+// The top level's forward COLUMN pass as a stream, fused with the u16 scaling and the DC shift (k_scale_shift): a thread
+// per column reads the frame's rows in order, carries the four lifting steps in a register pipeline two positions deep
+// (fdwt_tile's expressions, order and boundary forms, cas == 0) and writes the low-pass row j to row j and the high-pass
+// row j to row sn + j of the tile buffer.  Out of place by nature (frame -> jb.B), so the level needs no LDS staging,
+// every access is a full row segment, and the shifted samples never exist in memory.  The column is cut into gridDim.z
+// pieces; a piece starts two positions early and ends two late (an output depends on the inputs of positions i - 2 .. i + 2).
+constexpr int kFwdT = 64;
+__global__ __launch_bounds__(kFwdT) void k_j2k_cols_fwd_top(const float *__restrict__ data, float *__restrict__ B, const J2kGeom *geom,
+                                                             const FrameState *fs)
+{
+    const int frame = blockIdx.y;
+    if (fs[frame].const_field) return;
+    const J2kGeom &g = j2k_frame_geom(geom, frame);
+    constexpr int r = kJ2kRes - 1;
+    const int W = g.W, nv = g.rh[r], sn = g.rh[r - 1], dn = nv - sn;
+    const int col = blockIdx.x * kFwdT + threadIdx.x;
+    if (col >= g.rw[r]) return;
+    const size_t n_pix = (size_t) W * g.H;
+    const float *x = data + (size_t) frame * n_pix + col;
+    float *b = B + (size_t) frame * n_pix + col;
+    const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
+    auto sample = [&](int y) {                                          // k_scale_shift: u16 scaling (:686-689) and OpenJPEG's DC shift
+        const unsigned int u = __float2uint_rz(((x[(size_t) y * W] - mn) / rng) * 65535.0f) & 0xFFFFu;
+        return (float) ((int) u - 32768);
+    };
+    const float invK = (float) (1.0 / 1.230174105);
+    const int per = ceil_div(sn, (int) gridDim.z), ka = (int) blockIdx.z * per, kb = min(sn, ka + per);
+    const int j0 = max(ka - 2, 0);
+    float E_1 = 0, O_1 = 0;        // inputs of position j - 1
+    float o1_2 = 0, e1_2 = 0;      // after steps 1 and 2: position j - 2
+    float o2_3 = 0;                // after step 3: position j - 3
+    float e_in = sample(min(2 * j0, nv - 1)), o_in = sample(min(2 * j0 + 1, nv - 1));
+    for (int j = j0; j < kb + 2; j++) {
+        // the next position's rows are requested before this one is worked on
+        const int jn = j + 1;
+        const float e_nx = sample(min(2 * jn, nv - 1)), o_nx = sample(min(2 * jn + 1, nv - 1));
+        const float E0 = e_in, O0 = o_in;                                // E[j] (j < sn), O[j] (j < dn)
+        int i = j - 1;
+        float o1 = 0, e1 = 0;
+        if (i >= 0 && i < dn) o1 = (i + 1 < sn) ? O_1 + ((E_1 + E0) * kA) : O_1 + ((2 * E_1) * kA);
+        if (i >= 0 && i < sn) e1 = (i < dn) ? E_1 + (((i == 0 ? o1 : o1_2) + o1) * kB) : E_1 + ((2 * o1_2) * kB);
+        i = j - 2;
+        float o2 = 0;
+        if (i >= 0 && i < dn) o2 = (i + 1 < sn) ? o1_2 + ((e1_2 + e1) * kG) : o1_2 + ((2 * e1_2) * kG);
+        if (i >= ka && i < kb) {
+            const float e2 = (i < dn) ? e1_2 + (((i == 0 ? o2 : o2_3) + o2) * kD) : e1_2 + ((2 * o2_3) * kD);
+            b[(size_t) i * W] = e2 * invK;
+            if (i < dn) b[(size_t) (sn + i) * W] = o2 * kK;
+        }
+        E_1 = E0; O_1 = O0;
+        o1_2 = o1; e1_2 = e1;
+        o2_3 = o2;
+        e_in = e_nx; o_in = o_nx;
+    }
+}
+
 void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, hipStream_t s)
 {
     const FrameState *fs = jb.fs;
@@ -1455,11 +1511,18 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     const size_t n_pix = (size_t) g.W * g.H;
     const int total = n_frames * g.stride;
     hipLaunchKernelGGL(k_jf_reset, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.jf, n_frames);
-    hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
+    // plain frames: scaling, DC shift and the top level's column pass in one streaming kernel (EBCC_HIP_FWD_SPLIT=1: separate)
+    const bool fwd_top = !getenv("EBCC_HIP_FWD_SPLIT") && g.period == 1 && g.ry0[kJ2kRes - 1] % 2 == 0 && g.rh[kJ2kRes - 2] >= 2 &&
+                         g.rh[kJ2kRes - 1] - g.rh[kJ2kRes - 2] >= 1;
+    if (!fwd_top) hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.rate_path_n, 0, sizeof(int) * (size_t) n_frames, s));   // new pass tables: k_rate's record starts over
     EBCC_HIP_CHECK(hipMemsetAsync(jb.lastnp, 0xFF, sizeof(int) * (size_t) total, s));         // and so does the probe decode's
     timing_begin("j2k_dwt_fwd", s);
     for (int r = kJ2kRes - 1; r >= 1; r--) {                           // opj_dwt_encode_procedure: vertical, then horizontal
+        if (fwd_top && r == kJ2kRes - 1) {
+            const int pieces = std::max(1, std::min(8, g.rh[r - 1] / 16));
+            hipLaunchKernelGGL(k_j2k_cols_fwd_top, dim3(ceil_div(g.rw[r], kFwdT), n_frames, pieces), dim3(kFwdT), 0, s, data, jb.B, jb.d_geom, fs);
+        } else
         dwt_cols<true>(jb.B, jb, r, n_frames, fs, nullptr, s);
         if (g.rw[r] > 1) dwt_rows<true>(jb.B, nullptr, jb, r, n_frames, fs, nullptr, s);
     }

@@ -239,7 +239,7 @@ def test_tuning_knobs_do_not_change_results(monkeypatch):
     assert base[0] == L.orc_encode(frames[0], cfg) and base[16] == L.orc_encode(frames[16], cfg)
     for env in ({"EBCC_HOST_THREADS": "3"}, {"EBCC_T1_LPW": "8"}, {"EBCC_T1_LPW": "16,32,1,2"}, {"EBCC_HIP_SLICES": "3", "EBCC_HIP_DECODE_SLICES": "3"},
                 {"EBCC_HIP_T1_DECODE_SEG": "1"}, {"EBCC_HIP_T1_DECODE_GLOBAL": "1"}, {"EBCC_HIP_FIN_LDS": "1"}, {"EBCC_HIP_L5_SPLIT": "1"},
-                {"EBCC_HIP_LEVELS_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_UNFUSED": "1"}, {"EBCC_HIP_HOST_SEARCH": "1"},
+                {"EBCC_HIP_LEVELS_SPLIT": "1"}, {"EBCC_HIP_FWD_SPLIT": "1"}, {"EBCC_T1_DEC_MIX": "1,2"}, {"EBCC_T1_DEC_MIX": "4,8"}, {"EBCC_HIP_RESIDUAL_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_UNFUSED": "1"}, {"EBCC_HIP_HOST_SEARCH": "1"},
                 {"EBCC_HIP_SLICES": "2", "EBCC_HIP_SPECULATION": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -18,8 +18,9 @@ import os
 import sys
 import time
 
-# The encode path runs its batch as 4 concurrent slices when the HIP runtime has a hardware queue for each of their
-# streams (host_codec.hip: default_encode_slices); the runtime reads this when it starts, i.e. before torch loads.
+# The encode path runs its batch as concurrent slices (two by default, host_codec.hip: default_encode_slices), each with two
+# streams; the HIP runtime has a hardware queue for each when GPU_MAX_HW_QUEUES >= 8 - it reads this when it starts, i.e.
+# before torch loads.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
@@ -339,7 +340,7 @@ def main():
             roof = {"bound": "hbm", "kernel": "tier-1 encoder (k_t1_scan + k_t1_rowoffs + k_t1_emit + k_t1_mqrows)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(avg_s * 1e3, 4),
                     "algorithmic_bytes_per_launch": algo, "frames_per_launch": n * args.steps / launches.value}
-        slices = int(os.environ.get("EBCC_HIP_SLICES", "4" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "2"))
+        slices = int(os.environ.get("EBCC_HIP_SLICES", "2"))            # (host_codec.hip: default_encode_slices)
         lib.ebcc_hip_host_threads.restype = ctypes.c_int
         line = {
             "metric": "fp32 GB/s encode+decode, 721x1440 ERA5 frames MAX_ERROR=0.5",

@@ -1411,8 +1411,11 @@ int run_on_devices(size_t n_chunks, Fn fn)
 constexpr size_t kDefaultDecodeSlices = 1;
 static size_t default_encode_slices()
 {
-    const char *e = getenv("GPU_MAX_HW_QUEUES");
-    return e && atoi(e) >= 8 ? 4 : 2;
+    // Two since the end of round 2 (was four with GPU_MAX_HW_QUEUES >= 8): the search loops no longer leave the GPU idle
+    // between rounds, so two slices keep it busy, and every further slice repeats the latency-bound launches (k_rate,
+    // the MQ pass, the restart decode) for fewer frames each.  Alternating runs on one box (tools/gpu/ab_multi.sh):
+    // encode 8.4-8.5 GB/s with two, 8.1-8.6 with three, 6.8-7.5 with four.
+    return 2;
 }
 static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames, const char *env_name, size_t k)
 {

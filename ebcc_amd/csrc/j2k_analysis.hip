@@ -1054,11 +1054,16 @@ __global__ __launch_bounds__(64) void k_t1_rowoffs(std::uint16_t *seglen, uint32
     uint32_t off = 0;
     if (l.live) {
         const int nstr = (l.h + 3) >> 2;
-        for (int seg = t1::seg_index(l.P - 1, 2, 0); seg < kJ2kSegCount; seg++) {
-            if (!t1::seg_valid(l.P, nstr, t1::seg_plane(seg), t1::seg_type(seg), seg & 15)) continue;
-            const uint32_t n = L[(uint32_t) seg * 64u];
-            L[(uint32_t) seg * 64u] = (std::uint16_t) off;
-            off += t1::seg_rows(n);
+        // sixteen counts (the stripes of one pass) are requested together, then turned into offsets: the counts do not depend
+        // on the running offset, but read and written in place one at a time every load waited for the store before it
+        for (int seg0 = t1::seg_index(l.P - 1, 2, 0) & ~15; seg0 < kJ2kSegCount; seg0 += 16) {
+            if (!t1::seg_valid(l.P, nstr, t1::seg_plane(seg0), t1::seg_type(seg0), 0)) continue;      // (a pass the code-block does not have)
+            uint32_t n[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) n[k] = k < nstr ? L[(uint32_t) (seg0 + k) * 64u] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nstr) { L[(uint32_t) (seg0 + k) * 64u] = (std::uint16_t) off; off += t1::seg_rows(n[k]); }
         }
     }
     if (gid < total) lanerows[gid] = off;

@@ -262,10 +262,10 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     ok &= (ctx->d_u64a = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_u64b = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
-    ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
+    ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, 2 * max_frames)) != nullptr;      // (second half: the overlapped search's mask)
     ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 4 * max_frames)) != nullptr;
-    ok &= (ctx->d_search = ctx_alloc<uint8_t>(ctx, sizeof(DevChunk) * max_frames)) != nullptr;
-    ok &= (ctx->d_counter = (int *) ctx_alloc<uint32_t>(ctx, 4)) != nullptr;
+    ok &= (ctx->d_search = ctx_alloc<uint8_t>(ctx, 2 * sizeof(DevChunk) * max_frames)) != nullptr;   // (second half: the overlapped search)
+    ok &= (ctx->d_counter = (int *) ctx_alloc<uint32_t>(ctx, 8)) != nullptr;
     if (ok) {
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64a, max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_u64b, max_frames * sizeof(unsigned long long)));
@@ -274,8 +274,8 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 4 * max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_act, 2 * max_frames * sizeof(int)));
-        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, sizeof(DevChunk) * max_frames));
-        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_counter, 4 * sizeof(int)));
+        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, 2 * sizeof(DevChunk) * max_frames));
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_counter, 8 * sizeof(int)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
     }

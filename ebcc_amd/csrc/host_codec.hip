@@ -399,10 +399,11 @@ struct Batch {
     {
         memset(tjf, 0, sizeof(J2kFrame) * nt);
     }
-    void fetch_jf()
+    void fetch_jf(hipStream_t on = nullptr)
     {
-        EBCC_HIP_CHECK(hipMemcpyAsync(tjf, jb.jf, sizeof(J2kFrame) * nt, hipMemcpyDeviceToHost, s));
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        if (!on) on = s;
+        EBCC_HIP_CHECK(hipMemcpyAsync(tjf, jb.jf, sizeof(J2kFrame) * nt, hipMemcpyDeviceToHost, on));
+        EBCC_HIP_CHECK(hipStreamSynchronize(on));
         for (size_t c = 0; c < n; c++) {
             J2kFrame &o = jf[c];
             o.nbad = 0; o.err_sum = 0; o.overflow = 0; o.body_bytes = 0;
@@ -567,13 +568,45 @@ int search_rounds()
     if (const char *e = getenv("EBCC_HIP_SEARCH_ROUNDS")) return std::max(1, atoi(e));
     return 16;
 }
+constexpr int kSearchAll = 0, kSearchStart = 1, kSearchFinish = 2;
 template <class Jobs>
-void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
+void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, int lane = 0, int part = kSearchAll)
 {
+    // lane 1: the search runs on the engine's second stream with its own state, counters and active mask, beside whatever
+    // the first stream does (search #2 beside the residual layer).  part: enqueue the first batch of rounds only
+    // (kSearchStart: no host synchronisation), or take the search up from there (kSearchFinish), or both.
     ebcc_hip_ctx *ctx = b.ctx;
     const size_t n = b.n;
-    DevChunk *h = static_cast<DevChunk *>(ctx->h_search), *d = static_cast<DevChunk *>(ctx->d_search);
-    hipStream_t s = b.s;
+    DevChunk *h = static_cast<DevChunk *>(ctx->h_search) + (size_t) lane * ctx->max_frames, *d = static_cast<DevChunk *>(ctx->d_search) + (size_t) lane * ctx->max_frames;
+    int *const d_counter = ctx->d_counter + 4 * lane, *const h_counter = ctx->h_counter + 4 * lane;
+    int *const d_active = lane ? ctx->d_active + ctx->max_frames : b.d_active;
+    hipStream_t s = lane ? second_stream(ctx) : b.s;
+    J2kBuffers &jb = b.jb;
+    const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
+    const bool speculate = lane == 0 && (forced >= 0 ? forced != 0 : g_slices.load() <= 1);   // (lane 1 runs on the stream the candidates would use)
+    hipStream_t s2 = nullptr;
+    auto advance = [&]() {
+        launch_search_advance(d, jb.jf, d_active, (int) n, (int) b.tiles, k, (double) n_pix, d_counter, s,
+                              speculate ? jb.cand_cr : nullptr, speculate ? jb.cand_sel : nullptr);
+        if (speculate) launch_j2k_rate_publish(jb, (int) b.nt, s);
+    };
+    auto enqueue_rounds = [&](int rounds) {
+        for (int r = 0; r < rounds; r++) {
+            launch_j2k_rate(jb, (int) b.nt, d_active, s, speculate ? jb.have_rate : nullptr);
+            if (speculate) {
+                // the candidates read the record of bisection steps this k_rate may have extended, and the masks / rates of
+                // the advance: after both; the next advance reads their results: after them
+                EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));
+                EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
+                launch_j2k_rate_candidates(jb, (int) b.nt, d_active, s2);
+                EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
+            }
+            launch_j2k_probe_decode(b.d_frames, jb, (int) b.nt, d_active, s, k == 0 ? 2 : 0);     // (the field is stored where the advance asked for it: search.hip keeps_field)
+            if (speculate) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
+            advance();
+        }
+    };
+    if (part != kSearchFinish) {
     for (size_t f = 0; f < n; f++) {
         const Job &j = jobs[f];
         DevChunk &c = h[f];
@@ -589,8 +622,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
         o.last = DevProbe{j.last[k].cr, j.last[k].stream_bytes, j.last[k].nbad, j.last[k].err_sum};
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, s));
-    EBCC_HIP_CHECK(hipMemsetAsync(ctx->d_counter, 0, sizeof(int) * 4, s));
-    int rounds = search_rounds();
+    EBCC_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(int) * 4, s));
     // a round = the probe the previous advance asked for (rate allocation + decode of the active chunks), then the advance
     // that takes it in and asks for the next one.  Speculative rate allocation (EBCC_HIP_NO_SPECULATION=1 turns it off): a
     // step of the search can go two ways, so the layers of both rates it may ask for next are worked out on the engine's
@@ -599,10 +631,6 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
     // It shortens a slice's chain (search #1 of 256 frames in one slice: 33 -> 29 ms) at the price of two more k_rate per
     // round; with several slices in flight the chip has no idle issue slots left to pay with (four slices: encode 7.7 GB/s
     // without, 6.7 with) - so it is on for a batch that runs as one slice, off otherwise; EBCC_HIP_SPECULATION=1 / 0 forces it.
-    const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
-    const bool speculate = forced >= 0 ? forced != 0 : g_slices.load() <= 1;
-    hipStream_t s2 = nullptr;
-    J2kBuffers &jb = b.jb;
     if (speculate) {
         s2 = second_stream(ctx);
         if (!ctx->ev_a) {
@@ -612,36 +640,21 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
         EBCC_HIP_CHECK(hipMemsetAsync(jb.cand_cr, 0xFF, sizeof(float) * 2 * b.nt, s));       // (NaN: no candidate matches)
         EBCC_HIP_CHECK(hipMemsetAsync(jb.have_rate, 0, sizeof(int) * b.nt, s));
     }
-    auto advance = [&]() {
-        launch_search_advance(d, jb.jf, b.d_active, (int) n, (int) b.tiles, k, (double) n_pix, ctx->d_counter, s,
-                              speculate ? jb.cand_cr : nullptr, speculate ? jb.cand_sel : nullptr);
-        if (speculate) launch_j2k_rate_publish(jb, (int) b.nt, s);
-    };
     advance();
+    enqueue_rounds(search_rounds());
+    }
+    if (part == kSearchStart) return;
+    if (speculate && !s2) s2 = second_stream(ctx);
     for (;;) {
-        for (int r = 0; r < rounds; r++) {
-            launch_j2k_rate(jb, (int) b.nt, b.d_active, s, speculate ? jb.have_rate : nullptr);
-            if (speculate) {
-                // the candidates read the record of bisection steps this k_rate may have extended, and the masks / rates of
-                // the advance: after both; the next advance reads their results: after them
-                EBCC_HIP_CHECK(hipEventRecord(ctx->ev_a, s));
-                EBCC_HIP_CHECK(hipStreamWaitEvent(s2, ctx->ev_a, 0));
-                launch_j2k_rate_candidates(jb, (int) b.nt, b.d_active, s2);
-                EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
-            }
-            launch_j2k_probe_decode(b.d_frames, jb, (int) b.nt, b.d_active, s, k == 0 ? 2 : 0);     // (the field is stored where the advance asked for it: search.hip keeps_field)
-            if (speculate) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
-            advance();
-        }
         EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
-        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipMemcpyAsync(h_counter, d_counter, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipStreamSynchronize(s));
         bool done = true;
         for (size_t f = 0; f < n; f++) done &= h[f].rs[k].phase == 6;
         if (done) break;
-        rounds = 6;
+        enqueue_rounds(6);
     }
-    log_trace("rate search %d: %d probes of chunks over the rounds", k, ctx->h_counter[0]);
+    log_trace("rate search %d: %d probes of chunks over the rounds", k, h_counter[0]);
     for (size_t f = 0; f < n; f++) {
         Job &j = jobs[f];
         if (j.const_field) continue;
@@ -655,7 +668,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
         for (int i = 0; i < c.n_probes; i++) j.probes.push_back(ProbeRec{c.probes[i].cr, c.probes[i].nbad, c.probes[i].stream_bytes, c.probes[i].err_sum});
         b.state_cr[f] = c.state_cr;
     }
-    b.fetch_jf();                                                         // (the host mirror of the per-frame scalars follows the device again)
+    b.fetch_jf(s);                                                        // (the host mirror of the per-frame scalars follows the device again)
 }
 template <class Jobs>
 void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
@@ -776,6 +789,29 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         }
         pt.mark("rate search 1");
         b.collect_tails(jobs);                                                                // base layer of search #1
+        // ---- the pure base-layer search (:819-836) depends on nothing the residual layer produces.  EBCC_HIP_SEARCH2_OVERLAP=1
+        //      queues its rounds on the engine's second stream now (own state, counters and mask: device_rate_search lane 1),
+        //      beside the residual layer and the truncation search, and takes it up again where the reference runs it
+        //      (below).  Not the default: in the reference's place the search runs while host cores do the level-22 zstd of
+        //      the residual streams - the longer of the two - so moving it earlier only makes the residual phase share the
+        //      GPU (two slices, alternating runs: encode 8.43 GB/s overlapped, 8.66 in place).
+        auto start_search2 = [&]() {
+            for (size_t f = 0; f < n; f++) {
+                if (jobs[f].const_field) continue;
+                if (env.no_consistency) jobs[f].rs[1].start(jobs[f].cr, jobs[f].q, 1.0);      // from search #1's state
+                else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);                 // :829-833 == the first probe
+            }
+        };
+        const bool overlap2 = want_pure && tiles == 1 && rc == ctx && !getenv("EBCC_HIP_HOST_SEARCH") && getenv("EBCC_HIP_SEARCH2_OVERLAP");
+        struct DrainSecond {               // an error return between here and the take-up must not leave rounds in flight
+            ebcc_hip_ctx *c; bool armed;
+            ~DrainSecond() { if (armed && c->stream2) hipStreamSynchronize(c->stream2); }
+        } drain2{ctx, false};
+        if (overlap2) {
+            start_search2();
+            device_rate_search(b, 1, jobs, n_pix, 1, kSearchStart);
+            drain2.armed = true;
+        }
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
         fetch_frame_states(rc, n);
         bool any_resid = false;
@@ -924,10 +960,16 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         // one job per frame on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so
         // the host is never oversubscribed however many slices run
         std::atomic<size_t> next_frame{0};
+        // longest first: level 22 takes ~1 ms per KB on one core and a batch has frames whose prefix is ten times the
+        // average - started last, such a frame alone decides when the slice can go on
+        std::vector<size_t> zorder(n);
+        for (size_t f = 0; f < n; f++) zorder[f] = f;
+        std::stable_sort(zorder.begin(), zorder.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
         auto zworker = [&]() {
             // below the threads that steer the GPU (this one, the other slices'): they must not wait for a core
             setpriority(PRIO_PROCESS, (id_t) syscall(SYS_gettid), 10);
-            for (size_t f = next_frame++; f < n; f = next_frame++) {
+            for (size_t i = next_frame++; i < n; i = next_frame++) {
+                const size_t f = zorder[i];
                 Job &j = jobs[f];
                 if (j.coeffs_size == 0) continue;
                 j.zbytes.resize(zstd().bound(j.coeffs_size));
@@ -945,12 +987,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             // The pure-base-layer search restarts from base_cr with the quantile of a re-encode at base_cr
             // (:829-833), i.e. of the first probe above (unless that consistency step is disabled), and re-uses
             // every probe search #1 made; it runs here, while host cores do the level-22 zstd.
-            for (size_t f = 0; f < n; f++) {
-                if (jobs[f].const_field) continue;
-                if (env.no_consistency) jobs[f].rs[1].start(jobs[f].cr, jobs[f].q, 1.0);      // from search #1's state
-                else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);                 // :829-833 == the first probe
-            }
-            rate_search(b, 1, jobs, n_pix);                                                   // :836
+            if (overlap2) { device_rate_search(b, 1, jobs, n_pix, 1, kSearchFinish); drain2.armed = false; }
+            else { start_search2(); rate_search(b, 1, jobs, n_pix); }                         // :836
             zjoin();
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {

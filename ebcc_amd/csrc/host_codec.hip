@@ -989,7 +989,9 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             // every probe search #1 made; it runs here, while host cores do the level-22 zstd.
             if (overlap2) { device_rate_search(b, 1, jobs, n_pix, 1, kSearchFinish); drain2.armed = false; }
             else { start_search2(); rate_search(b, 1, jobs, n_pix); }                         // :836
+            pt.mark("rate search 2");
             zjoin();
+            pt.mark("zstd: wait for the workers");
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];

@@ -1453,7 +1453,11 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
     const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
     const bool global_state = getenv("EBCC_HIP_T1_DECODE_GLOBAL") != nullptr;         // (the decoder with its state in jb.T1S)
-    const int lpw = t1_lanes_per_wave(T1_DECODE);
+    int lpw = t1_lanes_per_wave(T1_DECODE);
+    // few code-blocks (a frame or a few decoded alone, e.g. from an HDF5 filter callback): there are wave slots to spare and
+    // a wave per code-block ends soonest (one 721 x 1440 frame through ebcc_decode: 16.8 -> 8.6 ms)
+    const bool few_blocks = !getenv("EBCC_T1_LPW") && !getenv("EBCC_T1_DEC_MIX") && total <= 4096;
+    if (few_blocks) lpw = 1;
     const bool lds_state = !seg_decoder && !global_state && lpw <= 16;
     if (!lds_state) EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_decode", s);
@@ -1474,6 +1478,7 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
             // 256 frames: 27.3 ms all at 2 lanes, 23.5 ms with 32,4, 34 ms with 16,8 - tools/gpu/dec_mix.sh)
             int den = 32, lpw_small = 4;
             if (const char *e = getenv("EBCC_T1_DEC_MIX")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && (b == 1 || b == 2 || b == 4 || b == 8 || b == 16)) { den = a; lpw_small = b; } }
+            if (few_blocks) lpw_small = 1;
             if (lpw_small < lpw) lpw_small = lpw;
             const int n_big = lpw_small == lpw ? total : std::min(total, ceil_div(ceil_div(total, den), lpw) * lpw);
             const unsigned waves = (unsigned) (ceil_div(n_big, lpw) + ceil_div(total - n_big, lpw_small));

@@ -314,6 +314,7 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->d_stage) hipFree(ctx->d_stage);
     if (ctx->d_io) hipFree(ctx->d_io);
+    if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

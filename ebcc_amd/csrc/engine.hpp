@@ -43,6 +43,7 @@ struct ebcc_hip_ctx {
     // device image of the host arrays the reference-compatible entry points are handed (kept between calls)
     float *d_io = nullptr;
     size_t io_cap = 0;                      // bytes
+    uint8_t *h_bounce = nullptr;            // 2 x kBounceBytes pinned: pageable host arrays cross PCIe through it (host_codec.hip)
     unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 pieces per frame][offset, length]
 };
 

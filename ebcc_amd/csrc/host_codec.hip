@@ -14,6 +14,7 @@
 #include <sched.h>
 #include <condition_variable>
 #include <map>
+#include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -253,6 +254,48 @@ float *io_buffer(ebcc_hip_ctx *ctx, size_t bytes)
     if (e != hipSuccess) { char b[128]; snprintf(b, sizeof b, "device buffer of %zu bytes: %s", bytes, hipGetErrorString(e)); throw HipFailure(b); }
     ctx->d_io = (float *) p; ctx->io_cap = bytes;
     return ctx->d_io;
+}
+
+// A pageable host array <-> the device image, through two pinned buffers: the DMA engine fills (or drains) one while a few
+// host threads copy the other to (or from) the caller's memory.  hipMemcpy on pageable memory stages through one internal
+// buffer on one thread: ~10 GB/s, 100 ms for the 1.06 GB of a 256-frame batch - four times the decode itself.
+constexpr size_t kBounceBytes = (size_t) 32 << 20;
+static void host_copy_parallel(void *dst, const void *src, size_t bytes)
+{
+    const size_t nthreads = std::min<size_t>(8, std::max<size_t>(1, bytes >> 20));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthreads; t++)
+        pool.emplace_back([=]() { const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
+                                  memcpy((char *) dst + lo, (const char *) src + lo, hi - lo); });
+    memcpy(dst, src, bytes / nthreads);
+    for (auto &t : pool) t.join();
+}
+static void copy_pageable(ebcc_hip_ctx *ctx, void *host, void *dev, size_t bytes, bool to_host)
+{
+    if (bytes < 2 * kBounceBytes || getenv("EBCC_HIP_PLAIN_COPIES")) {
+        EBCC_HIP_CHECK(hipMemcpy(to_host ? host : dev, to_host ? dev : host, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
+        return;
+    }
+    if (!ctx->h_bounce) EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_bounce, 2 * kBounceBytes));
+    hipStream_t s = ctx->stream;
+    const size_t chunks = (bytes + kBounceBytes - 1) / kBounceBytes;
+    auto len = [&](size_t i) { return std::min(kBounceBytes, bytes - i * kBounceBytes); };
+    if (to_host) {
+        EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_bounce, dev, len(0), hipMemcpyDeviceToHost, s));
+        for (size_t i = 0; i < chunks; i++) {
+            EBCC_HIP_CHECK(hipStreamSynchronize(s));                                       // chunk i has arrived
+            if (i + 1 < chunks)
+                EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_bounce + ((i + 1) & 1) * kBounceBytes, (char *) dev + (i + 1) * kBounceBytes, len(i + 1), hipMemcpyDeviceToHost, s));
+            host_copy_parallel((char *) host + i * kBounceBytes, ctx->h_bounce + (i & 1) * kBounceBytes, len(i));
+        }
+    } else {
+        for (size_t i = 0; i < chunks; i++) {
+            host_copy_parallel(ctx->h_bounce + (i & 1) * kBounceBytes, (const char *) host + i * kBounceBytes, len(i));
+            if (i >= 1) EBCC_HIP_CHECK(hipStreamSynchronize(s));                           // (chunk i - 1 has left: its buffer is filled next)
+            EBCC_HIP_CHECK(hipMemcpyAsync((char *) dev + i * kBounceBytes, ctx->h_bounce + (i & 1) * kBounceBytes, len(i), hipMemcpyHostToDevice, s));
+        }
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    }
 }
 
 // Frames per device batch of the host-pointer entry points: EBCC_HIP_MAX_BATCH (default 256), reduced for large
@@ -1400,7 +1443,7 @@ int encode_host_frames(int device, const float *data, size_t n, int H, int W, co
             int rcode;
             // (the whole batch in one copy: uploads issued from inside the slices slowed every slice down -
             //  tools/gpu/host_api_rate.py: 5.6 GB/s encode this way, 3.7 with four uploading slices)
-            EBCC_HIP_CHECK(hipMemcpy(d, data + done * n_pix, k * n_pix * sizeof(float), hipMemcpyHostToDevice));
+            copy_pageable(ctx, const_cast<float *>(data + done * n_pix), d, k * n_pix * sizeof(float), false);
             if (tiles == 1) rcode = run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done);   // one-frame chunks: concurrent slices
             else rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
             if (rcode) return rcode;
@@ -1828,6 +1871,28 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     std::vector<float> chunks;
     if (!in_place) chunks.resize(nchunks * csize);
     float *h_chunks = in_place ? o : chunks.data();
+    // a fresh allocation of this size is unmapped pages: the download would fault them in one by one on the copying thread.
+    // A few host threads touch them while the GPU decodes (the reference-compatible output must be a malloc'd buffer).
+    struct Prefault {
+        std::vector<std::thread> pool;
+        Prefault(void *p, size_t bytes)
+        {
+            const size_t nthreads = bytes >= ((size_t) 64 << 20) ? std::min<size_t>(16, std::max(1u, (unsigned) entropy_threads(1))) : 0;
+            if (nthreads) {                                             // huge pages where the system grants them: 512 x fewer faults
+                const uintptr_t a = ((uintptr_t) p + ((size_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), e = ((uintptr_t) p + bytes) & ~(((uintptr_t) 2 << 20) - 1);
+                if (e > a) madvise((void *) a, e - a, MADV_HUGEPAGE);
+            }
+            for (size_t t = 0; t < nthreads; t++)
+                pool.emplace_back([=]() {
+                    volatile char *c = (volatile char *) p;
+                    const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
+                    for (size_t i = lo; i < hi; i += 4096) c[i] = 0;
+                });
+        }
+        std::mutex m;                                                   // (one device thread per device may come here)
+        void join() { std::lock_guard<std::mutex> g(m); for (auto &t : pool) if (t.joinable()) t.join(); }
+        ~Prefault() { join(); }
+    } prefault(in_place ? (void *) o : nullptr, in_place ? total * sizeof(float) : 0);
     const size_t tiles = cd[0];
     const int rcode = run_on_devices(nchunks, [&](int device, size_t first, size_t count) {
         try {
@@ -1837,14 +1902,20 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
             ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
             if (!chunk_engines(device, H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
             if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+            PhaseTimer pt;
             float *d = io_buffer(ctx, cap * csize * sizeof(float));
+            pt.mark("decode_chunking: engine, device image");
             for (size_t done = first; done < first + count;) {
                 const size_t k = std::min(cap, first + count - done);
                 // (one download per batch: copies issued from inside the slices slowed them down)
                 const int r = tiles > 1 ? decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d)
                                         : run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d);
                 if (r) return r;
-                EBCC_HIP_CHECK(hipMemcpy(h_chunks + done * csize, d, k * csize * sizeof(float), hipMemcpyDeviceToHost));
+                pt.mark("decode_chunking: decode");
+                prefault.join();
+                pt.mark("decode_chunking: output pages");
+                copy_pageable(ctx, h_chunks + done * csize, d, k * csize * sizeof(float), true);
+                pt.mark("decode_chunking: download");
                 done += k;
             }
             return 0;

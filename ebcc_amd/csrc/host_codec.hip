@@ -1441,8 +1441,8 @@ int encode_host_frames(int device, const float *data, size_t n, int H, int W, co
         while (done < n) {
             size_t k = std::min(cap, n - done);
             int rcode;
-            // (the whole batch in one copy: uploads issued from inside the slices slowed every slice down -
-            //  tools/gpu/host_api_rate.py: 5.6 GB/s encode this way, 3.7 with four uploading slices)
+            // (the whole batch in one go: uploads issued from inside the slices slow every slice down - measured in round 1 with
+            //  pageable copies, 5.6 against 3.7 GB/s, and again in round 2 through the bounce buffers, 7.1 against 6.5)
             copy_pageable(ctx, const_cast<float *>(data + done * n_pix), d, k * n_pix * sizeof(float), false);
             if (tiles == 1) rcode = run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done);   // one-frame chunks: concurrent slices
             else rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);

@@ -6,10 +6,10 @@ O=gpurun_out/icache
 rm -rf $O && mkdir -p $O
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQC\?_[A-Z_0-9]*" | sort -u > $O/avail.txt
 for C in ${COUNTERS:-SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_IFETCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY}; do
-  EBCC_HIP_SLICES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 bench.py --steps 1 --warmup 1 --frames 64 --no-cpu-baseline --no-extras > $O/$C.log 2>&1
+  EBCC_HIP_SLICES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 bench.py --steps 1 --warmup 1 --frames ${FRAMES:-64} --no-cpu-baseline --no-extras > $O/$C.log 2>&1
   echo "$C rc=$?"
   c=$(find $O/$C -name "*counter_collection.csv" | head -1)
-  [ -n "$c" ] && python3 tools/pmc_summary.py "$c" $C 64 > $O/$C.json
+  [ -n "$c" ] && python3 tools/pmc_summary.py "$c" $C ${FRAMES:-64} > $O/$C.json
   rm -rf $O/$C
 done
 python3 - <<'PY'

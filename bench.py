@@ -370,7 +370,7 @@ def main():
             pass
         if extras:
             line.update(extras)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:               # (rank 0 at N = 1 only: the other ranks would wait at the end)
             try:
                 cores = min(16, len(os.sched_getaffinity(0)))
                 line["cpu_baseline"] = cpu_baseline(frames[:4].cpu().numpy(), cores)

@@ -1003,6 +1003,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         // one job per frame on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so
         // the host is never oversubscribed however many slices run
         std::atomic<size_t> next_frame{0};
+        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0};    // (EBCC_HIP_PHASE_TIMING: core time, longest job, bytes)
         // longest first: level 22 takes ~1 ms per KB on one core and a batch has frames whose prefix is ten times the
         // average - started last, such a frame alone decides when the slice can go on
         std::vector<size_t> zorder(n);
@@ -1015,9 +1016,15 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 const size_t f = zorder[i];
                 Job &j = jobs[f];
                 if (j.coeffs_size == 0) continue;
+                const auto z0 = std::chrono::steady_clock::now();
                 j.zbytes.resize(zstd().bound(j.coeffs_size));
                 size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
                 j.zbytes.resize(z);
+                if (pt.on) {
+                    const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+                    zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
+                    long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
+                }
             }
         };
         std::vector<std::thread> zpool;
@@ -1035,6 +1042,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             pt.mark("rate search 2");
             zjoin();
             pt.mark("zstd: wait for the workers");
+            if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms\n", zstd_us.load() / 1e3, zstd_bytes.load(), zstd_max_us.load() / 1e3);
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];

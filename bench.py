@@ -33,6 +33,37 @@ FRAME_BYTES = H * W * 4
 BASE_CR, MAX_ERR = 30.0, 0.5
 
 
+def cgroup_cpu():
+    """CPU quota and throttling counters of this container (cgroup v2 cpu.max / cpu.stat, or the v1 files): the GPU box
+    of this project is a 16-CPU quota on a 256-thread host, and the level-22 zstd stage is ~1.3 core-seconds per step."""
+    out = {"quota_cpus": None, "nr_periods": None, "nr_throttled": None, "throttled_usec": None, "usage_usec": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        out["quota_cpus"] = None if q == "max" else round(int(q) / int(per), 3)
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k in out:
+                out[k] = int(v)
+        return out
+    except OSError:
+        pass
+    for d in ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+        try:
+            q = int(open(d + "/cpu.cfs_quota_us").read())
+            per = int(open(d + "/cpu.cfs_period_us").read())
+            out["quota_cpus"] = None if q <= 0 else round(q / per, 3)
+            for line in open(d + "/cpu.stat"):
+                k, v = line.split()
+                if k == "throttled_time":
+                    out["throttled_usec"] = int(v) // 1000
+                elif k in out:
+                    out[k] = int(v)
+            return out
+        except OSError:
+            continue
+    return out
+
+
 def synth_frames(torch, n, device, seed, slope=1.5, amp=2.5, ramp=None):
     """SURVEY.md section 8(d) generator on the device: k^-slope spectrum noise (amplitude amp) on a zonal profile;
     ramp = (a, b): frame i's noise amplitude and profile swing are scaled by a + (b - a) * i / (n - 1), so that the
@@ -76,7 +107,7 @@ def cpu_baseline(sample, cores):
         kind = "port"
     frames = [np.ascontiguousarray(sample[i % len(sample)]) for i in range(2 * cores)]
     t0 = time.time()
-    with mp.get_context("fork").Pool(cores) as pool:
+    with mp.get_context("spawn").Pool(cores) as pool:      # (never fork a process that has initialised HIP)
         res = pool.map(_cpu_one, [(kind, f) for f in frames], chunksize=2)
     wall = time.time() - t0
     enc = float(np.median([r[0] for r in res]))
@@ -173,10 +204,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib.ebcc_hip_host_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    lib.ebcc_hip_host_stats.restype = None
+    hstats = (ctypes.c_double * 6)()
     for _ in range(args.warmup):
         step()
     lib.ebcc_hip_timing_enable(ctx, 1)
+    lib.ebcc_hip_host_stats(hstats, 1)                          # (reset)
     barrier()
+    cg0 = cgroup_cpu()
+    ru0 = os.times()
     t0 = time.perf_counter()
     enc_t = dec_t = 0.0
     comp = 0
@@ -186,15 +223,33 @@ def main():
         dec_t += d
     barrier()
     elapsed = time.perf_counter() - t0
+    ru1 = os.times()
+    cg1 = cgroup_cpu()
     lib.ebcc_hip_timing_enable(ctx, 0)
+    lib.ebcc_hip_host_stats(hstats, 0)
+    # host side of this rank over the timed region (per step): what the entropy stage cost, what the process burnt in all
+    # its threads, and whether the container's CPU quota throttled it
+    host = {"pool_threads": lib.ebcc_hip_host_threads(int(os.environ.get("EBCC_HIP_SLICES", "2"))) if hasattr(lib, "ebcc_hip_host_threads") else None,
+            "usable_cpus": int(hstats[0]), "quota_cpus": hstats[1] or None,
+            "zstd_core_s_per_step": round(hstats[2] / args.steps, 4), "zstd_wait_ms_per_step": round(hstats[3] / args.steps * 1e3, 2),
+            "zstd_MB_per_step": round(hstats[4] / args.steps / 1e6, 3),
+            "process_cpu_s_per_step": round(((ru1.user - ru0.user) + (ru1.system - ru0.system)) / args.steps, 4)}
+    if cg0["nr_throttled"] is not None and cg1["nr_throttled"] is not None:
+        host["cgroup"] = {"quota_cpus": cg1["quota_cpus"], "periods": cg1["nr_periods"] - cg0["nr_periods"],
+                          "throttled_periods": cg1["nr_throttled"] - cg0["nr_throttled"],
+                          "throttled_ms_per_step": round((cg1["throttled_usec"] - cg0["throttled_usec"]) / 1e3 / args.steps, 2),
+                          "cpu_s_per_step": None if cg0["usage_usec"] is None else round((cg1["usage_usec"] - cg0["usage_usec"]) / 1e6 / args.steps, 4)}
 
     # parity guard on the timed data: the error bound holds on every frame (size-independent property)
     max_err = float((out - frames).abs().amax())
     assert max_err <= MAX_ERR * 1.01 + 1e-3, max_err
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    hosts = [host]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hosts = [None] * world
+        dist.all_gather_object(hosts, host)
     elapsed = float(t.item())
 
     def run_batches(data, cfg_, reps=1):
@@ -350,13 +405,20 @@ def main():
             "config": {"workload": f"{n}-frame batch 721x1440 fp32 per GPU, base_cr=30 MAX_ERROR=0.5 (BASELINE configs[1])",
                        "frames_per_gpu": n, "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "encode_slices": slices, "host_zstd_threads_per_slice": lib.ebcc_hip_host_threads(slices),
-                       "host_cpus": len(os.sched_getaffinity(0))},
+                       "encode_slices": slices, "host_pool_threads": lib.ebcc_hip_host_threads(slices),
+                       "host_cpus_affinity": len(os.sched_getaffinity(0))},
             "encode_GBps": round(total_frames * FRAME_BYTES * args.steps / enc_t / 1e9, 4),
             "decode_GBps": round(total_frames * FRAME_BYTES * args.steps / dec_t / 1e9, 4),
             "compressed_bytes_per_frame": int(comp / n), "max_abs_error": round(max_err, 5),
             "kernels": kern, "roofline": roof,
         }
+        # the host side, per rank; and the step time the host alone would allow: every rank's zstd core-seconds over the CPUs
+        # the ranks share (the container's quota if there is one) - a run whose ms_per_step sits on it is bound by the host
+        cpus_shared = hosts[0]["quota_cpus"] or len(os.sched_getaffinity(0))
+        line["host"] = {"ranks": hosts,
+                        "zstd_core_s_per_step_all_ranks": round(sum(h["zstd_core_s_per_step"] for h in hosts), 4),
+                        "cpus_shared_by_ranks": cpus_shared,
+                        "projected_host_bound_ms_per_step": round(sum(h["zstd_core_s_per_step"] for h in hosts) / cpus_shared * 1e3, 2)}
         try:                                                    # HBM-bound kernels, measured alone (tools/gpu/hbm_table.sh): best and worst of the table
             hk = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_kernels.json")))
             # rows that are HBM measurements: at least 1 MB per frame to move by role, counter traffic within 2x of it either

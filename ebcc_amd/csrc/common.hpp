@@ -40,8 +40,14 @@ struct HipFailure : std::runtime_error {
     } catch (const std::exception &e_) { ::ebcc::set_error("%s", e_.what()); }
 
 void set_error(const char *fmt, ...);
+void clear_error();                 // this thread's last-error text
 // hipMalloc through one door: EBCC_HIP_FAIL_ALLOC=<n> (tests) makes the n-th allocation of the process fail
 hipError_t device_malloc(void **p, size_t bytes);
+
+// Host wait for a stream.  By default through an event created with hipEventBlockingSync: the waiting thread sleeps
+// instead of spinning (hipStreamSynchronize spins on a core for as long as the GPU works - two slice threads waiting are
+// two of the container's CPUs, taken from the zstd workers).  EBCC_HIP_SPIN_SYNC=1 restores hipStreamSynchronize.
+void wait_stream(hipStream_t s);
 
 constexpr int kWave = 64;             // CDNA wavefront
 constexpr int kResidualStages = 3;    // WAVELET_LEVELS, reference src/ebcc_codec.c:28

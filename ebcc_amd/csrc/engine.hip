@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string>
 #include <cstring>
+#include <vector>
 
 #include "../../include/ebcc_hip.h"
 #include "search.hpp"
@@ -25,6 +26,30 @@ void set_error(const char *fmt, ...)
     g_last_error = buf;
     std::fprintf(stderr, "ebcc-hip: %s\n", buf);
 }
+
+void wait_stream(hipStream_t s)
+{
+    static const bool spin = getenv("EBCC_HIP_SPIN_SYNC") && atoi(getenv("EBCC_HIP_SPIN_SYNC")) != 0;
+    if (spin) { EBCC_HIP_CHECK(hipStreamSynchronize(s)); return; }
+    // events come from a per-device free list (an event belongs to the device that was current when it was made; slice
+    // threads are short-lived, so nothing is kept per thread)
+    static std::mutex m;
+    static std::vector<hipEvent_t> spare[64];
+    int dev = 0;
+    EBCC_HIP_CHECK(hipGetDevice(&dev));
+    hipEvent_t e = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(m);
+        auto &v = spare[dev & 63];
+        if (!v.empty()) { e = v.back(); v.pop_back(); }
+    }
+    if (!e) EBCC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming));
+    struct Return { hipEvent_t e; int dev; ~Return() { std::lock_guard<std::mutex> lock(m); spare[dev & 63].push_back(e); } } back{e, dev};
+    EBCC_HIP_CHECK(hipEventRecord(e, s));
+    EBCC_HIP_CHECK(hipEventSynchronize(e));
+}
+
+void clear_error() { g_last_error.clear(); }
 
 hipError_t device_malloc(void **p, size_t bytes)
 {
@@ -84,11 +109,17 @@ size_t stage_layout(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t n)
         total += (len[f] + 15) & ~(size_t) 15;
     }
     if (total > ctx->stage_cap) {                                    // grow (rare: sized by the largest batch seen)
-        if (ctx->h_stage) EBCC_HIP_CHECK(hipHostFree(ctx->h_stage));
-        if (ctx->d_stage) EBCC_HIP_CHECK(hipFree(ctx->d_stage));
-        ctx->stage_cap = total + total / 2 + 4096;
-        EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_stage, ctx->stage_cap));
-        EBCC_HIP_CHECK(device_malloc((void **) &ctx->d_stage, ctx->stage_cap));
+        // the context stays cached after a failed call: it must never keep a freed pointer or a capacity it does not have
+        uint8_t *h_old = ctx->h_stage, *d_old = ctx->d_stage;
+        ctx->h_stage = nullptr; ctx->d_stage = nullptr; ctx->stage_cap = 0;
+        if (h_old) hipHostFree(h_old);
+        if (d_old) hipFree(d_old);
+        const size_t cap = total + total / 2 + 4096;
+        uint8_t *h_new = nullptr, *d_new = nullptr;
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &h_new, cap));
+        const hipError_t e = device_malloc((void **) &d_new, cap);
+        if (e != hipSuccess) { hipHostFree(h_new); EBCC_HIP_CHECK(e); }
+        ctx->h_stage = h_new; ctx->d_stage = d_new; ctx->stage_cap = cap;
     }
     return total;
 }
@@ -102,7 +133,7 @@ void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const 
     EBCC_HIP_CHECK(hipMemcpyAsync(ctx->d_pack, ctx->h_pack, 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_stage, dim3((unsigned) n, 4), dim3(256), 0, s, const_cast<uint8_t *>(src), stride, ctx->d_pack, ctx->d_stage, 1);
     EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_stage, ctx->d_stage, total, hipMemcpyDeviceToHost, s));
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
 }
 
 void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m) { stage_layout(ctx, len, off, m); }
@@ -124,7 +155,7 @@ void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first,
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n)
 {
     EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_fs, ctx->rb.fs, n * sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
-    EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    wait_stream(ctx->stream);
 }
 void push_frame_states(ebcc_hip_ctx *ctx, size_t n)
 {
@@ -229,6 +260,7 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     }
     EBCC_HIP_CHECK(hipSetDevice(device));
     ebcc_hip_ctx *ctx = new ebcc_hip_ctx();
+    try {                                                   // (a throw below must not leak the half-built engine)
     ctx->device = device;
     ctx->max_frames = max_frames;
     ctx->height = (int) height;
@@ -283,8 +315,12 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
         ebcc_hip_destroy(ctx);
         return nullptr;
     }
-    EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    wait_stream(ctx->stream);
     return ctx;
+    } catch (...) {
+        ebcc_hip_destroy(ctx);
+        throw;
+    }
     EBCC_API_CATCH(nullptr)
 }
 
@@ -380,7 +416,7 @@ static int collect_streams(ebcc_hip_ctx *ctx, size_t n, uint8_t **out_streams, s
         EBCC_HIP_CHECK(hipMemcpyAsync(out_streams[f], ctx->rb.stream + f * ctx->rb.stream_words, nb,
                                       hipMemcpyDeviceToHost, ctx->stream));
     }
-    EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    wait_stream(ctx->stream);
     return 0;
 }
 
@@ -434,7 +470,7 @@ int ebcc_hip_spiht_decode_prefix(ebcc_hip_ctx *ctx, size_t n_frames, const size_
     launch_reconstruct(ctx->rb, (int) n_frames, ctx->d_u64b, nullptr, s);
     launch_synthesis(ctx->rb, (int) n_frames, nullptr, s);
     launch_emit_image(d_images_out, ctx->rb, (int) n_frames, s);
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     return 0;
     EBCC_API_CATCH(1)
 }
@@ -483,7 +519,7 @@ int ebcc_hip_spiht_decode(ebcc_hip_ctx *ctx, const uint8_t *const *streams, cons
     launch_spiht_decode((const uint8_t *) ctx->rb.stream, slot, ctx->d_u64a, ctx->d_u64b, ctx->rb, (int) n_frames, nullptr, s);
     launch_synthesis(ctx->rb, (int) n_frames, nullptr, s);
     launch_emit_image(d_images_out, ctx->rb, (int) n_frames, s);
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     return 0;
     EBCC_API_CATCH(1)
 }

@@ -13,6 +13,8 @@
 #include <ctime>
 #include <sched.h>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <sys/mman.h>
 #include <sys/resource.h>
@@ -201,7 +203,10 @@ std::vector<int> device_list()
             char *end;
             long d = strtol(p, &end, 10);
             if (end == p) break;
-            if (d >= 0 && d < n && std::find(out.begin(), out.end(), (int) d) == out.end()) out.push_back((int) d);
+            // (a device named twice counts once - unless EBCC_HIP_DEVICES_KEEP_REPEATS=1, the tests' way to drive the
+            //  several-devices path of run_on_devices on a one-GPU box: the per-device lock then serialises the blocks)
+            static const bool keep = getenv("EBCC_HIP_DEVICES_KEEP_REPEATS") != nullptr;
+            if (d >= 0 && d < n && (keep || std::find(out.begin(), out.end(), (int) d) == out.end())) out.push_back((int) d);
             p = *end == ',' ? end + 1 : end;
         }
     } else if (e || !multi_process_job()) {
@@ -264,10 +269,14 @@ static void host_copy_parallel(void *dst, const void *src, size_t bytes)
 {
     const size_t nthreads = std::min<size_t>(8, std::max<size_t>(1, bytes >> 20));
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < nthreads; t++)
-        pool.emplace_back([=]() { const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
-                                  memcpy((char *) dst + lo, (const char *) src + lo, hi - lo); });
+    size_t started = 1;
+    try {
+        for (size_t t = 1; t < nthreads; t++, started++)
+            pool.emplace_back([=]() { const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
+                                      memcpy((char *) dst + lo, (const char *) src + lo, hi - lo); });
+    } catch (const std::exception &) {}                                 // (thread limit: this thread copies what is left)
     memcpy(dst, src, bytes / nthreads);
+    if (started < nthreads) { const size_t lo = bytes / nthreads * started; memcpy((char *) dst + lo, (const char *) src + lo, bytes - lo); }
     for (auto &t : pool) t.join();
 }
 static void copy_pageable(ebcc_hip_ctx *ctx, void *host, void *dev, size_t bytes, bool to_host)
@@ -283,7 +292,7 @@ static void copy_pageable(ebcc_hip_ctx *ctx, void *host, void *dev, size_t bytes
     if (to_host) {
         EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_bounce, dev, len(0), hipMemcpyDeviceToHost, s));
         for (size_t i = 0; i < chunks; i++) {
-            EBCC_HIP_CHECK(hipStreamSynchronize(s));                                       // chunk i has arrived
+            wait_stream(s);                                       // chunk i has arrived
             if (i + 1 < chunks)
                 EBCC_HIP_CHECK(hipMemcpyAsync(ctx->h_bounce + ((i + 1) & 1) * kBounceBytes, (char *) dev + (i + 1) * kBounceBytes, len(i + 1), hipMemcpyDeviceToHost, s));
             host_copy_parallel((char *) host + i * kBounceBytes, ctx->h_bounce + (i & 1) * kBounceBytes, len(i));
@@ -291,10 +300,10 @@ static void copy_pageable(ebcc_hip_ctx *ctx, void *host, void *dev, size_t bytes
     } else {
         for (size_t i = 0; i < chunks; i++) {
             host_copy_parallel(ctx->h_bounce + (i & 1) * kBounceBytes, (const char *) host + i * kBounceBytes, len(i));
-            if (i >= 1) EBCC_HIP_CHECK(hipStreamSynchronize(s));                           // (chunk i - 1 has left: its buffer is filled next)
+            if (i >= 1) wait_stream(s);                           // (chunk i - 1 has left: its buffer is filled next)
             EBCC_HIP_CHECK(hipMemcpyAsync((char *) dev + i * kBounceBytes, ctx->h_bounce + (i & 1) * kBounceBytes, len(i), hipMemcpyHostToDevice, s));
         }
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
     }
 }
 
@@ -388,29 +397,162 @@ hipStream_t second_stream(ebcc_hip_ctx *c)
     return c->stream2;
 }
 
-// Host threads of one slice of an encode call for the entropy stage (level-22 zstd of the residual streams is the
-// longest host step): EBCC_HOST_THREADS, else from the CPUs in the affinity mask.  Stand-alone process, measured on the
-// MI355X box (a 16-CPU container quota on a 256-thread host; tools/gpu/threads_sweep.sh): the work comes in short bursts
-// - 6 ms per frame, once per slice - that stay far below the quota on average, so more threads than the quota's CPU
-// count shorten the burst (32 per slice: 251 ms/step, 16: 262, 64: 255).  One rank of a multi-process job
-// (LOCAL_WORLD_SIZE ranks share the host): the process as a whole - all its slices - stays within its share
-// cpus / LOCAL_WORLD_SIZE, so eight ranks do not put a thousand compressing threads on one host.
+// CPUs this process may really use: the affinity mask, cut down to the container's CPU quota where one is set (cgroup v2
+// cpu.max "quota period", cgroup v1 cpu.cfs_quota_us / cpu.cfs_period_us).  The MI355X box of this project is a 16-CPU
+// quota on a 256-thread host: the mask says 256, and a pool sized from it bursts into the quota, gets the whole cgroup
+// throttled for the rest of the 100 ms period - the threads that steer the GPU included.
+static double cgroup_cpu_quota()
+{
+    auto read_two = [](const char *path, long long &a, long long &b) {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char tok[64];
+        bool ok = fscanf(f, "%63s %lld", tok, &b) == 2;
+        fclose(f);
+        if (!ok || !strcmp(tok, "max")) return false;
+        a = atoll(tok);
+        return a > 0 && b > 0;
+    };
+    auto read_one = [](const char *path, long long &v) {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        bool ok = fscanf(f, "%lld", &v) == 1;
+        fclose(f);
+        return ok;
+    };
+    if (const char *e = getenv("EBCC_HOST_CPU_QUOTA")) return std::max(0.0, strtod(e, nullptr));    // (containers that hide their cgroup; tests)
+    long long q = 0, per = 0;
+    if (read_two("/sys/fs/cgroup/cpu.max", q, per)) return (double) q / (double) per;
+    for (const char *dir : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+        char a[128], b[128];
+        snprintf(a, sizeof a, "%s/cpu.cfs_quota_us", dir);
+        snprintf(b, sizeof b, "%s/cpu.cfs_period_us", dir);
+        if (read_one(a, q) && read_one(b, per) && q > 0 && per > 0) return (double) q / (double) per;
+    }
+    return 0;                                                   // no quota
+}
+unsigned usable_cpus()
+{
+    static const unsigned cached = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned) CPU_COUNT(&set);
+        const double q = cgroup_cpu_quota();
+        if (q > 0) n = std::min(n, (unsigned) std::max(1.0, std::floor(q + 0.5)));
+        return std::max(1u, n);
+    }();
+    return cached;
+}
+// Host threads of one encode call for the entropy stage (level-22 zstd of the residual prefixes - the longest host
+// step, ~1.3 core-seconds per 256 frames): EBCC_HOST_THREADS, else the usable CPUs (above) divided by the ranks that
+// share the host (LOCAL_WORLD_SIZE), minus one per slice for the threads that steer the GPU - they must never wait
+// behind the compressors, and a pool larger than the quota only moves the wait into the kernel's throttling.  The pool
+// is per encode call and shared by its slices (encode_batch).
 unsigned entropy_threads_for(unsigned cpus, unsigned local_world, unsigned slices)
 {
-    if (local_world > 1) return std::max(1u, cpus / local_world / std::max(1u, slices));
-    return std::min(32u, std::max(4u, cpus));
+    const unsigned share = std::max(1u, cpus / std::max(1u, local_world));
+    const unsigned steer = std::min(slices, share > 4 ? 2u : 0u);
+    return std::max(1u, std::min(64u, share - steer));
 }
-std::atomic<unsigned> g_slices{1};          // slices of the encode call in progress (run_slices)
 unsigned entropy_threads(unsigned slices = 1)
 {
     if (const char *e = getenv("EBCC_HOST_THREADS")) return (unsigned) std::max(1L, strtol(e, nullptr, 10));
-    unsigned n = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned) CPU_COUNT(&set);
     unsigned lws = 1;
     if (const char *e = getenv("LOCAL_WORLD_SIZE")) lws = (unsigned) std::max(1, atoi(e));
-    return entropy_threads_for(n, lws, slices);
+    return entropy_threads_for(usable_cpus(), lws, slices);
 }
+
+// Host-side accounting of the entropy stage since the last reset (ebcc_hip_host_stats: bench.py prints it per rank so that
+// a multi-GPU run that is bound by the host's CPUs can be told from one that is bound by the GPUs).
+struct HostStats {
+    std::atomic<long long> zstd_core_us{0}, zstd_wait_us{0}, zstd_bytes{0}, batches{0};
+    void add(long long core_us, long long wait_us, long long bytes) { zstd_core_us += core_us; zstd_wait_us += wait_us; zstd_bytes += bytes; batches++; }
+    void reset() { zstd_core_us = 0; zstd_wait_us = 0; zstd_bytes = 0; batches = 0; }
+};
+HostStats &host_stats() { static HostStats h; return h; }
+
+// ------------------------------------------------------------------------------------------------
+// HostPool: the process-wide worker threads of the host-side stages (level-22 zstd of the residual prefixes, frame
+// parsing and zstd decompression of the decode).  Every slice of every call on every device feeds the same workers, so
+// the number of compressing threads is the budget above whatever the slicing - a pool per slice (round 2) doubled it
+// with two slices and would multiply it again with several devices in one process.  Workers run at nice 10: below the
+// threads that steer the GPU.  A job that throws, or a worker that cannot be started, fails the batch it belongs to -
+// nothing on a worker thread can take the process down.
+// ------------------------------------------------------------------------------------------------
+class HostPool {
+  public:
+    struct Batch {
+        std::function<void(size_t)> fn;
+        size_t n = 0;
+        std::atomic<size_t> next{0};
+        std::atomic<size_t> left{0};
+        std::atomic<bool> failed{false};
+        std::string error;                                      // first failure's text (under m)
+        std::mutex m;
+        std::condition_variable cv;
+        void fail(const char *what) { std::lock_guard<std::mutex> l(m); if (!failed.exchange(true)) error = what; }
+        // the calling thread helps until the indices are handed out, then waits for the stragglers
+        bool wait()
+        {
+            work();
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return left.load() == 0; });
+            return !failed.load();
+        }
+        void work()
+        {
+            for (size_t i = next++; i < n; i = next++) {
+                try { fn(i); } catch (const std::exception &e) { fail(e.what()); } catch (...) { fail("unknown exception on a host worker"); }
+                if (--left == 0) { std::lock_guard<std::mutex> l(m); cv.notify_all(); }
+            }
+        }
+    };
+    static HostPool &instance() { static HostPool *p = new HostPool(); return *p; }      // (never destroyed: workers may outlive main)
+    // n jobs fn(0 .. n - 1) on up to `width` workers; returns at once.  The caller keeps the batch alive until wait() returned.
+    std::shared_ptr<Batch> submit(size_t n, unsigned width, std::function<void(size_t)> fn)
+    {
+        auto b = std::make_shared<Batch>();
+        b->fn = std::move(fn); b->n = n; b->left = n;
+        if (n == 0) return b;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            grow(width);
+            queue_.push_back(b);
+        }
+        cv_.notify_all();
+        return b;
+    }
+    unsigned threads() { std::lock_guard<std::mutex> l(m_); return (unsigned) workers_; }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Batch>> queue_;
+    size_t workers_ = 0;
+    void grow(unsigned width)
+    {
+        while (workers_ < width) {
+            try { std::thread([this]() { run(); }).detach(); } catch (const std::exception &) { break; }   // (thread limit: the callers' wait() does the work)
+            workers_++;
+        }
+    }
+    void run()
+    {
+        setpriority(PRIO_PROCESS, (id_t) syscall(SYS_gettid), 10);
+        for (;;) {
+            std::shared_ptr<Batch> b;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] {
+                    while (!queue_.empty() && queue_.front()->next.load() >= queue_.front()->n) queue_.pop_front();
+                    return !queue_.empty();
+                });
+                b = queue_.front();
+            }
+            b->work();
+        }
+    }
+};
 
 // The base layer of a batch of chunks.  A chunk is one frame, or `tiles` frames stacked along the row axis that
 // the reference codes as ONE JPEG 2000 image with one tile per frame (src/ebcc_codec.c:105-180, n_tiles > 1).
@@ -446,7 +588,7 @@ struct Batch {
     {
         if (!on) on = s;
         EBCC_HIP_CHECK(hipMemcpyAsync(tjf, jb.jf, sizeof(J2kFrame) * nt, hipMemcpyDeviceToHost, on));
-        EBCC_HIP_CHECK(hipStreamSynchronize(on));
+        wait_stream(on);
         for (size_t c = 0; c < n; c++) {
             J2kFrame &o = jf[c];
             o.nbad = 0; o.err_sum = 0; o.overflow = 0; o.body_bytes = 0;
@@ -517,7 +659,7 @@ struct Batch {
                 at += part;
             }
         }
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
         const unsigned H = (unsigned) jb.geom.H;
         for (size_t c = 0; c < n; c++) {
             if (!active[c]) continue;
@@ -613,7 +755,7 @@ int search_rounds()
 }
 constexpr int kSearchAll = 0, kSearchStart = 1, kSearchFinish = 2;
 template <class Jobs>
-void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, int lane = 0, int part = kSearchAll)
+void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices, int lane = 0, int part = kSearchAll)
 {
     // lane 1: the search runs on the engine's second stream with its own state, counters and active mask, beside whatever
     // the first stream does (search #2 beside the residual layer).  part: enqueue the first batch of rounds only
@@ -626,7 +768,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, int lane = 0,
     hipStream_t s = lane ? second_stream(ctx) : b.s;
     J2kBuffers &jb = b.jb;
     const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
-    const bool speculate = lane == 0 && (forced >= 0 ? forced != 0 : g_slices.load() <= 1);   // (lane 1 runs on the stream the candidates would use)
+    const bool speculate = lane == 0 && (forced >= 0 ? forced != 0 : slices <= 1);   // (lane 1 runs on the stream the candidates would use)
     hipStream_t s2 = nullptr;
     auto advance = [&]() {
         launch_search_advance(d, jb.jf, d_active, (int) n, (int) b.tiles, k, (double) n_pix, d_counter, s,
@@ -691,7 +833,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, int lane = 0,
     for (;;) {
         EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
         EBCC_HIP_CHECK(hipMemcpyAsync(h_counter, d_counter, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
         bool done = true;
         for (size_t f = 0; f < n; f++) done &= h[f].rs[k].phase == 6;
         if (done) break;
@@ -714,10 +856,10 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, int lane = 0,
     b.fetch_jf(s);                                                        // (the host mirror of the per-frame scalars follows the device again)
 }
 template <class Jobs>
-void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
+void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices)
 {
     const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
-    if (host_loop) run_search(b, k, jobs, n_pix); else device_rate_search(b, k, jobs, n_pix);
+    if (host_loop) run_search(b, k, jobs, n_pix); else device_rate_search(b, k, jobs, n_pix, slices);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,7 +868,7 @@ void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix)
 // `n` chunks of `tiles` frames each (tiles == 1: the frame-per-chunk case); `rctx`: residual engine for the stacked
 // chunk image when tiles > 1.
 int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
-                 SliceGate *next = nullptr, size_t tiles = 1, ebcc_hip_ctx *rctx = nullptr)
+                 SliceGate *next = nullptr, size_t tiles = 1, ebcc_hip_ctx *rctx = nullptr, unsigned slices = 1)
 {
     struct Release { SliceGate *g; ~Release() { if (g) g->release(); } } release_on_exit{next};   // (error paths too)
     const EncodeEnv env;
@@ -761,7 +903,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
     launch_j2k_analysis(d_frames, jb, (int) nt, s);
     if (next) {                                   // the next slice may start: this one's first stage is queued
         const char *e = getenv("EBCC_HIP_SLICE_GATE");
-        if (e && atoi(e) == 1) { EBCC_HIP_CHECK(hipStreamSynchronize(s)); }
+        if (e && atoi(e) == 1) { wait_stream(s); }
         next->release(); release_on_exit.g = nullptr;
     }
     fetch_frame_states(ctx, nt);
@@ -825,7 +967,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         const bool want_pure = !pure_done && !env.no_fallback;
         for (size_t f = 0; f < n; f++)
             if (!jobs[f].const_field) jobs[f].rs[0].start(cfg->base_cr, jobs[f].q, q_target);
-        rate_search(b, 0, jobs, n_pix);
+        rate_search(b, 0, jobs, n_pix, slices);
         for (size_t f = 0; f < n; f++) {
             b.active[f] = jobs[f].const_field ? 0 : 1;
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
@@ -852,7 +994,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         } drain2{ctx, false};
         if (overlap2) {
             start_search2();
-            device_rate_search(b, 1, jobs, n_pix, 1, kSearchStart);
+            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart);
             drain2.armed = true;
         }
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
@@ -934,7 +1076,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                         launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                     }
                     EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
-                    EBCC_HIP_CHECK(hipStreamSynchronize(rs));
+                    wait_stream(rs);
                     bool done = true;
                     for (size_t f = 0; f < n; f++) done &= !h[f].trunc_active;
                     if (done) break;
@@ -1002,45 +1144,44 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         const uint8_t *const coeff_base = rc->h_stage;
         // one job per frame on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so
         // the host is never oversubscribed however many slices run
-        std::atomic<size_t> next_frame{0};
-        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0};    // (EBCC_HIP_PHASE_TIMING: core time, longest job, bytes)
+        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0};    // core time, longest job, bytes
         // longest first: level 22 takes ~1 ms per KB on one core and a batch has frames whose prefix is ten times the
         // average - started last, such a frame alone decides when the slice can go on
-        std::vector<size_t> zorder(n);
-        for (size_t f = 0; f < n; f++) zorder[f] = f;
+        std::vector<size_t> zorder;
+        for (size_t f = 0; f < n; f++) if (jobs[f].coeffs_size > 0) zorder.push_back(f);
         std::stable_sort(zorder.begin(), zorder.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
-        auto zworker = [&]() {
-            // below the threads that steer the GPU (this one, the other slices'): they must not wait for a core
-            setpriority(PRIO_PROCESS, (id_t) syscall(SYS_gettid), 10);
-            for (size_t i = next_frame++; i < n; i = next_frame++) {
-                const size_t f = zorder[i];
-                Job &j = jobs[f];
-                if (j.coeffs_size == 0) continue;
-                const auto z0 = std::chrono::steady_clock::now();
-                j.zbytes.resize(zstd().bound(j.coeffs_size));
-                size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
-                j.zbytes.resize(z);
-                if (pt.on) {
-                    const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
-                    zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
-                    long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
-                }
-            }
+        auto zbatch = HostPool::instance().submit(zorder.size(), entropy_threads(slices), [&](size_t i) {
+            const size_t f = zorder[i];
+            Job &j = jobs[f];
+            const auto z0 = std::chrono::steady_clock::now();
+            j.zbytes.resize(zstd().bound(j.coeffs_size));
+            const size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
+            if ((zstd().is_error && zstd().is_error(z)) || z > j.zbytes.size()) throw std::runtime_error("ZSTD_compress failed on a residual prefix");
+            j.zbytes.resize(z);
+            const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+            zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
+            long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
+        });
+        struct WaitOnExit { std::shared_ptr<HostPool::Batch> b; ~WaitOnExit() { if (b) b->wait(); } } wait_on_exit{zbatch};   // (error paths too: the jobs point into this frame)
+        bool zstd_ok = true;
+        auto zjoin = [&]() {
+            if (!wait_on_exit.b) return;
+            const auto w0 = std::chrono::steady_clock::now();
+            zstd_ok = zbatch->wait();
+            wait_on_exit.b.reset();
+            host_stats().add(zstd_us.load(), std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count(), zstd_bytes.load());
         };
-        std::vector<std::thread> zpool;
-        struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } join_on_exit{zpool};   // (error paths too)
-        for (size_t t = 0; t < std::min<size_t>(entropy_threads(g_slices.load()), n); t++) zpool.emplace_back(zworker);
-        auto zjoin = [&]() { for (auto &t : zpool) if (t.joinable()) t.join(); };
         pt.mark("zstd");
         // ---- pure base-layer fallback (:819-854)
         if (want_pure) {
             // The pure-base-layer search restarts from base_cr with the quantile of a re-encode at base_cr
             // (:829-833), i.e. of the first probe above (unless that consistency step is disabled), and re-uses
             // every probe search #1 made; it runs here, while host cores do the level-22 zstd.
-            if (overlap2) { device_rate_search(b, 1, jobs, n_pix, 1, kSearchFinish); drain2.armed = false; }
-            else { start_search2(); rate_search(b, 1, jobs, n_pix); }                         // :836
+            if (overlap2) { device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchFinish); drain2.armed = false; }
+            else { start_search2(); rate_search(b, 1, jobs, n_pix, slices); }                         // :836
             pt.mark("rate search 2");
             zjoin();
+            if (!zstd_ok) { log_fatal("entropy stage failed: %s", zbatch->error.c_str()); set_error("%s", zbatch->error.c_str()); return 1; }
             pt.mark("zstd: wait for the workers");
             if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms\n", zstd_us.load() / 1e3, zstd_bytes.load(), zstd_max_us.load() / 1e3);
             bool any_pure = false;
@@ -1066,6 +1207,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
         }
         zjoin();
+        if (!zstd_ok) { log_fatal("entropy stage failed: %s", zbatch->error.c_str()); set_error("%s", zbatch->error.c_str()); return 1; }
     }
 
     pt.mark("fallback search + tails");
@@ -1176,17 +1318,20 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     // the host side of a batch - frame headers, packet headers, zstd of the residual streams - is per frame and runs on a
     // few host threads (decode is one slice: nothing else hides it); a frame's failure fails the batch
     std::atomic<bool> failed{false}, resid{false};
+    // (the reason a frame was rejected is written on the worker's thread - set_error's text is per thread; the first one is
+    //  carried over to the calling thread, where ebcc_hip_last_error is read)
     auto for_frames = [&](auto body) {
-        const size_t nthreads = std::min<size_t>({(size_t) 16, (size_t) std::max(1u, (unsigned) entropy_threads(1)), (n + 7) / 8});
-        std::atomic<size_t> next_frame{0};
-        auto worker = [&]() {
-            for (size_t f = next_frame++; f < n && !failed.load(std::memory_order_relaxed); f = next_frame++)
-                if (!body(f)) failed = true;
-        };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
-        worker();
-        for (auto &t : pool) t.join();
+        const unsigned width = (unsigned) std::min<size_t>({(size_t) 16, (size_t) entropy_threads(1), (n + 7) / 8});
+        auto batch = HostPool::instance().submit(n, width, [&](size_t f) {
+            if (failed.load(std::memory_order_relaxed)) return;
+            clear_error();
+            if (!body(f)) {
+                failed = true;
+                const char *why = ebcc_hip_last_error();
+                throw std::runtime_error(why && *why ? why : "invalid encoded data");
+            }
+        });
+        if (!batch->wait()) { failed = true; set_error("%s", batch->error.c_str()); }
     };
     for_frames([&](size_t f) -> bool {
         const uint8_t *d = streams[f];
@@ -1277,9 +1422,9 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         if (ctx->h_fs[f].const_field) {
             std::vector<float> v(n_pix, ctx->h_fs[f].minv);
             EBCC_HIP_CHECK(hipMemcpyAsync(d_out + f * n_pix, v.data(), n_pix * sizeof(float), hipMemcpyHostToDevice, s));
-            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+            wait_stream(s);
         }
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     pt.mark("decode: kernels");
     return 0;
 }
@@ -1343,7 +1488,7 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
     push_frame_states(ctx, nt);
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
     launch_j2k_decode(jb, (int) nt, s);
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     if (any_resid) {
         push_frame_states(rc, n);
         const size_t slot = rc->rb.stream_words * 4;
@@ -1359,16 +1504,16 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
         launch_spiht_decode((const uint8_t *) rc->rb.stream, slot, rc->d_u64a, rc->d_u64b, rc->rb, (int) n, rc->d_active, rs);
         launch_synthesis_head(rc->rb, (int) n, rc->d_active, rs);
         launch_synthesis_tail_add(jb.DEC, rc->rb, (int) n, rc->d_active, rs);
-        EBCC_HIP_CHECK(hipStreamSynchronize(rs));
+        wait_stream(rs);
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (size_t c = 0; c < n; c++)
         if (rc->h_fs[c].const_field) {
             std::vector<float> v(n_pix, rc->h_fs[c].minv);
             EBCC_HIP_CHECK(hipMemcpyAsync(d_out + c * n_pix, v.data(), n_pix * sizeof(float), hipMemcpyHostToDevice, s));
-            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+            wait_stream(s);
         }
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     return 0;
 }
 
@@ -1492,10 +1637,9 @@ int run_on_devices(size_t n_chunks, Fn fn)
 
 // Slices of a batch: EBCC_HIP_SLICES (encode, 1 = off) / EBCC_HIP_DECODE_SLICES engines of max_frames / slices
 // frames each, created on first use.  Small batches stay on the context's own engine.  More than two slices only
-// pay when the HIP runtime has a hardware queue for each (GPU_MAX_HW_QUEUES, default 4, shared with the
+// pay when the HIP runtime has a hardware queue for each stream (GPU_MAX_HW_QUEUES, default 4, shared with the
 // application's streams; it is read when the runtime starts, so the application sets it): streams that share a
-// queue run one after the other.  Default for encode: 4 slices when the process runs with GPU_MAX_HW_QUEUES >= 8
-// (measured best on MI355X: the host-side zstd of one slice hides behind the GPU phases of the others), else 2.
+// queue run one after the other.  Default for encode: TWO slices (default_encode_slices below).
 // Decode runs as ONE slice since round 2: its launch is as long as the longest SPIHT stream of the batch whatever the
 // batch size, and the tier-1 decoder is bound by vector issue slots - two half batches side by side only shared them
 // (A/B on one box, tools/gpu/ab_dec.sh: 33 GB/s with one slice, 27 with two).
@@ -1532,8 +1676,7 @@ template <class Fn>
 static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env_name, size_t default_slices)
 {
     const size_t k = slice_engines(ctx, n_frames, env_name, default_slices);
-    g_slices = (unsigned) k;
-    if (k == 1) return fn(ctx, (size_t) 0, n_frames, (SliceGate *) nullptr);
+    if (k == 1) return fn(ctx, (size_t) 0, n_frames, (SliceGate *) nullptr, 1u);
     const size_t per = (n_frames + k - 1) / k;
     std::vector<int> rc(k, 0);
     std::vector<std::string> err(k);
@@ -1547,7 +1690,7 @@ static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env
             try {
                 EBCC_HIP_CHECK(hipSetDevice(ctx->device));
                 if (i > 0) gates[i - 1].wait();
-                rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i]);
+                rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i], (unsigned) k);
                 if (rc[i]) err[i] = ebcc_hip_last_error();
             } catch (const std::exception &e) {
                 rc[i] = 1; err[i] = e.what();
@@ -1570,8 +1713,8 @@ namespace {
 int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
 {
     const size_t n_pix = ctx->n_pix;
-    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
-        return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next);
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next, unsigned slices) {
+        return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next, 1, nullptr, slices);
     }, "EBCC_HIP_SLICES", default_encode_slices());
 }
 
@@ -1581,7 +1724,7 @@ int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames,
 int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out)
 {
     const size_t n_pix = ctx->n_pix;
-    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next) {
+    return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next, unsigned) {
         return decode_batch(c, streams + lo, sizes + lo, cnt, d_out + lo * n_pix, next);
     }, "EBCC_HIP_DECODE_SLICES", kDefaultDecodeSlices);
 }
@@ -1616,6 +1759,19 @@ void print_config(codec_config_t *c)
 }
 
 int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) std::max(1, slices)); }
+
+// out[0..5] = usable CPUs (affinity mask cut to the cgroup quota), CPU quota (0: none), zstd core-seconds, seconds the
+// slices waited for the zstd workers, bytes compressed, entropy batches - since the last call with reset != 0
+void ebcc_hip_host_stats(double *out, int reset)
+{
+    HostStats &h = host_stats();
+    if (out) {
+        out[0] = (double) usable_cpus(); out[1] = cgroup_cpu_quota();
+        out[2] = h.zstd_core_us.load() / 1e6; out[3] = h.zstd_wait_us.load() / 1e6;
+        out[4] = (double) h.zstd_bytes.load(); out[5] = (double) h.batches.load();
+    }
+    if (reset) h.reset();
+}
 
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
 {
@@ -1890,12 +2046,14 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
                 const uintptr_t a = ((uintptr_t) p + ((size_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), e = ((uintptr_t) p + bytes) & ~(((uintptr_t) 2 << 20) - 1);
                 if (e > a) madvise((void *) a, e - a, MADV_HUGEPAGE);
             }
-            for (size_t t = 0; t < nthreads; t++)
-                pool.emplace_back([=]() {
-                    volatile char *c = (volatile char *) p;
-                    const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
-                    for (size_t i = lo; i < hi; i += 4096) c[i] = 0;
-                });
+            try {
+                for (size_t t = 0; t < nthreads; t++)
+                    pool.emplace_back([=]() {
+                        volatile char *c = (volatile char *) p;
+                        const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
+                        for (size_t i = lo; i < hi; i += 4096) c[i] = 0;
+                    });
+            } catch (const std::exception &) {}                         // (no thread to be had: the download faults the pages in itself)
         }
         std::mutex m;                                                   // (one device thread per device may come here)
         void join() { std::lock_guard<std::mutex> g(m); for (auto &t : pool) if (t.joinable()) t.join(); }
@@ -1933,7 +2091,7 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
             return 1;
         }
     });
-    if (rcode) { free(o); return 0; }
+    if (rcode) { prefault.join(); free(o); return 0; }         // (the page-touching threads write into `o` until they are joined)
     if (!in_place)
         for (size_t cl = 0; cl < nchunks; cl++) box.scatter(chunks.data() + cl * csize, cl, o);          // :353-370
     *out_buffer = o;

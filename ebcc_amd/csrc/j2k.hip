@@ -101,7 +101,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_table, sizeof(int) * 4 * total));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->rate_path_n, 0, sizeof(int) * F, s));
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     return true;
 }
 
@@ -382,10 +382,10 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx
     launch_j2k_analysis(d_frames, jb, n, s);
     std::vector<J2kFrame> jf(n_frames);
     EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     if (j2k_tier1_retry(jb, n, jf.data(), s)) {
         EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
     }
     for (size_t f = 0; f < n_frames; f++) { jf[f].cr = cr[f]; jf[f].target = 0; }
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n_frames, hipMemcpyHostToDevice, s));
@@ -401,7 +401,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_encode(ebcc_hip_ctx *ctx
         EBCC_HIP_CHECK(hipMemcpyAsync(out_streams[f], jb.stream + f * jb.stream_cap, out_sizes[f], hipMemcpyDeviceToHost, s));
         if (minmax) { minmax[2 * f] = ctx->h_fs[f].minv; minmax[2 * f + 1] = ctx->h_fs[f].maxv; }
     }
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     return 0;
     EBCC_API_CATCH(1)
 }
@@ -419,13 +419,13 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_emulated_decode(ebcc_hip
     hipStream_t s = ctx->stream;
     std::vector<J2kFrame> jf(n_frames);
     EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     for (size_t f = 0; f < n_frames; f++) jf[f].target = target[f];
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.jf, jf.data(), sizeof(J2kFrame) * n_frames, hipMemcpyHostToDevice, s));
     launch_j2k_probe_decode(d_frames, jb, (int) n_frames, nullptr, s);
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n_frames * ctx->n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
     EBCC_HIP_CHECK(hipMemcpyAsync(jf.data(), jb.jf, sizeof(J2kFrame) * n_frames, hipMemcpyDeviceToHost, s));
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     for (size_t f = 0; f < n_frames; f++) { nbad[f] = jf[f].nbad; err_sum[f] = jf[f].err_sum; }
     return 0;
     EBCC_API_CATCH(1)
@@ -455,7 +455,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
     launch_j2k_decode(jb, (int) n_frames, s);
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n_frames * ctx->n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
-    EBCC_HIP_CHECK(hipStreamSynchronize(s));
+    wait_stream(s);
     return 0;
     EBCC_API_CATCH(1)
 }

@@ -1380,7 +1380,7 @@ static const short *nmsedec_luts(hipStream_t s)
         }
         EBCC_HIP_CHECK(device_malloc((void **) &g_luts, sizeof h));
         EBCC_HIP_CHECK(hipMemcpyAsync(g_luts, h, sizeof h, hipMemcpyHostToDevice, s));
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
     }
     return g_luts;
 }
@@ -1422,7 +1422,7 @@ void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool si
         if (getenv("EBCC_HIP_T1_STATS")) {                               // diagnostics: rows of 16 decisions per code-block (a wave of the MQ pass walks its longest lane's)
             std::vector<uint32_t> tot((size_t) total);
             EBCC_HIP_CHECK(hipMemcpyAsync(tot.data(), jb.lanerows, sizeof(uint32_t) * (size_t) total, hipMemcpyDeviceToHost, s));
-            EBCC_HIP_CHECK(hipStreamSynchronize(s));
+            wait_stream(s);
             uint32_t mx = 0; double sum = 0, wsum = 0;
             for (size_t g0 = 0; g0 < (size_t) total; g0 += 64) {
                 uint32_t wm = 0;

@@ -910,7 +910,7 @@ static const int *step_table(hipStream_t s)
         }
         EBCC_HIP_CHECK(device_malloc((void **) &g_step_table, sizeof h));
         EBCC_HIP_CHECK(hipMemcpyAsync(g_step_table, h, sizeof h, hipMemcpyHostToDevice, s));
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
     }
     return g_step_table;
 }

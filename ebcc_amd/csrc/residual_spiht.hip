@@ -886,7 +886,7 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
     timing_end("spiht_decode", s);
     if (prof) {
         unsigned long long v[10];
-        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        wait_stream(s);
         EBCC_HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_spiht_prof), sizeof v));
         fprintf(stderr, "spiht_decode profile (%d frames): LIP %.1f Mcycles %llu entries | LIS %.1f Mcycles %llu entries | refinement %.1f Mcycles %llu bits | %llu stream bits, longest %llu | slowest frame: %llu cycle-counter ticks in %.1f us (100 MHz clock)\n",
                 n_frames, v[0] / 1e6, v[1], v[2] / 1e6, v[3], v[4] / 1e6, v[5], v[6], v[7], v[8], v[9] / 100.0);

@@ -64,8 +64,9 @@ def encode_stack_sharded(frames, config, encode_fn, group=None):
     return assemble_ebck((n, h, w), (1, h, w), streams)
 
 
-def host_threads_per_rank(lib, slices=4):
-    """Compressing (zstd) host threads this rank will run per encode call: the library divides the CPUs the process may use
-    by LOCAL_WORLD_SIZE (set by torchrun) so that the ranks of a node share its cores - ebcc_hip_host_threads()."""
+def host_threads_per_rank(lib, slices=2):
+    """Compressing (zstd) host threads of this rank: ONE pool per process, shared by all slices of all calls.  The library
+    sizes it from the CPUs the process may really use (affinity mask cut down to the cgroup CPU quota) divided by
+    LOCAL_WORLD_SIZE (set by torchrun), so that the ranks of a node share its cores - ebcc_hip_host_threads()."""
     lib.ebcc_hip_host_threads.restype = __import__("ctypes").c_int
-    return int(lib.ebcc_hip_host_threads(int(slices))) * int(slices)
+    return int(lib.ebcc_hip_host_threads(int(slices)))

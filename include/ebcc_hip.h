@@ -91,8 +91,7 @@ int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t 
  * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
  * one frame / ebcc_encode_chunking with chunk_dims {1,H,W} produce).  Streams are malloc'd (free_buffer).
  * Return 0 = ok, 1 = error, 2 = NaN/Inf in the input; on failure entries of out_streams that are not NULL
- * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default 4 when the process has
- * GPU_MAX_HW_QUEUES >= 8, else 2), each on its own engine, stream and host thread; results do not depend on the
+ * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default 2), each on its own engine, stream and host thread; results do not depend on the
  * slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
  * n_frames (part of setting a context up, like ebcc_hip_create).  Returns 0. */
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
@@ -101,10 +100,15 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                            float *d_frames_out);
 
-/* Host threads one slice of an encode call uses for the zstd stage when the call runs as `slices` concurrent slices:
- * EBCC_HOST_THREADS, else from the CPUs the process may run on - divided by LOCAL_WORLD_SIZE and the slices when the
- * process is one rank of a multi-process job, so that the ranks of a node share its cores. */
+/* Worker threads of the process-wide host pool that runs the entropy stage (level-22 zstd of the residual prefixes) of
+ * every slice of every call: EBCC_HOST_THREADS, else the CPUs the process may really use - its affinity mask cut down to
+ * the container's CPU quota (cgroup cpu.max) - divided by LOCAL_WORLD_SIZE when the process is one rank of a multi-process
+ * job, minus one per slice for the threads that steer the GPU. */
 int ebcc_hip_host_threads(int slices);
+/* Host-side accounting since the last reset: out[0] usable CPUs (affinity and quota), out[1] CPU quota of the container in
+ * CPUs (0: none), out[2] core-seconds spent in zstd, out[3] seconds the slices waited for the zstd workers, out[4] bytes
+ * compressed, out[5] entropy batches.  bench.py prints them per rank (a run bound by the host's CPUs shows here). */
+void ebcc_hip_host_stats(double *out, int reset);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).  Names: "t1_encode",
  * "t1_probe_decode", "t1_decode", "rate_alloc", "j2k_dwt_fwd", "spiht_encode".  Process-wide switch. */

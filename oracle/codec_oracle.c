@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define WAVELET_LEVELS 3                       /* ebcc_codec.c:28 */
 #define DIM_MIN 32                             /* ebcc_codec.h:16 */
@@ -311,6 +312,15 @@ after_search:
                 cr = cfg->base_cr;
             }
             rate_search(&S, cr, 1.0);                                          /* :836 */
+            if (getenv("ORC_DUMP_DIR") && coeffs_size > 0) {                   /* study hook (tools/zstd_bound_study.py): the inputs of the :838 comparison */
+                char path[512];
+                snprintf(path, sizeof path, "%s/dump_%d_%zu.bin", getenv("ORC_DUMP_DIR"), (int) getpid(), (size_t) g_trace.n_j2k_encodes);
+                FILE *fp = fopen(path, "wb");
+                if (fp) {
+                    uint64_t hdr[4] = { coeffs_size, zlen, tail_len, S.cs_len };
+                    fwrite(hdr, 8, 4, fp); fwrite(coeffs, 1, coeffs_size, fp); fclose(fp);
+                }
+            }
             if (S.cs_len < zlen + tail_len || need_pure) {
                 mean_err = mean_error(data, S.decoded, NULL, n);               /* :843 */
                 zlen = 0; coeffs_size = 0;

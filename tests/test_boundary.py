@@ -169,18 +169,35 @@ def test_codestream_parser_rejects_malformed_streams():
 
 
 def test_host_thread_budget_per_rank():
-    """One rank of a multi-process job keeps its compressing threads within cpus / LOCAL_WORLD_SIZE (all slices together)."""
+    """The process-wide pool of compressing threads: the CPUs the process may really use (affinity mask cut to the cgroup
+    quota), divided by LOCAL_WORLD_SIZE, minus the threads that steer the GPU."""
     import sys
     if not os.path.exists(L.PRODUCT_SO):
         pytest.skip("library not built")
     child = ("import ctypes, os; lib = ctypes.CDLL(%r); lib.ebcc_hip_host_threads.restype = ctypes.c_int; "
-             "print(lib.ebcc_hip_host_threads(1), lib.ebcc_hip_host_threads(4), len(os.sched_getaffinity(0)))" % L.PRODUCT_SO)
-    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "EBCC_HOST_THREADS")}
-    one, four, cpus = map(int, subprocess.check_output([sys.executable, "-c", child], env=env).split())
-    assert one == four == min(32, max(4, cpus))                                   # stand-alone: the measured burst setting
+             "s = (ctypes.c_double * 6)(); lib.ebcc_hip_host_stats(s, 0); "
+             "print(lib.ebcc_hip_host_threads(1), lib.ebcc_hip_host_threads(4), len(os.sched_getaffinity(0)), int(s[0]), s[1])" % L.PRODUCT_SO)
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "EBCC_HOST_THREADS", "EBCC_HOST_CPU_QUOTA")}
+
+    def run():
+        a = subprocess.check_output([sys.executable, "-c", child], env=env).split()
+        return int(a[0]), int(a[1]), int(a[2]), int(a[3]), float(a[4])
+
+    env["EBCC_HOST_CPU_QUOTA"] = "0"                                              # no quota: the affinity mask counts
+    one, four, cpus, usable, quota = run()
+    assert usable == cpus and quota == 0
+    assert one == (cpus - 1 if cpus > 4 else cpus) and four == (cpus - 2 if cpus > 4 else cpus)
+    env["EBCC_HOST_CPU_QUOTA"] = "16"                                             # the MI355X box: 16-CPU quota on a 256-thread host
+    one, four, cpus, usable, quota = run()
+    assert usable == min(cpus, 16) and quota == 16.0
+    assert four == (usable - 2 if usable > 4 else usable)
+    env["EBCC_HOST_CPU_QUOTA"] = "2.5"
+    one, four, cpus, usable, quota = run()
+    assert usable == min(cpus, 3) and one == four == usable                       # (small shares: nothing set aside)
+    env["EBCC_HOST_CPU_QUOTA"] = "0"
     env["LOCAL_WORLD_SIZE"] = "8"
-    one, four, cpus = map(int, subprocess.check_output([sys.executable, "-c", child], env=env).split())
+    one, four, cpus, usable, quota = run()
     share = max(1, cpus // 8)
-    assert one == share and 1 <= four and 4 * four <= max(4, share)
+    assert 1 <= one <= share and 1 <= four <= share
     env["EBCC_HOST_THREADS"] = "3"
-    assert int(subprocess.check_output([sys.executable, "-c", child], env=env).split()[0]) == 3
+    assert run()[0] == 3

@@ -44,7 +44,7 @@ def _worker(rank, world, port, n_frames, q):
         if os.path.exists(L.PRODUCT_SO):
             os.environ["LOCAL_WORLD_SIZE"] = "8"
             os.environ.pop("EBCC_HOST_THREADS", None)
-            budget = (sharding.host_threads_per_rank(ctypes.CDLL(L.PRODUCT_SO), 4), len(os.sched_getaffinity(0)))
+            budget = (sharding.host_threads_per_rank(ctypes.CDLL(L.PRODUCT_SO), 2), len(os.sched_getaffinity(0)))
         q.put((out, budget))
     dist.barrier()
     dist.destroy_process_group()
@@ -63,7 +63,7 @@ def test_two_rank_sharded_container_equals_serial(n_frames):
     got, budget = q.get(timeout=120)
     if budget is not None:
         threads, cpus = budget
-        assert 4 <= threads <= max(4, cpus // 8), budget          # (at least one thread per slice)
+        assert 1 <= threads <= max(1, cpus // 8), budget          # (one pool per process, within the rank's share)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -206,7 +206,7 @@ def main():
 
     lib.ebcc_hip_host_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     lib.ebcc_hip_host_stats.restype = None
-    hstats = (ctypes.c_double * 6)()
+    hstats = (ctypes.c_double * 8)()
     for _ in range(args.warmup):
         step()
     lib.ebcc_hip_timing_enable(ctx, 1)
@@ -233,6 +233,7 @@ def main():
             "usable_cpus": int(hstats[0]), "quota_cpus": hstats[1] or None,
             "zstd_core_s_per_step": round(hstats[2] / args.steps, 4), "zstd_wait_ms_per_step": round(hstats[3] / args.steps * 1e3, 2),
             "zstd_MB_per_step": round(hstats[4] / args.steps / 1e6, 3),
+            "prefix_MB_per_step_decided_without_zstd": round(hstats[6] / args.steps / 1e6, 3),
             "process_cpu_s_per_step": round(((ru1.user - ru0.user) + (ru1.system - ru0.system)) / args.steps, 4)}
     if cg0["nr_throttled"] is not None and cg1["nr_throttled"] is not None:
         host["cgroup"] = {"quota_cpus": cg1["quota_cpus"], "periods": cg1["nr_periods"] - cg0["nr_periods"],

@@ -75,6 +75,7 @@ struct Zstd {
     size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
     size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
     unsigned (*is_error)(size_t) = nullptr;
+    unsigned (*version)(void) = nullptr;
     bool ok = false;
     Zstd()
     {
@@ -86,6 +87,7 @@ struct Zstd {
         compress = (size_t(*)(void *, size_t, const void *, size_t, int)) dlsym(h, "ZSTD_compress");
         decompress = (size_t(*)(void *, size_t, const void *, size_t)) dlsym(h, "ZSTD_decompress");
         is_error = (unsigned (*)(size_t)) dlsym(h, "ZSTD_isError");
+        version = (unsigned (*)(void)) dlsym(h, "ZSTD_versionNumber");
         ok = bound && compress && decompress;
     }
 };
@@ -93,6 +95,58 @@ Zstd &zstd()
 {
     static Zstd z;
     return z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A lower bound on the size of the zstd frame ZSTD_compress writes for [src, src + n), at any level.
+//
+// The reference compresses the kept SPIHT prefix at level 22 (:813-817) and then compares its size z with the pure
+// base-layer alternative (:838, len2 < z + len1).  Whenever a bound z >= F already gives len2 < F + len1 the comparison is
+// decided without z, and the (discarded) compression with it.  The bound, from the format alone (RFC 8878):
+//   * a frame is >= 9 bytes of magic, frame header and one block header around its blocks;
+//   * a block regenerates its bytes from literals and matches; a match copies >= 3 bytes (Match_Length code 0 = 3) that
+//     occurred EARLIER in the regenerated data (offsets are positive; no dictionary), so a byte at position i can only be
+//     part of a match if one of the three-byte windows [q, q + 3), q in {i - 2, i - 1, i}, repeats a three-byte string that
+//     starts before q.  All other positions ("uncoverable") are literals of their block in every valid frame;
+//   * the literals of a block are stored raw (8 bits each), as one repeated byte (only if they are all equal) or under
+//     one prefix code per block (Huffman, at most 11 bits - still a prefix code; a first block cannot reuse a table), so
+//     they cost at least their empirical entropy m log2 m - sum_s c_s log2 c_s, and that function only grows when further
+//     literals join the multiset: the uncoverable positions alone bound it from below;
+//   * libzstd before 1.5 cuts the input into blocks of min(128 KB, window) bytes and nothing finer (no block splitter,
+//     no target block size unless asked for): inputs of at most 128 KB are ONE block, which is the case used here -
+//     zstd_floor_usable() checks the library's version, tests/test_zstd_floor.py checks the single block and the bound
+//     itself against the library on the fixtures and on random material.
+// Cost: one pass with a 2^24-bit table of the three-byte strings seen, a few microseconds per KB.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kZstdFloorMaxBytes = (size_t) 128 << 10;
+bool zstd_floor_usable()
+{
+    return zstd().ok && zstd().version && zstd().version() < 10500;
+}
+size_t zstd_size_lower_bound(const uint8_t *src, size_t n)
+{
+    if (n < 8 || n > kZstdFloorMaxBytes) return 0;
+    thread_local std::vector<uint64_t> seen;                             // one bit per three-byte string
+    thread_local std::vector<uint8_t> cov;
+    if (seen.empty()) seen.assign((size_t) 1 << 18, 0);
+    cov.assign(n, 0);
+    auto tri = [&](size_t q) { return ((uint32_t) src[q] << 16) | ((uint32_t) src[q + 1] << 8) | (uint32_t) src[q + 2]; };
+    for (size_t q = 0; q + 3 <= n; q++) {
+        const uint32_t t = tri(q);
+        uint64_t &w = seen[t >> 6];
+        const uint64_t bit = 1ull << (t & 63);
+        if (w & bit) { cov[q] = cov[q + 1] = cov[q + 2] = 1; } else w |= bit;
+    }
+    for (size_t q = 0; q + 3 <= n; q++) { const uint32_t t = tri(q); seen[t >> 6] = 0; }     // (leave the table clean for the next call)
+    size_t cnt[256] = {0}, m = 0;
+    for (size_t i = 0; i < n; i++) if (!cov[i]) { cnt[src[i]]++; m++; }
+    if (m == 0) return 9;
+    double bits = (double) m * std::log2((double) m);
+    for (size_t c : cnt) if (c) bits -= (double) c * std::log2((double) c);
+    if (!(bits > 0)) return 9;
+    // (a byte less than the arithmetic gives: the logarithms are rounded)
+    const double bytes = std::floor(bits / 8.0) - 1.0;
+    return 9 + (bytes > 0 ? (size_t) bytes : 0);
 }
 
 // ================================================================================================
@@ -465,9 +519,9 @@ unsigned entropy_threads(unsigned slices = 1)
 // Host-side accounting of the entropy stage since the last reset (ebcc_hip_host_stats: bench.py prints it per rank so that
 // a multi-GPU run that is bound by the host's CPUs can be told from one that is bound by the GPUs).
 struct HostStats {
-    std::atomic<long long> zstd_core_us{0}, zstd_wait_us{0}, zstd_bytes{0}, batches{0};
+    std::atomic<long long> zstd_core_us{0}, zstd_wait_us{0}, zstd_bytes{0}, batches{0}, skipped_bytes{0};
     void add(long long core_us, long long wait_us, long long bytes) { zstd_core_us += core_us; zstd_wait_us += wait_us; zstd_bytes += bytes; batches++; }
-    void reset() { zstd_core_us = 0; zstd_wait_us = 0; zstd_bytes = 0; batches = 0; }
+    void reset() { zstd_core_us = 0; zstd_wait_us = 0; zstd_bytes = 0; batches = 0; skipped_bytes = 0; }
 };
 HostStats &host_stats() { static HostStats h; return h; }
 
@@ -770,9 +824,14 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
     const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
     const bool speculate = lane == 0 && (forced >= 0 ? forced != 0 : slices <= 1);   // (lane 1 runs on the stream the candidates would use)
     hipStream_t s2 = nullptr;
+    // probes that only steer the search stop counting once they are certainly infeasible (search.hpp); EBCC_HIP_EXACT_PROBES=1
+    // and TRACE logging (which prints every probe's count) keep every probe exact
+    double jobs_qt0 = 0.0;                                               // the error-bounded search's quantile target (0: it never ran)
+    for (size_t f = 0; f < n; f++) if (!jobs[f].const_field) { jobs_qt0 = jobs[f].rs[0].qt; break; }
+    const double limit_qt = getenv("EBCC_HIP_EXACT_PROBES") || g_log_level <= 0 ? 0.0 : std::min(jobs_qt0, 1.0);
     auto advance = [&]() {
         launch_search_advance(d, jb.jf, d_active, (int) n, (int) b.tiles, k, (double) n_pix, d_counter, s,
-                              speculate ? jb.cand_cr : nullptr, speculate ? jb.cand_sel : nullptr);
+                              speculate ? jb.cand_cr : nullptr, speculate ? jb.cand_sel : nullptr, limit_qt);
         if (speculate) launch_j2k_rate_publish(jb, (int) b.nt, s);
     };
     auto enqueue_rounds = [&](int rounds) {
@@ -974,12 +1033,6 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         }
         pt.mark("rate search 1");
         b.collect_tails(jobs);                                                                // base layer of search #1
-        // ---- the pure base-layer search (:819-836) depends on nothing the residual layer produces.  EBCC_HIP_SEARCH2_OVERLAP=1
-        //      queues its rounds on the engine's second stream now (own state, counters and mask: device_rate_search lane 1),
-        //      beside the residual layer and the truncation search, and takes it up again where the reference runs it
-        //      (below).  Not the default: in the reference's place the search runs while host cores do the level-22 zstd of
-        //      the residual streams - the longer of the two - so moving it earlier only makes the residual phase share the
-        //      GPU (two slices, alternating runs: encode 8.43 GB/s overlapped, 8.66 in place).
         auto start_search2 = [&]() {
             for (size_t f = 0; f < n; f++) {
                 if (jobs[f].const_field) continue;
@@ -987,16 +1040,6 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);                 // :829-833 == the first probe
             }
         };
-        const bool overlap2 = want_pure && tiles == 1 && rc == ctx && !getenv("EBCC_HIP_HOST_SEARCH") && getenv("EBCC_HIP_SEARCH2_OVERLAP");
-        struct DrainSecond {               // an error return between here and the take-up must not leave rounds in flight
-            ebcc_hip_ctx *c; bool armed;
-            ~DrainSecond() { if (armed && c->stream2) hipStreamSynchronize(c->stream2); }
-        } drain2{ctx, false};
-        if (overlap2) {
-            start_search2();
-            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart);
-            drain2.armed = true;
-        }
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
         fetch_frame_states(rc, n);
         bool any_resid = false;
@@ -1021,6 +1064,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 unsigned long long bits0 = (unsigned long long) jobs[f].len1 * 8 + 128;       // trunc_bits + 128
                 rc->h_u64a[f] = bits0;
                 rc->h_fs[f].budget = bits0 - 128;
+                rc->h_fs[f].exit_above = 0.0f;                                               // (the host's own probes are exact)
             }
             push_frame_states(rc, n);
             EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64a, rc->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
@@ -1128,9 +1172,13 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             }
         }
         pt.mark("residual layer + truncation");
-        // ---- entropy stage of the kept SPIHT prefix on host cores (:811-817): level-22 zstd is by far the
-        //      longest host step, so the frames are compressed by a small thread pool while the GPU runs
-        //      the fallback search; the results are only needed for the size comparison at :838
+        // ---- entropy stage of the kept SPIHT prefix on host cores (:811-817) and the pure base-layer fallback (:819-854).
+        //      Level-22 zstd is by far the longest host step (~160 ns per byte on one core: 1.3 core-seconds per 256 frames
+        //      of the bench workload on a box whose container has 16 CPUs), and the reference throws most of it away: the
+        //      compressed size z is compared with what the pure base-layer search gives (:838: len2 < z + len1), and for
+        //      ~95 % of ERA5-like frames the base layer alone wins.  So z is only worked out where it can matter: a frame
+        //      whose z is PROVABLY above len2 - len1 (zstd_size_lower_bound: the literals no match can cover cost at least
+        //      their entropy) takes the pure base layer without being compressed - the same decision, bytes unchanged.
         if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
         // the kept SPIHT prefixes of the batch in one packed download; the workers read them where they land (the staging
         // buffer of the residual engine is not touched again before they are done)
@@ -1142,56 +1190,114 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         }
         stage_download(rc, (const uint8_t *) rc->rb.stream, rc->rb.stream_words * sizeof(uint32_t), coeff_len.data(), coeff_off.data(), n, rs);
         const uint8_t *const coeff_base = rc->h_stage;
-        // one job per frame on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so
-        // the host is never oversubscribed however many slices run
-        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0};    // core time, longest job, bytes
-        // longest first: level 22 takes ~1 ms per KB on one core and a batch has frames whose prefix is ten times the
-        // average - started last, such a frame alone decides when the slice can go on
-        std::vector<size_t> zorder;
-        for (size_t f = 0; f < n; f++) if (jobs[f].coeffs_size > 0) zorder.push_back(f);
-        std::stable_sort(zorder.begin(), zorder.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
-        auto zbatch = HostPool::instance().submit(zorder.size(), entropy_threads(slices), [&](size_t i) {
-            const size_t f = zorder[i];
-            Job &j = jobs[f];
-            const auto z0 = std::chrono::steady_clock::now();
-            j.zbytes.resize(zstd().bound(j.coeffs_size));
-            const size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
-            if ((zstd().is_error && zstd().is_error(z)) || z > j.zbytes.size()) throw std::runtime_error("ZSTD_compress failed on a residual prefix");
-            j.zbytes.resize(z);
-            const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
-            zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
-            long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
-        });
-        struct WaitOnExit { std::shared_ptr<HostPool::Batch> b; ~WaitOnExit() { if (b) b->wait(); } } wait_on_exit{zbatch};   // (error paths too: the jobs point into this frame)
-        bool zstd_ok = true;
-        auto zjoin = [&]() {
-            if (!wait_on_exit.b) return;
-            const auto w0 = std::chrono::steady_clock::now();
-            zstd_ok = zbatch->wait();
-            wait_on_exit.b.reset();
-            host_stats().add(zstd_us.load(), std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count(), zstd_bytes.load());
+        // jobs on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so the host is never
+        // oversubscribed however many slices run
+        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0}, bound_us{0};    // core time, longest job, bytes
+        enum : uint8_t { kZNone = 0, kZQueued = 1, kZSkipped = 2 };
+        std::vector<uint8_t> zstate(n, kZNone);
+        std::vector<size_t> zfloor(n, 0);                               // lower bound of z (0: none)
+        std::vector<std::shared_ptr<HostPool::Batch>> zbatches;
+        struct WaitOnExit { std::vector<std::shared_ptr<HostPool::Batch>> &v; ~WaitOnExit() { for (auto &b : v) if (b) b->wait(); } } wait_on_exit{zbatches};   // (error paths too: the jobs point into this frame)
+        // level-22 zstd of the frames in `list`, longest first: level 22 takes ~0.16 ms per KB on one core and a batch has
+        // frames whose prefix is ten times the average - started last, such a frame alone decides when the slice can go on
+        auto submit_zstd = [&](std::vector<size_t> list) {
+            std::stable_sort(list.begin(), list.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
+            for (size_t f : list) zstate[f] = kZQueued;
+            auto order = std::make_shared<std::vector<size_t>>(std::move(list));
+            zbatches.push_back(HostPool::instance().submit(order->size(), entropy_threads(slices), [&, order](size_t i) {
+                const size_t f = (*order)[i];
+                Job &j = jobs[f];
+                const auto z0 = std::chrono::steady_clock::now();
+                j.zbytes.resize(zstd().bound(j.coeffs_size));
+                const size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
+                if ((zstd().is_error && zstd().is_error(z)) || z > j.zbytes.size()) throw std::runtime_error("ZSTD_compress failed on a residual prefix");
+                j.zbytes.resize(z);
+                const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+                zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
+                long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
+            }));
         };
-        pt.mark("zstd");
-        // ---- pure base-layer fallback (:819-854)
+        long long wait_us = 0;
+        auto zjoin = [&]() -> bool {
+            const auto w0 = std::chrono::steady_clock::now();
+            bool ok = true;
+            std::string why;
+            for (auto &b : zbatches) if (b && !b->wait()) { ok = false; if (why.empty()) why = b->error; }
+            zbatches.clear();
+            wait_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count();
+            if (!ok) { log_fatal("entropy stage failed: %s", why.c_str()); set_error("%s", why.c_str()); }
+            return ok;
+        };
+        std::vector<size_t> with_prefix;
+        for (size_t f = 0; f < n; f++) if (jobs[f].coeffs_size > 0) with_prefix.push_back(f);
+        const bool use_floor = want_pure && zstd_floor_usable() && !getenv("EBCC_HIP_ZSTD_ALL");
+        if (!want_pure) {
+            submit_zstd(with_prefix);                                   // no fallback: every prefix is part of its stream
+        } else {
+            // frames whose residual layer could not reach the target are coded by the base layer whatever z is (:838 need_pure)
+            std::vector<size_t> cand, now;
+            for (size_t f : with_prefix) {
+                if (jobs[f].need_pure) { zstate[f] = kZSkipped; continue; }
+                if (use_floor && jobs[f].coeffs_size <= kZstdFloorMaxBytes) cand.push_back(f); else now.push_back(f);
+            }
+            if (!now.empty()) submit_zstd(now);
+            if (!cand.empty()) {
+                auto list = std::make_shared<std::vector<size_t>>(cand);
+                zbatches.push_back(HostPool::instance().submit(list->size(), entropy_threads(slices), [&, list](size_t i) {
+                    const size_t f = (*list)[i];
+                    const auto z0 = std::chrono::steady_clock::now();
+                    zfloor[f] = zstd_size_lower_bound(coeff_base + coeff_off[f], jobs[f].coeffs_size);
+                    bound_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+                }));
+            }
+        }
+        pt.mark("zstd: queued");
         if (want_pure) {
             // The pure-base-layer search restarts from base_cr with the quantile of a re-encode at base_cr
             // (:829-833), i.e. of the first probe above (unless that consistency step is disabled), and re-uses
-            // every probe search #1 made; it runs here, while host cores do the level-22 zstd.
-            if (overlap2) { device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchFinish); drain2.armed = false; }
-            else { start_search2(); rate_search(b, 1, jobs, n_pix, slices); }                         // :836
+            // every probe search #1 made; it runs here, while host cores work on the prefixes: first the floors (a few
+            // microseconds per KB), then - the search still running on the GPU - zstd of the prefixes whose floor is so
+            // low that they will probably have to be compressed anyway (they are the short, compressible ones).
+            start_search2();
+            const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
+            if (!host_loop) device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchStart);
+            if (!zjoin()) return 1;                                                           // (floors, and the prefixes too long for one)
+            {
+                std::vector<size_t> early;
+                for (size_t f : with_prefix)
+                    if (zstate[f] == kZNone && zfloor[f] * 3 < jobs[f].coeffs_size) early.push_back(f);
+                if (!early.empty()) submit_zstd(early);
+            }
+            if (host_loop) run_search(b, 1, jobs, n_pix); else device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchFinish);   // :836
             pt.mark("rate search 2");
-            zjoin();
-            if (!zstd_ok) { log_fatal("entropy stage failed: %s", zbatch->error.c_str()); set_error("%s", zbatch->error.c_str()); return 1; }
+            {
+                std::vector<size_t> late;
+                for (size_t f : with_prefix) {
+                    if (zstate[f] != kZNone) continue;
+                    const Job &j = jobs[f];
+                    const size_t len2 = (size_t) j.last[1].stream_bytes;
+                    // z >= zfloor: len2 < zfloor + len1 implies len2 < z + len1 - the base layer alone wins (:838)
+                    if (zfloor[f] > 0 && len2 < zfloor[f] + j.len1) zstate[f] = kZSkipped; else late.push_back(f);
+                }
+                if (!late.empty()) submit_zstd(late);
+            }
+            if (!zjoin()) return 1;
             pt.mark("zstd: wait for the workers");
-            if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms\n", zstd_us.load() / 1e3, zstd_bytes.load(), zstd_max_us.load() / 1e3);
+            long long skipped_bytes = 0, skipped = 0;
+            for (size_t f : with_prefix) if (zstate[f] == kZSkipped) { skipped++; skipped_bytes += (long long) jobs[f].coeffs_size; }
+            if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms; floors %.1f ms; %lld of %zu prefixes (%lld bytes) decided without compressing\n",
+                               zstd_us.load() / 1e3, zstd_bytes.load(), zstd_max_us.load() / 1e3, bound_us.load() / 1e3, skipped, with_prefix.size(), skipped_bytes);
+            host_stats().skipped_bytes += skipped_bytes;
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
                 b.active[f] = 0;
                 if (j.const_field) continue;
                 const size_t len2 = (size_t) j.last[1].stream_bytes;
-                if (len2 < j.zbytes.size() + j.len1 || j.need_pure) {                         // :838
-                    if (len2 < j.zbytes.size() + j.len1)
+                const bool decided = zstate[f] == kZSkipped && !j.need_pure;                  // (z not known, only that it loses)
+                if (decided || len2 < j.zbytes.size() + j.len1 || j.need_pure) {              // :838
+                    if (decided) log_info("frame %zu: pure base compression (%zu) beats base (%zu) + residual (at least %zu)", f, len2, j.len1, zfloor[f]);
+                    else if (len2 < j.zbytes.size() + j.len1)
                         log_info("frame %zu: pure base compression (%zu) beats base (%zu) + residual (%zu)", f, len2, j.len1, j.zbytes.size());
                     j.mean_err = j.last[1].err_sum / (double) n_pix;                          // :843
                     j.zbytes.clear(); j.coeffs_size = 0;
@@ -1206,8 +1312,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 b.collect_tails(jobs);
             }
         }
-        zjoin();
-        if (!zstd_ok) { log_fatal("entropy stage failed: %s", zbatch->error.c_str()); set_error("%s", zbatch->error.c_str()); return 1; }
+        if (!zjoin()) return 1;
+        host_stats().add(zstd_us.load() + bound_us.load(), wait_us, zstd_bytes.load());
     }
 
     pt.mark("fallback search + tails");
@@ -1760,15 +1866,19 @@ void print_config(codec_config_t *c)
 
 int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) std::max(1, slices)); }
 
-// out[0..5] = usable CPUs (affinity mask cut to the cgroup quota), CPU quota (0: none), zstd core-seconds, seconds the
-// slices waited for the zstd workers, bytes compressed, entropy batches - since the last call with reset != 0
+// out[0..6] = usable CPUs (affinity mask cut to the cgroup quota), CPU quota (0: none), zstd core-seconds, seconds the
+// slices waited for the zstd workers, bytes compressed, entropy batches, prefix bytes whose compression was proved
+// unnecessary - since the last call with reset != 0
+// the lower bound of zstd_size_lower_bound (0: not applicable - longer than 128 KB, or a libzstd that may split blocks)
+size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n) { return zstd_floor_usable() ? zstd_size_lower_bound(src, n) : 0; }
+
 void ebcc_hip_host_stats(double *out, int reset)
 {
     HostStats &h = host_stats();
     if (out) {
         out[0] = (double) usable_cpus(); out[1] = cgroup_cpu_quota();
         out[2] = h.zstd_core_us.load() / 1e6; out[3] = h.zstd_wait_us.load() / 1e6;
-        out[4] = (double) h.zstd_bytes.load(); out[5] = (double) h.batches.load();
+        out[4] = (double) h.zstd_bytes.load(); out[5] = (double) h.batches.load(); out[6] = (double) h.skipped_bytes.load();
     }
     if (reset) h.reset();
 }

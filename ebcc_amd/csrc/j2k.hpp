@@ -100,6 +100,11 @@ struct J2kFrame {                 // per-frame scalars (device)
     int keep;                     // probes launched with keep_field == 2 store their decoded field only where this is set (search.hip)
     float hdr_share;              // this tile's share of the main header in the byte budget (opj_j2k_update_rates:
                                   // main header bytes / number of tiles); 0 = a single tile = all 135 bytes
+    // A probe whose only use is the search's "feasible or not" (search.hip: every probe but the final one of a search and
+    // the one that restores its decode) may stop counting once bad_seen >= bad_limit: from that count on the quantile is
+    // below the target by more than the search's tolerance whatever the rest of the frame holds.  0: count everything.
+    unsigned int bad_limit;
+    unsigned int bad_seen;        // running count of the probe in flight (reset by k_finish_reduce)
 };
 
 struct J2kBuffers {

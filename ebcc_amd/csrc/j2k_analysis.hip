@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kRowT) void k_j2k_rows(float *__restrict__ B, const
 struct J2kFinish {
     const float *data;             // nullptr: no statistics
     float *DEC;
-    const J2kFrame *jf;
+    J2kFrame *jf;
     double *partial;               // [frames][kPartials]
     unsigned long long *partial_u;
     int per_frame;                 // DEC is written only for frames with jf[frame].keep set
@@ -653,6 +653,22 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int3
     // starts its pipeline two positions early - an output depends on the inputs of positions i - 2 .. i + 2 only
     const int per = ceil_div(snv, (int) gridDim.z), ja = (int) blockIdx.z * per, jb = min(snv, ja + per);
     const int jstart = max(ja - 2, 0);
+    // statistics-only probes of the rate search stop once the frame has gathered bad_limit samples above the target
+    // (J2kFrame::bad_limit): the pieces are dispatched piece-major over all frames, so the later pieces of a frame that
+    // is clearly infeasible at this rate leave without reading their strip
+    unsigned int limit = 0;
+    if constexpr (FIN) {
+        if (x && !d) {
+            limit = fin.jf[frame].bad_limit;
+            if (limit && __hip_atomic_load(&fin.jf[frame].bad_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit) {
+                if (threadIdx.x == 0) {
+                    fin.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = 0.0;
+                    fin.partial_u[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = 0;
+                }
+                return;
+            }
+        }
+    }
     fetch(jstart, in_ll, in_hl, in_lh, in_hh);
     for (int j = jstart; j < jb + 2; j++) {
         float n_ll, n_hl, n_lh, n_hh;
@@ -687,6 +703,7 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int3
         if (threadIdx.x == 0) {
             fin.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = acc;
             fin.partial_u[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = bad;
+            if (limit && bad) atomicAdd(&fin.jf[frame].bad_seen, bad);
         }
     }
 }
@@ -1563,7 +1580,8 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
     for (int r = 1; r < kJ2kRes; r++) {                                // opj_dwt_decode_tile_97: horizontal, then vertical
         if (r >= first_fused) {
             const int strips = ceil_div(g.rw[r - 1], kL5Pairs);
-            const int pieces = std::max(1, std::min({4, kPartials / strips, g.rh[r - 1] / 16}));
+            // (the top level in more, shorter pieces: a piece is what an infeasible probe can skip)
+            const int pieces = std::max(1, std::min({r == kJ2kRes - 1 ? 8 : 4, kPartials / strips, g.rh[r - 1] / 16}));
             if (r > 1 && !ll) ll = B;                                   // (the separate passes below left their result in B)
             J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};
             if (r == kJ2kRes - 1) {

@@ -908,6 +908,7 @@ __global__ void k_finish_reduce(const double *partial, const unsigned long long 
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n || (active && !active[f]) || fs[f].const_field) return;
+    jf[f].bad_seen = 0;                                                 // (the early-exit counter of the probe just finished)
     double s = 0;
     unsigned long long b = 0;
     for (int i = 0; i < n_partials; i++) { s += partial[(size_t) f * kPartials + i]; b += partial_u[(size_t) f * kPartials + i]; }
@@ -1241,37 +1242,39 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
     rpass[gid] = plan;
 }
 
+// One workgroup per (code-block, frame): a code-block that keeps its passes returns at once (round 2 walked every sample of
+// the frame through the code-block map to find that out - 2 MB per frame and round), the others rewrite their own
+// rectangle, 256-byte row segments.
 __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ Q6, const int *__restrict__ rpass,
                                                      const int *__restrict__ numbps, const unsigned long long *__restrict__ SPS,
-                                                     const std::uint16_t *__restrict__ blkmap, int32_t *__restrict__ V,
-                                                     const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
-                                                     const int *active)
+                                                     int32_t *__restrict__ V, const J2kGeom *geom, const J2kBlock *blocks,
+                                                     const FrameState *fs, const int *active)
 {
-    const int frame = blockIdx.y;
+    const int frame = blockIdx.y, bi = blockIdx.x;
     if ((active && !active[frame]) || fs[frame].const_field) return;
+    const int gid = frame * geom->stride + bi;
+    const int plan = rpass[gid];
+    if (plan == -2) return;                                             // unchanged code-block: V is up to date
+    if (bi >= j2k_frame_geom(geom, frame).nblocks) return;              // (slots past this tile position's last code-block)
     const int W = geom->W;
     const size_t n_pix = (size_t) W * geom->H;
-    const int32_t *q = Q6 + (size_t) frame * n_pix;
-    int32_t *v = V + (size_t) frame * n_pix;
-    const int gid0 = frame * geom->stride;
-    blkmap = j2k_frame_blkmap(geom, blkmap, frame);
-    blocks = j2k_frame_blocks(geom, blocks, frame);
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += (size_t) gridDim.x * blockDim.x) {
-        const int bi = blkmap[i], gid = gid0 + bi;
-        const int plan = rpass[gid];
-        if (plan == -2) continue;                                       // unchanged code-block: V is up to date
-        const int q6 = q[i];
+    const J2kBlock blk = j2k_frame_blocks(geom, blocks, frame)[bi];
+    const int P = numbps[gid];
+    const int x = threadIdx.x & 63;
+    if (x >= blk.w) return;
+    const int32_t *q = Q6 + (size_t) frame * n_pix + (size_t) blk.y * W + blk.x + x;
+    int32_t *v = V + (size_t) frame * n_pix + (size_t) blk.y * W + blk.x + x;
+    const unsigned long long *spsrow = SPS + ((size_t) (gid >> 6) * 64) * 64 + (gid & 63);
+    for (int y = threadIdx.x >> 6; y < blk.h; y += 4) {
+        const int q6 = q[(size_t) y * W];
         const unsigned int a = (unsigned int) (q6 < 0 ? -q6 : q6) >> 6;
         int out = 0;
         if (plan > 0 && a) {
-            const int P = numbps[gid];
             const int bs = 31 - __clz(a);
-            const J2kBlock blk = blocks[bi];
-            const int y = (int) (i / W), x = (int) (i - (size_t) y * W);
             // rows above the restart stripe have already been through pass r
-            const int r = (plan & 0xFF) + ((y - blk.y) < 4 * (plan >> 8) ? 1 : 0);
-            const unsigned long long sps = SPS[(((size_t) (gid >> 6)) * 64 + (y - blk.y)) * 64 + (gid & 63)];
-            const int ps = bs == P - 1 ? 0 : 3 * (P - 1 - bs) - (((sps >> (x - blk.x)) & 1ull) ? 2 : 0);
+            const int r = (plan & 0xFF) + (y < 4 * (plan >> 8) ? 1 : 0);
+            const unsigned long long sps = spsrow[(size_t) y * 64];
+            const int ps = bs == P - 1 ? 0 : 3 * (P - 1 - bs) - (((sps >> x) & 1ull) ? 2 : 0);
             if (ps < r) {
                 out = 3 << bs;                                          // 1.5 * 2^bs in half units, then the refinements
                 for (int pl = bs - 1; pl >= 0; pl--) {
@@ -1281,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_probe_init(const int32_t *__restrict__ 
                 if (q6 < 0) out = -out;
             }
         }
-        v[i] = out;
+        v[(size_t) y * W] = out;
     }
 }
 
@@ -1432,7 +1435,7 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
     void *ck = jb.ckpt;
     hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
                        jb.lastnp, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
-    hipLaunchKernelGGL(k_probe_init, dim3(128, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.numbps, jb.SPS, jb.d_blkmap, jb.V,
+    hipLaunchKernelGGL(k_probe_init, dim3(jb.geom.stride, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.numbps, jb.SPS, jb.V,
                        jb.d_geom, jb.d_blocks, jb.fs, d_active);
     timing_begin("t1_probe_decode", s);
     const int lpw = t1_lanes_per_wave(T1_RESUME);

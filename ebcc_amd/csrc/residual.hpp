@@ -34,6 +34,8 @@ struct FrameState {
     double err_sum;
     int err_sum_inexact;
     unsigned long long nbad;                // count(|x - d| > target)
+    float exit_above;                       // > 0: a probe of the truncation search may stop once its running maximum exceeds
+                                            // this (the search then only asks "max error > target?", search.hip); 0: exact
     // ---- decode
     int dec_stages, dec_dc, dec_top_step;
     unsigned long long dec_budget;

@@ -467,6 +467,15 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     const float dc = fs.dc, rmin = fs.rmin, rng = fs.rmax - fs.rmin;
     const int per = (half + (int) gridDim.z - 1) / (int) gridDim.z, ka = (int) blockIdx.z * per, kb = min(half, ka + per);
     const int jstart = max(ka - 2, 0);
+    // A probe that only has to answer "is the maximum error above the target?" (the truncation bisection's rounds,
+    // /root/reference/src/ebcc_codec.c:788: cur > target moves trunc_lo and uses nothing else of the probe) is decided as
+    // soon as one wave has seen such a sample: the waves that start after that leave at once.  Pieces are dispatched
+    // piece-major over all frames, so most of an infeasible probe's waves never read their strip.
+    const float exit_above = fs.exit_above;
+    if (exit_above > 0.0f && __uint_as_float(__hip_atomic_load(&u.fs[frame].maxerr_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > exit_above) {
+        if (threadIdx.x == 0) u.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = 0.0;
+        return;
+    }
     // the three detail coefficients of a vertical position (ordinal always, value and slot only inside the prefix) + LL
     struct Det { uint32_t o, l; int c; };
     struct Raw { float ll; Det lh, hl, hh; };

@@ -68,8 +68,25 @@ __device__ float next_rate_if(const DevChunk &C, const DevRateSearch &R, int k, 
     return -1.0f;
 }
 
+// The count of samples above the target from which a probe is infeasible for both searches beyond the bisection's
+// tolerance: q(m) = 1. - m / n_pix (:512) falls with m, so there is a largest feasible count T (q(T) >= qt), and from
+// T + 2 + ceil(1e-8 n_pix) on q(m) < qt and |q(m) - qt| > 1e-8 hold - every test :559-588 makes of q comes out as it
+// does for the exact count.  0: no such shortcut (the count is needed, or the arithmetic here is not trusted).
+__device__ unsigned int infeasible_from(double qt, double n_pix)
+{
+    if (!(qt > 0.0 && qt <= 1.0) || !(n_pix >= 1.0 && n_pix < 2e9)) return 0;
+    double m = floor((1.0 - qt) * n_pix) - 2.0;
+    if (m < 0) m = 0;
+    if (!(1. - (m / n_pix) >= qt)) return 0;                           // (m must be feasible to start from)
+    int guard = 0;
+    while (1. - ((m + 1.0) / n_pix) >= qt) { m += 1.0; if (++guard > 16) return 0; }
+    const double from = m + 2.0 + ceil(1e-8 * n_pix);
+    if (!(1. - (from / n_pix) < qt) || !(fabs((1. - (from / n_pix)) - qt) > 1e-8) || from > 4.0e9) return 0;
+    return (unsigned int) from;
+}
+
 __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, int n_chunks, int tiles, int k, double n_pix,
-                                 int *unfinished, float *cand_cr, int *cand_sel)
+                                 int *unfinished, float *cand_cr, int *cand_sel, double limit_qt)
 {
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= n_chunks) return;
@@ -133,13 +150,17 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
     }
     set_active(R.want);
     if (R.want) {
-        for (int t = 0; t < tiles; t++) { jf[t0 + t].cr = R.want_cr; jf[t0 + t].keep = keeps_field(k, R.phase); }
+        // the final probe of a search (:590: its size, error sum and count are the search's result) and the probe that
+        // restores a decode are exact; every other probe only has to tell feasible from infeasible
+        const bool exact = R.phase == 3 || R.phase == 5 || tiles > 1 || limit_qt <= 0.0;
+        const unsigned int limit = exact ? 0u : infeasible_from(limit_qt < R.qt ? limit_qt : R.qt, n_pix);
+        for (int t = 0; t < tiles; t++) { jf[t0 + t].cr = R.want_cr; jf[t0 + t].keep = keeps_field(k, R.phase); jf[t0 + t].bad_limit = limit; }
         atomicAdd(unfinished, 1);
     }
 }
 
 // ---- :765-796 ------------------------------------------------------------------------------------------
-__global__ void k_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *active, int n_chunks,
+__global__ void k_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *active, int n_chunks,
                                 double n_pix, int *unfinished)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,6 +180,7 @@ __global__ void k_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned
     const double eps = 1e-8;
     if (((C.target - C.best_err) / C.target > eps) && (C.t_hi - C.t_lo > 8 * 4)) {
         trunc_bits[f] = (unsigned long long) ceil((C.t_hi + C.t_lo) / 2 / 8) * 8ull;
+        fs[f].exit_above = C.target;                                  // (cur > target is all that is asked of an infeasible cut, above)
         C.trunc_pending = 1;
         active[f] = 1;
         atomicAdd(unfinished, 1);
@@ -171,14 +193,14 @@ __global__ void k_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned
 }  // namespace
 
 void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_chunks, int tiles, int k, double n_pix,
-                           int *unfinished, hipStream_t s, float *cand_cr, int *cand_sel)
+                           int *unfinished, hipStream_t s, float *cand_cr, int *cand_sel, double limit_qt)
 {
     hipLaunchKernelGGL(k_search_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, jf, d_active, n_chunks, tiles, k, n_pix,
-                       unfinished, cand_cr, cand_sel);
+                       unfinished, cand_cr, cand_sel, limit_qt);
     EBCC_HIP_LAUNCH_CHECK();
 }
 
-void launch_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
+void launch_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
                           double n_pix, int *unfinished, hipStream_t s)
 {
     hipLaunchKernelGGL(k_trunc_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, fs, trunc_bits, d_active, n_chunks, n_pix,

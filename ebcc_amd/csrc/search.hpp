@@ -52,12 +52,15 @@ struct DevChunk {                  // per chunk (= frame, or the frames coded as
 // or finish.  `unfinished` (device int) is incremented by every chunk that still wants a probe.
 // cand_cr / cand_sel (J2kBuffers, may be null): speculative rate allocation - the round also says which of the previous round's
 // two candidate rates is the one asked for now (cand_sel) and writes the two rates the search can ask for next (cand_cr).
+// limit_qt > 0: probes that only have to tell feasible from infeasible may stop counting early (J2kFrame::bad_limit); the
+// quantile target the limit is derived from is the smaller of limit_qt (the error-bounded search's, whose probes the pure
+// base-layer search re-uses) and the running search's own.  0: every probe counts the whole frame.
 void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_chunks, int tiles, int k, double n_pix,
-                           int *unfinished, hipStream_t s, float *cand_cr = nullptr, int *cand_sel = nullptr);
+                           int *unfinished, hipStream_t s, float *cand_cr = nullptr, int *cand_sel = nullptr, double limit_qt = 0.0);
 
 // One round of the truncation bisection: take in the statistics of the cut made in the previous round, choose the next
 // cut (trunc_bits[f], active[f] = 1) or finish.
-void launch_trunc_advance(DevChunk *chunks, const FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
+void launch_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
                           double n_pix, int *unfinished, hipStream_t s);
 
 }  // namespace ebcc

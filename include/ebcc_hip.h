@@ -107,8 +107,13 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
 int ebcc_hip_host_threads(int slices);
 /* Host-side accounting since the last reset: out[0] usable CPUs (affinity and quota), out[1] CPU quota of the container in
  * CPUs (0: none), out[2] core-seconds spent in zstd, out[3] seconds the slices waited for the zstd workers, out[4] bytes
- * compressed, out[5] entropy batches.  bench.py prints them per rank (a run bound by the host's CPUs shows here). */
+ * compressed, out[5] entropy batches, out[6] prefix bytes whose compression was proved unnecessary (ebcc_hip_zstd_floor).  bench.py prints them per rank (a run bound by the host's CPUs shows here). */
 void ebcc_hip_host_stats(double *out, int reset);
+/* Lower bound (bytes) of the zstd frame ZSTD_compress writes for [src, src + n) at any level, from the format alone (the
+ * literals no match can cover cost at least their entropy; host_codec.hip: zstd_size_lower_bound); 0 = no bound (n above
+ * 128 KB, or a libzstd that may split blocks).  The encoder uses it to decide the reference's "pure base layer beats base +
+ * residual" comparison (src/ebcc_codec.c:838) without compressing prefixes that provably lose it. */
+size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).  Names: "t1_encode",
  * "t1_probe_decode", "t1_decode", "rate_alloc", "j2k_dwt_fwd", "spiht_encode".  Process-wide switch. */

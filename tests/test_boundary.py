@@ -175,7 +175,7 @@ def test_host_thread_budget_per_rank():
     if not os.path.exists(L.PRODUCT_SO):
         pytest.skip("library not built")
     child = ("import ctypes, os; lib = ctypes.CDLL(%r); lib.ebcc_hip_host_threads.restype = ctypes.c_int; "
-             "s = (ctypes.c_double * 6)(); lib.ebcc_hip_host_stats(s, 0); "
+             "s = (ctypes.c_double * 8)(); lib.ebcc_hip_host_stats(s, 0); "
              "print(lib.ebcc_hip_host_threads(1), lib.ebcc_hip_host_threads(4), len(os.sched_getaffinity(0)), int(s[0]), s[1])" % L.PRODUCT_SO)
     env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "EBCC_HOST_THREADS", "EBCC_HOST_CPU_QUOTA")}
 

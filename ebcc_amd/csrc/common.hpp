@@ -81,6 +81,25 @@ inline Grid make_grid(int height, int width, int stages)
 template <typename T>
 __host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
+// XCD-aware workgroup -> tile mapping for kernels in which the `strips` workgroups of a tile read neighbouring column
+// ranges of the same rows (the fused inverse wavelet levels: 60 sample pairs per wave, ranges that are not multiples of a
+// 128-byte line, two pairs of halo either side).  MI355X deals workgroups round-robin over its 8 XCDs, each with its own L2
+// (observed placement; used for speed only): with the plain (strip, frame, piece) grid the neighbours of a strip run on
+// seven OTHER XCDs and every line two strips share - and every halo - is fetched from HBM once per XCD: the top inverse
+// level of the base layer moved 2.02x its bytes (profiles/r02_hbm_kernels.json).  Here workgroup b of a 1-D launch of
+// strips * tiles workgroups takes strip (b / 8) % strips of tile 8 * (b / 8 / strips) + b % 8: the strips of a tile are
+// consecutive workgroups of ONE XCD.  Tiles are numbered piece-major (tile = piece * frames + frame), so that all frames'
+// first pieces are dispatched first (the early exit of the search probes relies on that order for speed, not correctness).
+struct TileOfBlock { int strip, frame, piece; };
+__device__ inline TileOfBlock xcd_tile_of_block(unsigned b, unsigned strips, unsigned frames, unsigned pieces)
+{
+    const unsigned tiles = frames * pieces, groups = tiles / 8, s = b >> 3;
+    unsigned strip, tile;
+    if (s < groups * strips) { strip = s % strips; tile = (s / strips) * 8 + (b & 7); }
+    else { const unsigned idx = b - groups * 8 * strips; strip = idx % strips; tile = groups * 8 + idx / strips; }   // (the last tiles, fewer than 8)
+    return TileOfBlock{(int) strip, (int) (tile % frames), (int) (tile / frames)};
+}
+
 // Monotone key for float ordering with -0 == +0 (reference compares with < and >, so the two
 // zeros tie; ties are then broken by index to reproduce "first occurrence wins").
 __host__ __device__ inline uint32_t float_order_key(float f)

@@ -485,35 +485,54 @@ static double cgroup_cpu_quota()
     }
     return 0;                                                   // no quota
 }
+static unsigned affinity_cpus()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned) CPU_COUNT(&set);
+    return std::max(1u, n);
+}
 unsigned usable_cpus()
 {
     static const unsigned cached = [] {
-        unsigned n = std::thread::hardware_concurrency();
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned) CPU_COUNT(&set);
+        unsigned n = affinity_cpus();
         const double q = cgroup_cpu_quota();
         if (q > 0) n = std::min(n, (unsigned) std::max(1.0, std::floor(q + 0.5)));
         return std::max(1u, n);
     }();
     return cached;
 }
-// Host threads of one encode call for the entropy stage (level-22 zstd of the residual prefixes - the longest host
-// step, ~1.3 core-seconds per 256 frames): EBCC_HOST_THREADS, else the usable CPUs (above) divided by the ranks that
-// share the host (LOCAL_WORLD_SIZE), minus one per slice for the threads that steer the GPU - they must never wait
-// behind the compressors, and a pool larger than the quota only moves the wait into the kernel's throttling.  The pool
-// is per encode call and shared by its slices (encode_batch).
+// Width of the pool.  A quota of Q CPUs is Q x 100 ms of CPU time per 100 ms period, not a limit on how many threads run at
+// once: work that comes in bursts - the entropy stage, once per slice - may run wider than Q as long as a period's total
+// stays below the quota, and finishes sooner for it.  Round 2 ran 64 threads into the 16-CPU quota of the MI355X box with
+// 1.3-1.9 core-seconds of zstd per step: throttled in every second period (cpu.stat), the steering threads with it -
+// the "two timing modes".  Since the encoder only compresses the prefixes whose size can matter, a step needs 0.6-0.9
+// core-seconds, and a burst TWICE the quota wide stays clear of it (tools/gpu/host_sweep.sh: 32 threads 159-167 ms per
+// step and no throttled period, 15 threads 172-177, 8 threads 197).  So: min(affinity, 2 x quota) divided by the ranks
+// that share the host (LOCAL_WORLD_SIZE), minus the threads that steer the GPU; EBCC_HOST_THREADS overrides.  The pool is
+// per process and shared by the slices of every call (HostPool).
 unsigned entropy_threads_for(unsigned cpus, unsigned local_world, unsigned slices)
 {
     const unsigned share = std::max(1u, cpus / std::max(1u, local_world));
     const unsigned steer = std::min(slices, share > 4 ? 2u : 0u);
     return std::max(1u, std::min(64u, share - steer));
 }
+static unsigned burst_cpus()
+{
+    static const unsigned cached = [] {
+        unsigned n = affinity_cpus();
+        const double q = cgroup_cpu_quota();
+        if (q > 0) n = std::min(n, (unsigned) std::max(1.0, std::floor(2.0 * q + 0.5)));
+        return std::max(1u, n);
+    }();
+    return cached;
+}
 unsigned entropy_threads(unsigned slices = 1)
 {
     if (const char *e = getenv("EBCC_HOST_THREADS")) return (unsigned) std::max(1L, strtol(e, nullptr, 10));
     unsigned lws = 1;
     if (const char *e = getenv("LOCAL_WORLD_SIZE")) lws = (unsigned) std::max(1, atoi(e));
-    return entropy_threads_for(usable_cpus(), lws, slices);
+    return entropy_threads_for(burst_cpus(), lws, slices);
 }
 
 // Host-side accounting of the entropy stage since the last reset (ebcc_hip_host_stats: bench.py prints it per rank so that
@@ -1193,19 +1212,21 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         // jobs on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so the host is never
         // oversubscribed however many slices run
         std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0}, bound_us{0};    // core time, longest job, bytes
-        enum : uint8_t { kZNone = 0, kZQueued = 1, kZSkipped = 2 };
-        std::vector<uint8_t> zstate(n, kZNone);
+        enum : uint8_t { kZNone = 0, kZQueued = 1, kZRunning = 2, kZSkipped = 3 };
+        std::unique_ptr<std::atomic<uint8_t>[]> zstate(new std::atomic<uint8_t>[n]);
+        for (size_t f = 0; f < n; f++) zstate[f] = kZNone;
         std::vector<size_t> zfloor(n, 0);                               // lower bound of z (0: none)
         std::vector<std::shared_ptr<HostPool::Batch>> zbatches;
         struct WaitOnExit { std::vector<std::shared_ptr<HostPool::Batch>> &v; ~WaitOnExit() { for (auto &b : v) if (b) b->wait(); } } wait_on_exit{zbatches};   // (error paths too: the jobs point into this frame)
-        // level-22 zstd of the frames in `list`, longest first: level 22 takes ~0.16 ms per KB on one core and a batch has
-        // frames whose prefix is ten times the average - started last, such a frame alone decides when the slice can go on
+        // level-22 zstd of the frames in `list`, in the order given; a frame that was decided in the meantime (kZSkipped)
+        // is passed over
         auto submit_zstd = [&](std::vector<size_t> list) {
-            std::stable_sort(list.begin(), list.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
             for (size_t f : list) zstate[f] = kZQueued;
             auto order = std::make_shared<std::vector<size_t>>(std::move(list));
             zbatches.push_back(HostPool::instance().submit(order->size(), entropy_threads(slices), [&, order](size_t i) {
                 const size_t f = (*order)[i];
+                uint8_t expect = kZQueued;
+                if (!zstate[f].compare_exchange_strong(expect, kZRunning)) return;
                 Job &j = jobs[f];
                 const auto z0 = std::chrono::steady_clock::now();
                 j.zbytes.resize(zstd().bound(j.coeffs_size));
@@ -1216,6 +1237,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
                 long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
             }));
+        };
+        // longest first: level 22 takes ~0.2 ms per KB on one core and a batch has frames whose prefix is ten times the
+        // average - started last, such a frame alone decides when the slice can go on
+        auto longest_first = [&](std::vector<size_t> &list) {
+            std::stable_sort(list.begin(), list.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
         };
         long long wait_us = 0;
         auto zjoin = [&]() -> bool {
@@ -1231,15 +1257,18 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         std::vector<size_t> with_prefix;
         for (size_t f = 0; f < n; f++) if (jobs[f].coeffs_size > 0) with_prefix.push_back(f);
         const bool use_floor = want_pure && zstd_floor_usable() && !getenv("EBCC_HIP_ZSTD_ALL");
+        std::vector<size_t> cand;
         if (!want_pure) {
+            longest_first(with_prefix);
             submit_zstd(with_prefix);                                   // no fallback: every prefix is part of its stream
         } else {
             // frames whose residual layer could not reach the target are coded by the base layer whatever z is (:838 need_pure)
-            std::vector<size_t> cand, now;
+            std::vector<size_t> now;
             for (size_t f : with_prefix) {
                 if (jobs[f].need_pure) { zstate[f] = kZSkipped; continue; }
                 if (use_floor && jobs[f].coeffs_size <= kZstdFloorMaxBytes) cand.push_back(f); else now.push_back(f);
             }
+            longest_first(now);
             if (!now.empty()) submit_zstd(now);
             if (!cand.empty()) {
                 auto list = std::make_shared<std::vector<size_t>>(cand);
@@ -1256,36 +1285,34 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             // The pure-base-layer search restarts from base_cr with the quantile of a re-encode at base_cr
             // (:829-833), i.e. of the first probe above (unless that consistency step is disabled), and re-uses
             // every probe search #1 made; it runs here, while host cores work on the prefixes: first the floors (a few
-            // microseconds per KB), then - the search still running on the GPU - zstd of the prefixes whose floor is so
-            // low that they will probably have to be compressed anyway (they are the short, compressible ones).
+            // microseconds per KB), then - the search still running on the GPU, len2 not known yet - zstd of the
+            // candidates in the order in which they are likely to need it (lowest floor per byte first); the moment the
+            // search's sizes are in, the candidates they decide are struck from the queue.
             start_search2();
             const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
             if (!host_loop) device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchStart);
-            if (!zjoin()) return 1;                                                           // (floors, and the prefixes too long for one)
-            {
-                std::vector<size_t> early;
-                for (size_t f : with_prefix)
-                    if (zstate[f] == kZNone && zfloor[f] * 3 < jobs[f].coeffs_size) early.push_back(f);
-                if (!early.empty()) submit_zstd(early);
+            if (!cand.empty()) {
+                if (!zjoin()) return 1;                                                       // (the floors - and with them the prefixes too long for one)
+                std::vector<size_t> spec = cand;
+                std::stable_sort(spec.begin(), spec.end(), [&](size_t a, size_t c) {
+                    return (double) zfloor[a] * (double) jobs[c].coeffs_size < (double) zfloor[c] * (double) jobs[a].coeffs_size; });
+                submit_zstd(spec);
             }
             if (host_loop) run_search(b, 1, jobs, n_pix); else device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchFinish);   // :836
             pt.mark("rate search 2");
-            {
-                std::vector<size_t> late;
-                for (size_t f : with_prefix) {
-                    if (zstate[f] != kZNone) continue;
-                    const Job &j = jobs[f];
-                    const size_t len2 = (size_t) j.last[1].stream_bytes;
-                    // z >= zfloor: len2 < zfloor + len1 implies len2 < z + len1 - the base layer alone wins (:838)
-                    if (zfloor[f] > 0 && len2 < zfloor[f] + j.len1) zstate[f] = kZSkipped; else late.push_back(f);
-                }
-                if (!late.empty()) submit_zstd(late);
+            long long skipped_bytes = 0, skipped = 0;
+            for (size_t f : cand) {
+                const Job &j = jobs[f];
+                const size_t len2 = (size_t) j.last[1].stream_bytes;
+                // z >= zfloor: len2 < zfloor + len1 implies len2 < z + len1 - the base layer alone wins (:838)
+                if (!(zfloor[f] > 0 && len2 < zfloor[f] + j.len1)) continue;
+                uint8_t expect = kZQueued;
+                if (zstate[f].compare_exchange_strong(expect, kZSkipped)) { skipped++; skipped_bytes += (long long) j.coeffs_size; }
             }
             if (!zjoin()) return 1;
             pt.mark("zstd: wait for the workers");
-            long long skipped_bytes = 0, skipped = 0;
-            for (size_t f : with_prefix) if (zstate[f] == kZSkipped) { skipped++; skipped_bytes += (long long) jobs[f].coeffs_size; }
-            if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms; floors %.1f ms; %lld of %zu prefixes (%lld bytes) decided without compressing\n",
+            for (size_t f : with_prefix) if (jobs[f].need_pure) { skipped++; skipped_bytes += (long long) jobs[f].coeffs_size; }
+            if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms; floors %.1f ms; %lld of %zu prefixes (%lld bytes) not compressed\n",
                                zstd_us.load() / 1e3, zstd_bytes.load(), zstd_max_us.load() / 1e3, bound_us.load() / 1e3, skipped, with_prefix.size(), skipped_bytes);
             host_stats().skipped_bytes += skipped_bytes;
             bool any_pure = false;
@@ -1294,7 +1321,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 b.active[f] = 0;
                 if (j.const_field) continue;
                 const size_t len2 = (size_t) j.last[1].stream_bytes;
-                const bool decided = zstate[f] == kZSkipped && !j.need_pure;                  // (z not known, only that it loses)
+                const bool decided = zfloor[f] > 0 && len2 < zfloor[f] + j.len1;              // (z may not be known - only that it loses)
                 if (decided || len2 < j.zbytes.size() + j.len1 || j.need_pure) {              // :838
                     if (decided) log_info("frame %zu: pure base compression (%zu) beats base (%zu) + residual (at least %zu)", f, len2, j.len1, zfloor[f]);
                     else if (len2 < j.zbytes.size() + j.len1)

@@ -597,16 +597,17 @@ struct J2kLevelIO {
 };
 template <bool FIN>
 __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int32_t *__restrict__ V, const J2kGeom *geom,
-                                                        const FrameState *fs, const int *active, J2kFinish fin)
+                                                        const FrameState *fs, const int *active, J2kFinish fin, int strips, int n_frames, int pieces)
 {
-    const int frame = blockIdx.y;
+    const TileOfBlock tb = xcd_tile_of_block(blockIdx.x, (unsigned) strips, (unsigned) n_frames, (unsigned) pieces);   // (1-D launch, common.hpp)
+    const int frame = tb.frame;
     if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
     const J2kGeom &g = j2k_frame_geom(geom, frame);
     const int r = FIN ? kJ2kRes - 1 : io.r;
     const int W = g.W, nh = g.rw[r], snh = g.rw[r - 1], dnh = nh - snh;          // horizontal: samples, low-pass, high-pass
     const int nv = g.rh[r], snv = g.rh[r - 1], dnv = nv - snv;                   // vertical
     const size_t n_pix = (size_t) W * g.H;
-    const int i = (int) blockIdx.x * kL5Pairs + (int) threadIdx.x - 2;           // this lane's pair
+    const int i = tb.strip * kL5Pairs + (int) threadIdx.x - 2;                   // this lane's pair
     const bool has_e = i >= 0 && i < snh, has_o = i >= 0 && i < dnh;
     const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kL5Pairs && has_e;    // (halo lanes compute, owners put out)
     const float *b = io.ll ? io.ll + (size_t) frame * io.ll_frame : nullptr;
@@ -651,7 +652,8 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int3
     };
     // the vertical extent is cut into gridDim.z pieces (more waves in flight): a piece puts out positions [ja, jb) and
     // starts its pipeline two positions early - an output depends on the inputs of positions i - 2 .. i + 2 only
-    const int per = ceil_div(snv, (int) gridDim.z), ja = (int) blockIdx.z * per, jb = min(snv, ja + per);
+    const int per = ceil_div(snv, pieces), ja = tb.piece * per, jb = min(snv, ja + per);
+    const size_t part = (size_t) frame * kPartials + (size_t) (tb.strip + strips * tb.piece);   // this workgroup's partial sums
     const int jstart = max(ja - 2, 0);
     // statistics-only probes of the rate search stop once the frame has gathered bad_limit samples above the target
     // (J2kFrame::bad_limit): the pieces are dispatched piece-major over all frames, so the later pieces of a frame that
@@ -661,10 +663,7 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int3
         if (x && !d) {
             limit = fin.jf[frame].bad_limit;
             if (limit && __hip_atomic_load(&fin.jf[frame].bad_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit) {
-                if (threadIdx.x == 0) {
-                    fin.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = 0.0;
-                    fin.partial_u[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = 0;
-                }
+                if (threadIdx.x == 0) { fin.partial[part] = 0.0; fin.partial_u[part] = 0; }
                 return;
             }
         }
@@ -701,8 +700,8 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int3
     if (x) {
         for (int k = 32; k >= 1; k >>= 1) { acc += __shfl_xor(acc, k); bad += __shfl_xor(bad, k); }
         if (threadIdx.x == 0) {
-            fin.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = acc;
-            fin.partial_u[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = bad;
+            fin.partial[part] = acc;
+            fin.partial_u[part] = bad;
             if (limit && bad) atomicAdd(&fin.jf[frame].bad_seen, bad);
         }
     }
@@ -1586,11 +1585,11 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
             J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};
             if (r == kJ2kRes - 1) {
                 partials = strips * pieces;
-                hipLaunchKernelGGL(k_j2k_level5_fin<true>, dim3(strips, n_frames, pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active,
-                                   J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2});
+                hipLaunchKernelGGL(k_j2k_level5_fin<true>, dim3((unsigned) strips * n_frames * pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active,
+                                   J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2}, strips, n_frames, pieces);
             } else {
                 io.out = ll == spare ? B : spare;                         // never the buffer the level reads from
-                hipLaunchKernelGGL(k_j2k_level5_fin<false>, dim3(strips, n_frames, pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active, J2kFinish{});
+                hipLaunchKernelGGL(k_j2k_level5_fin<false>, dim3((unsigned) strips * n_frames * pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active, J2kFinish{}, strips, n_frames, pieces);
                 ll = io.out;
             }
             continue;

@@ -444,9 +444,10 @@ __global__ __launch_bounds__(kStreamT) void k_cols_inv_stream(const float *__res
 constexpr int kFusePairs = 60;
 __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__ src, Grid g, size_t np, const int32_t *__restrict__ Cb,
                                                         const uint32_t *__restrict__ sigordb, const uint32_t *__restrict__ lspidxb,
-                                                        const unsigned long long *trunc_bits, const int *active, RowUse u)
+                                                        const unsigned long long *trunc_bits, const int *active, RowUse u, int strips, int n_frames, int pieces)
 {
-    const int frame = blockIdx.y;
+    const TileOfBlock tb = xcd_tile_of_block(blockIdx.x, (unsigned) strips, (unsigned) n_frames, (unsigned) pieces);   // (1-D launch: the strips of a tile on one XCD, common.hpp)
+    const int frame = tb.frame;
     if (active && !active[frame]) return;
     const FrameState &fs = u.fs[frame];
     unsigned long long nb = trunc_bits[frame], bits0 = fs.budget + 128;   // spiht_decode: num_bits = min(num_bits, bits0) - 128 (spiht_re.c:495-500)
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     if (threadIdx.x < 32) { rbase[threadIdx.x] = fs.refine_base[threadIdx.x]; rreach[threadIdx.x] = fs.step_reached[threadIdx.x]; }
     __syncthreads();
     const int nx = g.nx, ny = g.ny, half = ny >> 1, hx = nx >> 1;
-    const int k = (int) blockIdx.x * kFusePairs + (int) threadIdx.x - 2;   // this lane's pair of output columns (2k, 2k + 1)
+    const int k = tb.strip * kFusePairs + (int) threadIdx.x - 2;           // this lane's pair of output columns (2k, 2k + 1)
     const bool in_range = k >= 0 && k < hx;
     const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kFusePairs && in_range;
     const int kc = min(max(k, 0), hx - 1);
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     const uint32_t *so = sigordb + (size_t) frame * np, *li = lspidxb + (size_t) frame * np;
     const float *x = u.data + (size_t) frame * u.n_pix, *d = u.decoded + (size_t) frame * u.n_pix;
     const float dc = fs.dc, rmin = fs.rmin, rng = fs.rmax - fs.rmin;
-    const int per = (half + (int) gridDim.z - 1) / (int) gridDim.z, ka = (int) blockIdx.z * per, kb = min(half, ka + per);
+    const int per = (half + pieces - 1) / pieces, ka = tb.piece * per, kb = min(half, ka + per);
+    const size_t part = (size_t) frame * kPartials + (size_t) (tb.strip + strips * tb.piece);
     const int jstart = max(ka - 2, 0);
     // A probe that only has to answer "is the maximum error above the target?" (the truncation bisection's rounds,
     // /root/reference/src/ebcc_codec.c:788: cur > target moves trunc_lo and uses nothing else of the probe) is decided as
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     // piece-major over all frames, so most of an infeasible probe's waves never read their strip.
     const float exit_above = fs.exit_above;
     if (exit_above > 0.0f && __uint_as_float(__hip_atomic_load(&u.fs[frame].maxerr_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > exit_above) {
-        if (threadIdx.x == 0) u.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = 0.0;
+        if (threadIdx.x == 0) u.partial[part] = 0.0;
         return;
     }
     // the three detail coefficients of a vertical position (ordinal always, value and slot only inside the prefix) + LL
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     }
     for (int q = 32; q >= 1; q >>= 1) { acc += __shfl_xor(acc, q); mx = fmaxf(mx, __shfl_xor(mx, q)); }
     if (threadIdx.x == 0) {
-        u.partial[(size_t) frame * kPartials + blockIdx.x + gridDim.x * blockIdx.z] = acc;
+        u.partial[part] = acc;
         atomicMax(&u.fs[frame].maxerr_bits, __float_as_uint(mx));
     }
 }
@@ -1024,8 +1026,8 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     const int strips = ceil_div(g.nx >> 1, kFusePairs);
     if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
         u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
-        hipLaunchKernelGGL(k_finest_inv_use, dim3(strips, n_frames, pieces), dim3(64), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
-                           d_trunc_bits, d_active, u);
+        hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) strips * n_frames * pieces), dim3(64), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
+                           d_trunc_bits, d_active, u, strips, n_frames, pieces);
         partials = strips * pieces;
     } else {
         hipLaunchKernelGGL(k_cols_inv_stream, dim3(ceil_div(g.nx, kStreamT), n_frames, pieces), dim3(kStreamT), 0, s, rb.A, rb.T, g, rb.np, rb.C,

@@ -183,17 +183,20 @@ def test_host_thread_budget_per_rank():
         a = subprocess.check_output([sys.executable, "-c", child], env=env).split()
         return int(a[0]), int(a[1]), int(a[2]), int(a[3]), float(a[4])
 
+    def width(cpus_, slices):
+        return max(1, min(64, cpus_ - (min(slices, 2) if cpus_ > 4 else 0)))
+
     env["EBCC_HOST_CPU_QUOTA"] = "0"                                              # no quota: the affinity mask counts
     one, four, cpus, usable, quota = run()
     assert usable == cpus and quota == 0
-    assert one == (cpus - 1 if cpus > 4 else cpus) and four == (cpus - 2 if cpus > 4 else cpus)
+    assert one == width(cpus, 1) and four == width(cpus, 4)
     env["EBCC_HOST_CPU_QUOTA"] = "16"                                             # the MI355X box: 16-CPU quota on a 256-thread host
     one, four, cpus, usable, quota = run()
     assert usable == min(cpus, 16) and quota == 16.0
-    assert four == (usable - 2 if usable > 4 else usable)
-    env["EBCC_HOST_CPU_QUOTA"] = "2.5"
+    assert four == width(min(cpus, 32), 4)                                        # (bursts up to twice the quota wide)
+    env["EBCC_HOST_CPU_QUOTA"] = "1.5"
     one, four, cpus, usable, quota = run()
-    assert usable == min(cpus, 3) and one == four == usable                       # (small shares: nothing set aside)
+    assert usable == min(cpus, 2) and one == four == min(cpus, 3)                 # (small shares: nothing set aside)
     env["EBCC_HOST_CPU_QUOTA"] = "0"
     env["LOCAL_WORLD_SIZE"] = "8"
     one, four, cpus, usable, quota = run()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HBM table of the bandwidth-bound kernels, each measured alone (EBCC_HIP_SLICES=1, 256 frames):
-    python3 tools/hbm_table.py <kernel_trace.csv> <FETCH_SIZE counter csv> <WRITE_SIZE counter csv> <frames> <sha> > profiles/r02_hbm_kernels.json
+    python3 tools/hbm_table.py <kernel_trace.csv> <FETCH_SIZE counter csv> <WRITE_SIZE counter csv> <frames> <sha> > profiles/r03_hbm_kernels.json
 The three CSVs come from three runs of the same deterministic command (tools/gpu/hbm_table.sh), so dispatch k of one
 run is dispatch k of the others; a row of the table is one (kernel, launch geometry) pair and reports the dispatches
 in which every frame of the batch was active (counter bytes within 10 % of the largest for that pair).
@@ -28,39 +28,44 @@ def short(name):
 
 def algo_bytes(kernel, rank, nkeys):
     """Bytes per frame the kernel must move by its role; `rank` = position of this launch geometry among the kernel's
-    geometries, largest first (level 5 / level 3 of the residual transform first)."""
-    k = kernel
-    if k.startswith("k_scale_shift"): return 2 * 4 * PIX, "read fp32 frame, write shifted fp32 samples"
-    if k.startswith("k_in_minmax"): return 4 * PIX, "read fp32 frame"
-    if k.startswith("k_quantize"): return 4 * PIX + 4 * PIX + PIX * 55 // 8, "read coefficients, write Q6 + 26 plane + sign + 28 suffix masks (1 bit each per sample)"
-    if k.startswith("k_j2k_level5_fin<true"): return 8 * PIX, "whole top level: read the four bands (LL fp32, rest int32) and the fp32 frame for the statistics (field kept: + 4 B/sample write)"
-    if k.startswith("k_j2k_level5_fin<false"):
+    geometries, largest first (level 5 / level 3 of the residual transform first).  Kernel names are matched whole
+    (k_rate is not k_rate_publish, k_residual_minmax is not k_residual_minmax_finish)."""
+    k = re.sub(r"<.*", "", kernel)                       # name without template arguments
+    targs = kernel[len(k):]
+    if k == "k_scale_shift": return 2 * 4 * PIX, "read fp32 frame, write shifted fp32 samples"
+    if k == "k_in_minmax": return 4 * PIX, "read fp32 frame"
+    if k == "k_quantize": return 4 * PIX + 4 * PIX + PIX * 55 // 8, "read coefficients, write Q6 + 26 plane + sign + 28 suffix masks (1 bit each per sample)"
+    if k == "k_j2k_level5_fin" and targs.startswith("<true"): return 8 * PIX, "whole top level: read the four bands (LL fp32, rest int32) and the fp32 frame for the statistics (field kept: + 4 B/sample write)"
+    if k == "k_j2k_level5_fin":
         lv = 4 - rank if rank < 4 else 1                 # geometries of levels 4, 3, 2, 1 - largest first
         w, h = RES[lv]
         return 8 * w * h, f"whole level {lv}: read the four bands, write {w}x{h} fp32"
-    if k.startswith("k_finest_inv_use"): return 4 * (NX * NY // 4) + 4 * 3 * (NX * NY // 4) + 8 * PIX, "finest residual level whole: LL read, the ordinals of three detail bands (+ coefficient and slot inside the prefix), frame and decoded field for the statistics"
-    if k.startswith("k_j2k_cols_fin"): return 8 * PIX, "level 5 columns: read the level and the fp32 frame (field kept: + 4 B/sample write)"
-    if k.startswith("k_rate"): return 300000, "per-pass rate / distortion tables (latency-bound: bisection)"
-    if k.startswith("k_t1_resume"): return 4 * PIX // 8, "a stripe or two of one coding pass per changed code-block (latency-bound)"
-    if k.startswith("k_j2k_rows") or k.startswith("k_j2k_cols"):
+    if k == "k_finest_inv_use": return 4 * (NX * NY // 4) + 4 * 3 * (NX * NY // 4) + 8 * PIX, "finest residual level whole: LL read, the ordinals of three detail bands (+ coefficient and slot inside the prefix), frame and decoded field for the statistics"
+    if k == "k_j2k_cols_fin": return 8 * PIX, "level 5 columns: read the level and the fp32 frame (field kept: + 4 B/sample write)"
+    if k in ("k_j2k_rows", "k_j2k_cols"):
         lv = 5 - rank if rank < 5 else 1
         w, h = RES[lv]
-        fin = "true>" in k.replace(" ", "") and k.startswith("k_j2k_cols<false")
+        fin = "true>" in targs.replace(" ", "") and k == "k_j2k_cols" and targs.startswith("<false")
         if fin: return 4 * w * h + 4 * PIX, f"level {lv}: read the level, read the fp32 frame for the statistics (field kept: + 4 B/sample write)"
         return 8 * w * h, f"level {lv}: read + write {w}x{h} fp32"
-    if k.startswith("k_pad_load"): return 8 * PIX + 4 * NY * NX, "read frame + decoded field, write padded grid"
-    if k.startswith("k_residual_minmax"): return 8 * PIX, "read frame + decoded field"
-    if re.match(r"k_(rows|cols)_(fwd|inv)", k):
+    if k == "k_j2k_cols_fwd_top": return 8 * PIX, "level 5: read the fp32 frame, write the column-transformed level"
+    if k == "k_pad_load": return 8 * PIX + 4 * NY * NX, "read frame + decoded field, write padded grid"
+    if k == "k_residual_minmax": return 8 * PIX, "read frame + decoded field"
+    if k in ("k_rows_fwd", "k_rows_inv", "k_cols_fwd", "k_cols_inv"):
         lv = rank                                  # 0 = full grid
         return 8 * (NX >> lv) * (NY >> lv), f"level {3 - lv}: read + write {(NX >> lv)}x{(NY >> lv)} fp32"
-    if k.startswith("k_cols_inv_stream"): return 12 * 3 * (NX * NY // 4) + 4 * (NX * NY // 4) + 4 * NX * NY, "finest level columns: three detail bands from the bookkeeping (coefficient + two ordinals), LL read, grid written"
-    if k.startswith("k_rows_inv_use"): return 4 * NX * NY + 8 * PIX, "read the grid, the frame and the decoded field (statistics only)"
-    if k.startswith("k_truncate"): return 8 * NX * NY, "read fp32 grid, write int32 coefficients"
-    if k.startswith("k_descmax"): return 12 * NX * NY, "read coefficients, write two maxima pyramids"
-    if k.startswith("k_reconstruct"): return 16 * NX * NY, "read coefficient + two ordinals, write fp32 grid"
-    if k.startswith("k_probe_init"): return 8 * PIX, "read Q6, write V (changed code-blocks only: upper bound)"
-    if k.startswith("k_distortion"): return 4 * PIX, "read Q6"
-    if k.startswith("k_int_to_float"): return 8 * NX * NY, "read int32, write fp32"
+    if k == "k_cols_inv_stream": return 12 * 3 * (NX * NY // 4) + 4 * (NX * NY // 4) + 4 * NX * NY, "finest level columns: three detail bands from the bookkeeping (coefficient + two ordinals), LL read, grid written"
+    if k == "k_rows_inv_use": return 4 * NX * NY + 8 * PIX, "read the grid, the frame and the decoded field (statistics only)"
+    if k == "k_truncate": return 8 * NX * NY, "read fp32 grid, write int32 coefficients"
+    if k == "k_descmax":
+        # one launch per level, coarsest parents last: level l reads the 2^-l x 2^-l grid of coefficients (or of maxima) and writes a quarter of it twice
+        n = (NX >> rank) * (NY >> rank)
+        return 4 * n + 2 * 4 * (n // 4), f"level {rank}: read {NX >> rank}x{NY >> rank} int32, write the two maxima of its parents"
+    if k == "k_reconstruct": return 16 * NX * NY, "read coefficient + two ordinals, write fp32 grid"
+    if k == "k_distortion": return 4 * PIX, "read Q6"
+    if k == "k_int_to_float": return 8 * NX * NY, "read int32, write fp32"
+    # latency-bound or data-dependent kernels (k_rate, k_t1_resume, the j2k k_probe_init, k_rate_publish, the *_finish sweeps ...)
+    # have no byte count by role: they are not rows of this table
     return None, ""
 
 
@@ -100,9 +105,16 @@ for (name, grid), lst in groups.items():
     cb = sum(b for _, b in full) / len(full)
     ab = a * frames
     gbps = ab / us / 1e3
-    rows.append({"kernel": name, "grid_threads": grid, "what": what, "dispatches": len(lst), "dispatches_all_frames_active": len(full),
-                 "duration_us": round(us, 1), "algorithmic_bytes": ab, "counter_bytes": int(cb), "counter_over_algorithmic": round(cb / ab, 2),
-                 "achieved_GBps": round(gbps, 1), "frac_of_8000": round(gbps / 8000, 4), "frac_of_6290": round(gbps / 6290, 4)})
+    if grid < 65536:
+        continue                                     # (a launch of a few hundred threads is not a bandwidth measurement)
+    row = {"kernel": name, "grid_threads": grid, "what": what, "dispatches": len(lst), "dispatches_all_frames_active": len(full),
+           "duration_us": round(us, 1), "algorithmic_bytes": ab, "counter_bytes": int(cb), "counter_over_algorithmic": round(cb / ab, 2),
+           "achieved_GBps": round(gbps, 1), "frac_of_8000": round(gbps / 8000, 4), "frac_of_6290": round(gbps / 6290, 4)}
+    if cb < 0.5 * ab:
+        # the input was written by the kernel before and is still in the 256 MB Infinity Cache: not an HBM rate
+        row["cache_served"] = True
+        row["frac_of_8000"] = row["frac_of_6290"] = None
+    rows.append(row)
 rows.sort(key=lambda r: (-r["duration_us"] * r["dispatches"]))
 print(json.dumps({"frames_per_dispatch": frames, "kernel_sources_sha": sha, "unmatched_dispatches": mismatch,
                   "note": "EBCC_HIP_SLICES=1: every kernel runs alone; durations from rocprofv3 --kernel-trace, bytes from separate --pmc FETCH_SIZE / WRITE_SIZE runs",

@@ -416,7 +416,7 @@ struct SliceGate {
 
 constexpr int kJ2kMainHeaderBytes = 135;     // SOC, SIZ, COD, QCD, COM of every codestream the codec writes
 
-struct ProbeRec { float cr = -1; unsigned long long nbad = 0; int stream_bytes = 0; double err_sum = 0; };
+struct ProbeRec { float cr = -1; unsigned long long nbad = 0; int stream_bytes = 0; double err_sum = 0; bool complete = true; };
 
 struct Job {                     // host-side state of one frame being encoded
     bool const_field = false;
@@ -877,12 +877,12 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
         c.state_cr = b.state_cr[f];
         c.q = j.q;
         c.n_probes = (int) std::min<size_t>(j.probes.size(), kMaxProbes);
-        for (int i = 0; i < c.n_probes; i++) c.probes[i] = DevProbe{j.probes[i].cr, j.probes[i].stream_bytes, j.probes[i].nbad, j.probes[i].err_sum};
+        for (int i = 0; i < c.n_probes; i++) c.probes[i] = DevProbe{j.probes[i].cr, j.probes[i].stream_bytes, j.probes[i].nbad, j.probes[i].err_sum, j.probes[i].complete ? 1 : 0, 0};
         const RateSearch &r = j.rs[k];
         DevRateSearch &o = c.rs[k];
         o.lo = r.lo; o.hi = r.hi; o.cr = r.cr; o.result = r.result; o.pending = r.pending; o.phase = j.const_field ? 6 : r.phase;
         o.q = r.q; o.q0 = r.q0; o.qt = r.qt; o.want = 0; o.want_cr = 0;
-        o.last = DevProbe{j.last[k].cr, j.last[k].stream_bytes, j.last[k].nbad, j.last[k].err_sum};
+        o.last = DevProbe{j.last[k].cr, j.last[k].stream_bytes, j.last[k].nbad, j.last[k].err_sum, 1, 0};
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(int) * 4, s));
@@ -928,7 +928,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
         j.last[k] = ProbeRec{o.last.cr, o.last.nbad, o.last.stream_bytes, o.last.err_sum};
         if (k == 0) j.q = c.q;
         j.probes.clear();
-        for (int i = 0; i < c.n_probes; i++) j.probes.push_back(ProbeRec{c.probes[i].cr, c.probes[i].nbad, c.probes[i].stream_bytes, c.probes[i].err_sum});
+        for (int i = 0; i < c.n_probes; i++) j.probes.push_back(ProbeRec{c.probes[i].cr, c.probes[i].nbad, c.probes[i].stream_bytes, c.probes[i].err_sum, c.probes[i].complete != 0});
         b.state_cr[f] = c.state_cr;
     }
     b.fetch_jf(s);                                                        // (the host mirror of the per-frame scalars follows the device again)
@@ -1059,6 +1059,22 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 else jobs[f].rs[1].start(cfg->base_cr, jobs[f].q_first, 1.0);                 // :829-833 == the first probe
             }
         };
+        // ---- the pure base-layer search (:819-836) depends on nothing the residual layer produces: its rounds are queued on the
+        //      engine's second stream now (own state, counters and mask: device_rate_search lane 1) and run beside the residual
+        //      layer and the truncation search; it is taken up again where the reference runs it (below).  Round 2 measured
+        //      this slower - the search was hidden behind the level-22 zstd of every prefix then; with the entropy stage cut
+        //      down to the prefixes whose size can matter, the search was what the slice waited for, and its sizes are what
+        //      decides which prefixes those are.  EBCC_HIP_SEARCH2_SERIAL=1: in the reference's place.
+        const bool overlap2 = want_pure && tiles == 1 && rc == ctx && !getenv("EBCC_HIP_HOST_SEARCH") && !getenv("EBCC_HIP_SEARCH2_SERIAL");
+        struct DrainSecond {               // an error return between here and the take-up must not leave rounds in flight
+            ebcc_hip_ctx *c; bool armed;
+            ~DrainSecond() { if (armed && c->stream2) hipStreamSynchronize(c->stream2); }
+        } drain2{ctx, false};
+        if (overlap2) {
+            start_search2();
+            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart);
+            drain2.armed = true;
+        }
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
         fetch_frame_states(rc, n);
         bool any_resid = false;
@@ -1288,26 +1304,41 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             // microseconds per KB), then - the search still running on the GPU, len2 not known yet - zstd of the
             // candidates in the order in which they are likely to need it (lowest floor per byte first); the moment the
             // search's sizes are in, the candidates they decide are struck from the queue.
-            start_search2();
             const bool host_loop = getenv("EBCC_HIP_HOST_SEARCH") != nullptr;
-            if (!host_loop) device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchStart);
-            if (!cand.empty()) {
-                if (!zjoin()) return 1;                                                       // (the floors - and with them the prefixes too long for one)
-                std::vector<size_t> spec = cand;
-                std::stable_sort(spec.begin(), spec.end(), [&](size_t a, size_t c) {
-                    return (double) zfloor[a] * (double) jobs[c].coeffs_size < (double) zfloor[c] * (double) jobs[a].coeffs_size; });
-                submit_zstd(spec);
+            if (overlap2) {
+                // the search has been running beside the residual layer: its sizes are (nearly) there, the floors take a
+                // millisecond - the prefixes that are still open after that are compressed, longest first
+                device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchFinish);              // :836
+                drain2.armed = false;
+                pt.mark("rate search 2");
+                if (!zjoin()) return 1;                                                       // (the floors)
+            } else {
+                start_search2();
+                if (!host_loop) device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchStart);
+                if (!cand.empty()) {
+                    if (!zjoin()) return 1;                                                   // (the floors - and with them the prefixes too long for one)
+                    std::vector<size_t> spec = cand;
+                    std::stable_sort(spec.begin(), spec.end(), [&](size_t a, size_t c) {
+                        return (double) zfloor[a] * (double) jobs[c].coeffs_size < (double) zfloor[c] * (double) jobs[a].coeffs_size; });
+                    submit_zstd(spec);
+                }
+                if (host_loop) run_search(b, 1, jobs, n_pix); else device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchFinish);   // :836
+                pt.mark("rate search 2");
             }
-            if (host_loop) run_search(b, 1, jobs, n_pix); else device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchFinish);   // :836
-            pt.mark("rate search 2");
             long long skipped_bytes = 0, skipped = 0;
             for (size_t f : cand) {
                 const Job &j = jobs[f];
                 const size_t len2 = (size_t) j.last[1].stream_bytes;
                 // z >= zfloor: len2 < zfloor + len1 implies len2 < z + len1 - the base layer alone wins (:838)
                 if (!(zfloor[f] > 0 && len2 < zfloor[f] + j.len1)) continue;
-                uint8_t expect = kZQueued;
+                uint8_t expect = overlap2 ? kZNone : kZQueued;
                 if (zstate[f].compare_exchange_strong(expect, kZSkipped)) { skipped++; skipped_bytes += (long long) j.coeffs_size; }
+            }
+            if (overlap2) {
+                std::vector<size_t> open;
+                for (size_t f : cand) if (zstate[f] == kZNone) open.push_back(f);
+                longest_first(open);
+                if (!open.empty()) submit_zstd(open);
             }
             if (!zjoin()) return 1;
             pt.mark("zstd: wait for the workers");
@@ -1896,6 +1927,10 @@ int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) 
 // out[0..6] = usable CPUs (affinity mask cut to the cgroup quota), CPU quota (0: none), zstd core-seconds, seconds the
 // slices waited for the zstd workers, bytes compressed, entropy batches, prefix bytes whose compression was proved
 // unnecessary - since the last call with reset != 0
+// arithmetic identities the kernels rely on, checked on the host (0 = all hold): the division-free s / 65535.0f of the fused
+// inverse level for every s in [0, 65535]
+int ebcc_hip_selfcheck(void) { return j2k_selfcheck_div65535(); }
+
 // the lower bound of zstd_size_lower_bound (0: not applicable - longer than 128 KB, or a libzstd that may split blocks)
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n) { return zstd_floor_usable() ? zstd_size_lower_bound(src, n) : 0; }
 

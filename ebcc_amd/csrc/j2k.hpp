@@ -168,6 +168,7 @@ enum T1Kernel { T1_ENCODE = 0, T1_MQ = 1, T1_RESUME = 2, T1_DECODE = 3 };
 int t1_lanes_per_wave(int kernel, int total_blocks = 0);   // (total_blocks: code-blocks in the launch, for the encoder kernels)
 
 J2kGeom make_j2k_geom(int H, int W, std::vector<J2kBlock> &blocks, int ty0 = 0);
+int j2k_selfcheck_div65535();   // mismatches of the division-free s / 65535.0f of the fused inverse level (0 expected)
 
 // ---- launchers (asynchronous on s) ---------------------------------------------------------------
 // check_nan_inf + findMinMaxf (ebcc_codec.c:598-605,515-533) -> fs.minv/maxv/const_field/has_nonfinite

@@ -583,10 +583,23 @@ struct ColPipe {
 // The WHOLE last inverse level (horizontal then vertical, opj_dwt_decode_tile_97 at the top resolution) with
 // dequantisation, field mapping and statistics in one pass over the data: a wave owns 60 sample pairs of the width
 // (+ 2 pairs of halo on either side), one pair per lane; for every vertical position it synthesises the low-pass and
-// the high-pass row horizontally in registers (neighbours through wave shuffles) and feeds two ColPipes, one per
+// the high-pass row horizontally in registers (neighbours through DPP wave shifts) and feeds two ColPipes, one per
 // column of the pair.  Nothing is written but the fp32 field (if wanted) and the statistics: against the separate
 // row and column passes this saves one write and one read of the frame per probe.  cas == 0 frames only.
+//
+// Round 3.  The kernel runs 34 times per frame and was thought to be HBM-bound with a 2x over-fetch; it was bound by
+// VALU issue (~600 wave-instructions per iteration of 240 samples: boundary tests on every step, 26 LDS-crossbar
+// shuffles, four correctly rounded divisions by 65535, four fp64 accumulations) AND moved 1.7-2x its bytes (the strips of
+// a frame are 240-byte column ranges with halo, not multiples of a 128-byte line: the lines two strips share were fetched
+// once per strip, because neighbouring strips ran as independent workgroups on different XCDs or microseconds apart).
+// Now: (1) the strips of a (frame, piece) tile are the WAVES OF ONE WORKGROUP - same CU, same instruction stream, started
+// together - so a shared line is fetched once and found in the CU's L1 by the neighbour; (2) the vertical positions away
+// from the top and bottom edge take a step without any boundary test (ColPipe::step_interior), (3) neighbours come
+// through v_mov_dpp wave shifts, (4) s / 65535.0f is fmaf(s, K_hi, s * K_lo) - equal to the correctly rounded quotient for
+// every integer s in [0, 65535] (div65535_exact; checked exhaustively by ebcc_hip_selfcheck and tests/test_boundary.py),
+// (5) frame samples and field leave / arrive as 8-byte pairs.
 constexpr int kL5Pairs = 60;
+constexpr int kL5MaxWaves = 16;       // strips (waves) of one workgroup
 // FIN = false: the same pass for a lower level r - the synthesised samples go to `out` (pitch out_pitch) as they are, the
 // next level's low-pass band.  Out of place: the level's output region covers its own LL input, so the levels alternate
 // between two buffers.  LL comes from `ll` (pitch ll_pitch), or for level 1 from the decoder's output like the other bands.
@@ -595,23 +608,90 @@ struct J2kLevelIO {
     float *out; int out_pitch; size_t out_frame;         // FIN = false only
     int r;
 };
+// value of the lane below / above (lane 0 / lane 63 keep their own): __shfl_up / __shfl_down by one as a single DPP move
+__device__ inline float lane_below(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ inline float lane_above(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+// s / 65535.0f for an integer-valued s in [0, 65535], without the division: K_hi + K_lo = 1 / 65535 to 2^-49, one rounding
+// at the end; the quotient's binary expansion repeats with period 16, so it is never within 2^-40 of a rounding boundary.
+__host__ __device__ inline float div65535_exact(float s)
+{
+    const float k_hi = 1.5259021893143654e-05f, k_lo = 3.552767888909125e-15f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmaf_rn(s, k_hi, __fmul_rn(s, k_lo));
+#else
+    return std::fma(s, k_hi, s * k_lo);
+#endif
+}
+// fin_map without 64-bit integers: rint, level shift, clamp in fp32 (exact: below 2^23 every step is; beyond, the sum only
+// has to stay outside [0, 65535], which it does), then the map to the field
+__device__ inline float fin_map_fast(float v, float rng, float mn)
+{
+    const float q = __builtin_amdgcn_fmed3f(__builtin_rintf(v) + 32768.0f, 0.0f, 65535.0f);
+    return div65535_exact(q) * rng + mn;
+}
+// the interior step of ColPipe: 2 <= j < dn (every neighbour exists); hands out the samples of position j - 2
+struct ColPipe2 {
+    float o0_prev = 0, e1_prev = 0, o1_prev = 0, e2_prev = 0;
+    __device__ void interior(float lo_raw, float hi_raw, float &even, float &odd)
+    {
+        const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
+        const float e0 = lo_raw * kK, o0 = hi_raw * kTwoInvK;
+        const float e1 = e0 + ((o0_prev + o0) * c1);
+        const float o1 = o0_prev + ((e1_prev + e1) * c2);
+        const float e2 = e1_prev + ((o1_prev + o1) * c3);
+        even = e2_prev;
+        odd = o1_prev + ((e2_prev + e2) * c4);
+        o0_prev = o0; e1_prev = e1; o1_prev = o1; e2_prev = e2;
+    }
+    // any position (the edges): the forms of ColPipe::step; has_even / has_odd say which of the two samples exist
+    __device__ void edge(int j, int sn, int dn, float lo_raw, float hi_raw, float &even, float &odd, bool &has_even, bool &has_odd)
+    {
+        const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
+        float e1 = 0, o0 = 0;
+        if (j < sn) {
+            const float e0 = lo_raw * kK;
+            if (j < dn) o0 = hi_raw * kTwoInvK;
+            if (j < dn) e1 = e0 + (((j == 0 ? o0 : o0_prev) + o0) * c1);
+            else        e1 = e0 + (o0_prev * (c1 + c1));
+        }
+        float o1 = 0;
+        const int i1 = j - 1;
+        if (i1 >= 0 && i1 < dn) o1 = (i1 + 1 < sn) ? o0_prev + ((e1_prev + e1) * c2) : o0_prev + (e1_prev * (c2 + c2));
+        float e2 = 0;
+        if (i1 >= 0 && i1 < sn) e2 = (i1 < dn) ? e1_prev + (((i1 == 0 ? o1 : o1_prev) + o1) * c3) : e1_prev + (o1_prev * (c3 + c3));
+        const int i2 = j - 2;
+        has_even = i2 >= 0 && i2 < sn; has_odd = i2 >= 0 && i2 < dn;
+        even = e2_prev;
+        odd = (i2 + 1 < sn) ? o1_prev + ((e2_prev + e2) * c4) : o1_prev + (e2_prev * (c4 + c4));
+        o0_prev = o0; e1_prev = e1; o1_prev = o1; e2_prev = e2;
+    }
+};
 template <bool FIN>
-__global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int32_t *__restrict__ V, const J2kGeom *geom,
+__global__ __launch_bounds__(64 * kL5MaxWaves) void k_j2k_level5_fin(J2kLevelIO io, const int32_t *__restrict__ V, const J2kGeom *geom,
                                                         const FrameState *fs, const int *active, J2kFinish fin, int strips, int n_frames, int pieces)
 {
-    const TileOfBlock tb = xcd_tile_of_block(blockIdx.x, (unsigned) strips, (unsigned) n_frames, (unsigned) pieces);   // (1-D launch, common.hpp)
-    const int frame = tb.frame;
+    // workgroup = the strips (up to 16, one per wave) of tile blockIdx.y = piece * n_frames + frame: piece-major, so that
+    // every frame's first pieces are dispatched first (the early exit below relies on that order for speed only)
+    const int lane = (int) threadIdx.x & 63, strip = (int) blockIdx.x * ((int) blockDim.x >> 6) + ((int) threadIdx.x >> 6);
+    const int frame = (int) blockIdx.y % n_frames, piece = (int) blockIdx.y / n_frames;
+    if (strip >= strips) return;                                        // (no barrier anywhere below)
     if ((active && !active[frame]) || (fs && fs[frame].const_field)) return;
     const J2kGeom &g = j2k_frame_geom(geom, frame);
     const int r = FIN ? kJ2kRes - 1 : io.r;
     const int W = g.W, nh = g.rw[r], snh = g.rw[r - 1], dnh = nh - snh;          // horizontal: samples, low-pass, high-pass
     const int nv = g.rh[r], snv = g.rh[r - 1], dnv = nv - snv;                   // vertical
     const size_t n_pix = (size_t) W * g.H;
-    const int i = tb.strip * kL5Pairs + (int) threadIdx.x - 2;                   // this lane's pair
+    const int i = strip * kL5Pairs + lane - 2;                                   // this lane's pair
     const bool has_e = i >= 0 && i < snh, has_o = i >= 0 && i < dnh;
-    const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kL5Pairs && has_e;    // (halo lanes compute, owners put out)
+    const bool owner = lane >= 2 && lane < 2 + kL5Pairs && has_e;                // (halo lanes compute, owners put out)
     const float *b = io.ll ? io.ll + (size_t) frame * io.ll_frame : nullptr;
-    const size_t lp = (size_t) io.ll_pitch;
+    const unsigned lp = (unsigned) io.ll_pitch;
     const int32_t *v = V + (size_t) frame * n_pix;
     const float s_ll = 0.5f * g.bands[0].step_dec, s_hl = 0.5f * g.bands[3 * (r - 1) + 1].step_dec, s_lh = 0.5f * g.bands[3 * (r - 1) + 2].step_dec,
                 s_hh = 0.5f * g.bands[3 * (r - 1) + 3].step_dec;
@@ -621,85 +701,130 @@ __global__ __launch_bounds__(64) void k_j2k_level5_fin(J2kLevelIO io, const int3
     const float mn = fs[frame].minv, rng = fs[frame].maxv - fs[frame].minv;
     const float target = x ? fin.jf[frame].target : 0.0f;
     const float c1 = -kD, c2 = -kG, c3 = -kB, c4 = -kA;
+    const bool first = i == 0, no_o = !(i < dnh), last_o = !(i + 1 < snh);
     // horizontal synthesis of one row: the pair's low-/high-pass inputs -> its two output samples (idwt_tile, cas 0)
     auto hsynth = [&](float e_raw, float o_raw, float &even, float &odd) {
         const float e0 = has_e ? e_raw * kK : 0.0f, o0 = has_o ? o_raw * kTwoInvK : 0.0f;
-        const float o0l = __shfl_up(o0, 1);
-        const float e1 = i < dnh ? e0 + (((i == 0 ? o0 : o0l) + o0) * c1) : e0 + (o0l * (c1 + c1));
-        const float e1r = __shfl_down(e1, 1);
-        const float o1 = i + 1 < snh ? o0 + ((e1 + e1r) * c2) : o0 + (e1 * (c2 + c2));
-        const float o1l = __shfl_up(o1, 1);
-        const float e2 = i < dnh ? e1 + (((i == 0 ? o1 : o1l) + o1) * c3) : e1 + (o1l * (c3 + c3));
-        const float e2r = __shfl_down(e2, 1);
+        const float o0l = lane_below(o0);
+        const float e1 = no_o ? e0 + (o0l * (c1 + c1)) : e0 + (((first ? o0 : o0l) + o0) * c1);
+        const float e1r = lane_above(e1);
+        const float o1 = last_o ? o0 + (e1 * (c2 + c2)) : o0 + ((e1 + e1r) * c2);
+        const float o1l = lane_below(o1);
+        const float e2 = no_o ? e1 + (o1l * (c3 + c3)) : e1 + (((first ? o1 : o1l) + o1) * c3);
+        const float e2r = lane_above(e2);
         even = e2;
-        odd = i + 1 < snh ? o1 + ((e2 + e2r) * c4) : o1 + (e2 * (c4 + c4));
+        odd = last_o ? o1 + (e2 * (c4 + c4)) : o1 + ((e2 + e2r) * c4);
     };
-    double acc = 0;
-    unsigned int bad = 0;
-    ColPipe p0, p1;
-    // every lane loads every step (halo and out-of-range lanes from clamped positions, their results are dropped), and
-    // the inputs of step j + 1 are requested before step j is computed: no divergent control flow around the memory
-    // accesses, one row of latency in flight
-    const size_t c_lo = (size_t) min(max(i, 0), snh - 1), c_hi = (size_t) snh + (size_t) min(max(i, 0), max(dnh - 1, 0));
-    const size_t c0 = (size_t) min(max(2 * i, 0), nh - 1), c1x = (size_t) min(max(2 * i + 1, 0), nh - 1);
-    float in_ll, in_hl, in_lh, in_hh;
-    auto fetch = [&](int j, float &ll, float &hl, float &lh, float &hh) {
-        const size_t rl = (size_t) min(j, snv - 1) * W, rh = (size_t) (snv + min(j, max(dnv - 1, 0))) * W;
-        ll = b ? b[(size_t) min(j, snv - 1) * lp + c_lo] : (float) v[rl + c_lo] * s_ll;
-        hl = (float) v[rl + c_hi] * s_hl;
-        lh = (float) v[rh + c_lo] * s_lh;
-        hh = (float) v[rh + c_hi] * s_hh;
-    };
-    // the vertical extent is cut into gridDim.z pieces (more waves in flight): a piece puts out positions [ja, jb) and
-    // starts its pipeline two positions early - an output depends on the inputs of positions i - 2 .. i + 2 only
-    const int per = ceil_div(snv, pieces), ja = tb.piece * per, jb = min(snv, ja + per);
-    const size_t part = (size_t) frame * kPartials + (size_t) (tb.strip + strips * tb.piece);   // this workgroup's partial sums
+    const int per = ceil_div(snv, pieces), ja = piece * per, jb = min(snv, ja + per);
+    const size_t part = (size_t) frame * kPartials + (size_t) (strip + strips * piece);   // this wave's partial sums
+    if (ja >= jb) {                                                     // (more pieces than positions: nothing to put out)
+        if (FIN && x && lane == 0) { fin.partial[part] = 0.0; fin.partial_u[part] = 0; }
+        return;
+    }
     const int jstart = max(ja - 2, 0);
     // statistics-only probes of the rate search stop once the frame has gathered bad_limit samples above the target
     // (J2kFrame::bad_limit): the pieces are dispatched piece-major over all frames, so the later pieces of a frame that
-    // is clearly infeasible at this rate leave without reading their strip
+    // is clearly infeasible at this rate leave without reading their strip.
     unsigned int limit = 0;
+    // (the error sum is taken by every probe: a search's result often rests on a probe that was made to steer it - the final
+    //  probe of the pure base-layer search is normally one already on record)
+    const bool need_sum = true;
     if constexpr (FIN) {
         if (x && !d) {
             limit = fin.jf[frame].bad_limit;
             if (limit && __hip_atomic_load(&fin.jf[frame].bad_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit) {
-                if (threadIdx.x == 0) { fin.partial[part] = 0.0; fin.partial_u[part] = 0; }
+                if (lane == 0) { fin.partial[part] = 0.0; fin.partial_u[part] = 0; }
                 return;
             }
         }
     }
+    double acc = 0;
+    unsigned int bad = 0;
+    ColPipe2 p0, p1;
+    // every lane loads every step (halo and out-of-range lanes from clamped positions, their results are dropped), and
+    // the inputs of step j + 1 are requested before step j is computed: no divergent control flow around the memory
+    // accesses, one row of latency in flight.  32-bit offsets from uniform bases.
+    const unsigned c_lo = (unsigned) min(max(i, 0), snh - 1), c_hi = (unsigned) snh + (unsigned) min(max(i, 0), max(dnh - 1, 0));
+    const unsigned c0 = (unsigned) min(max(2 * i, 0), nh - 1), c1x = (unsigned) min(max(2 * i + 1, 0), nh - 1);
+    // 8-byte accesses of the output pair (and of the frame's samples beside it): even widths and 8-byte aligned bases
+    const bool pair_io = (W & 1) == 0 && (nh & 1) == 0 && (n_pix & 1) == 0 && (((size_t) x | (size_t) d | (size_t) o) & 7) == 0 &&
+                         (!FIN ? (io.out_pitch & 1) == 0 && (io.out_frame & 1) == 0 : true);
+    float in_ll, in_hl, in_lh, in_hh;
+    auto fetch = [&](int j, float &ll, float &hl, float &lh, float &hh) {
+        const unsigned jl = (unsigned) min(j, snv - 1), jh = (unsigned) (snv + min(j, max(dnv - 1, 0)));
+        const unsigned rl = jl * (unsigned) W, rh = jh * (unsigned) W;
+        ll = b ? b[jl * lp + c_lo] : (float) v[rl + c_lo] * s_ll;
+        hl = (float) v[rl + c_hi] * s_hl;
+        lh = (float) v[rh + c_lo] * s_lh;
+        hh = (float) v[rh + c_hi] * s_hh;
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // what happens to the two finished samples (columns 2i, 2i + 1) of output row y
+    auto put_row = [&](bool emit, int y, float ev, float od, float xe, float xo, bool has_odd_col) {
+        if constexpr (!FIN) {
+            if (!emit) return;
+            float *q = o + (size_t) ((unsigned) y * (unsigned) io.out_pitch + 2u * (unsigned) i);
+            if (pair_io) *reinterpret_cast<f32x2 *>(q) = f32x2{ev, od};
+            else { q[0] = ev; if (has_odd_col) q[1] = od; }
+            return;
+        } else {
+            const float de = fin_map_fast(ev, rng, mn), dq = fin_map_fast(od, rng, mn);
+            if (d && emit) {
+                float *q = d + ((unsigned) y * (unsigned) W + 2u * (unsigned) i);
+                if (pair_io) *reinterpret_cast<f32x2 *>(q) = f32x2{de, dq};
+                else { q[0] = de; if (has_odd_col) q[1] = dq; }
+            }
+            if (x) {
+                const float e0 = xe - (de + 0.0f), e1 = xo - (dq + 0.0f);
+                const bool m0 = emit, m1 = emit && has_odd_col;
+                bad += (m0 && fabsf(e0) > target) ? 1u : 0u;
+                bad += (m1 && fabsf(e1) > target) ? 1u : 0u;
+                if (need_sum) { acc += m0 ? (double) e0 : 0.0; acc += m1 ? (double) e1 : 0.0; }
+            }
+        }
+    };
     fetch(jstart, in_ll, in_hl, in_lh, in_hh);
     for (int j = jstart; j < jb + 2; j++) {
         float n_ll, n_hl, n_lh, n_hh;
         fetch(j + 1, n_ll, n_hl, n_lh, n_hh);
         // the frame's samples at the four positions this step puts out (rows 2 (j - 2) and the next, this pair's columns)
-        const int y0 = min(max(2 * (j - 2), 0), nv - 1), y1 = min(max(2 * (j - 2) + 1, 0), nv - 1);
         float x00 = 0, x01 = 0, x10 = 0, x11 = 0;
-        if (x) { x00 = x[(size_t) y0 * W + c0]; x01 = x[(size_t) y0 * W + c1x]; x10 = x[(size_t) y1 * W + c0]; x11 = x[(size_t) y1 * W + c1x]; }
-        float lo_even = 0, lo_odd = 0, hi_even = 0, hi_odd = 0;
-        if (j < snv) hsynth(in_ll, in_hl, lo_even, lo_odd);              // (uniform) low-pass row j: LL from the previous level, HL from the decoder
-        if (j < dnv) hsynth(in_lh, in_hh, hi_even, hi_odd);              // high-pass row j: LH, HH
-        auto put = [&](bool mine, int col, int y, float val, float xv) {
-            if constexpr (!FIN) {
-                if (mine) o[(size_t) y * (size_t) io.out_pitch + (size_t) col] = val;
-                return;
+        if (x) {
+            const unsigned y0 = (unsigned) min(max(2 * (j - 2), 0), nv - 1), y1 = (unsigned) min(max(2 * (j - 2) + 1, 0), nv - 1);
+            if (pair_io) {
+                const f32x2 a = *reinterpret_cast<const f32x2 *>(x + (y0 * (unsigned) W + c0)), c = *reinterpret_cast<const f32x2 *>(x + (y1 * (unsigned) W + c0));
+                x00 = a.x; x01 = a.y; x10 = c.x; x11 = c.y;
+            } else {
+                x00 = x[y0 * (unsigned) W + c0]; x01 = x[y0 * (unsigned) W + c1x]; x10 = x[y1 * (unsigned) W + c0]; x11 = x[y1 * (unsigned) W + c1x];
             }
-            const float dv = fin_map(val, rng, mn);
-            if (d && mine) d[(size_t) y * W + (size_t) col] = dv;
-            if (x) {
-                const float e = xv - (dv + 0.0f);
-                acc += mine ? (double) e : 0.0;
-                bad += (mine && fabsf(e) > target) ? 1u : 0u;
-            }
-        };
+        }
         const bool emit = owner && j - 2 >= ja;                          // (positions before the piece belong to its neighbour)
-        p0.step(j, snv, dnv, lo_even, hi_even, [&](int y, float val) { put(emit, 2 * i, y, val, (y & 1) ? x10 : x00); });
-        p1.step(j, snv, dnv, lo_odd, hi_odd, [&](int y, float val) { put(emit && has_o, 2 * i + 1, y, val, (y & 1) ? x11 : x01); });
+        float lo_even = 0, lo_odd = 0, hi_even = 0, hi_odd = 0;
+        if (j >= 2 && j < dnv) {                                         // (uniform) every vertical neighbour exists: no boundary forms
+            hsynth(in_ll, in_hl, lo_even, lo_odd);                       // low-pass row j: LL from the previous level, HL from the decoder
+            hsynth(in_lh, in_hh, hi_even, hi_odd);                       // high-pass row j: LH, HH
+            float a0, a1, b0, b1;
+            p0.interior(lo_even, hi_even, a0, a1);                       // column 2i: rows 2 (j - 2), 2 (j - 2) + 1
+            p1.interior(lo_odd, hi_odd, b0, b1);                         // column 2i + 1
+            put_row(emit, 2 * (j - 2), a0, b0, x00, x01, has_o);
+            put_row(emit, 2 * (j - 2) + 1, a1, b1, x10, x11, has_o);
+        } else {
+            if (j < snv) hsynth(in_ll, in_hl, lo_even, lo_odd);
+            if (j < dnv) hsynth(in_lh, in_hh, hi_even, hi_odd);
+            float a0, a1, b0, b1;
+            bool he, ho, he1, ho1;
+            p0.edge(j, snv, dnv, lo_even, hi_even, a0, a1, he, ho);
+            p1.edge(j, snv, dnv, lo_odd, hi_odd, b0, b1, he1, ho1);
+            // (he / ho are uniform: whether rows 2 (j - 2) and 2 (j - 2) + 1 exist)
+            if (he) put_row(emit, 2 * (j - 2), a0, b0, x00, x01, has_o);
+            if (ho) put_row(emit, 2 * (j - 2) + 1, a1, b1, x10, x11, has_o);
+            (void) he1; (void) ho1;
+        }
         in_ll = n_ll; in_hl = n_hl; in_lh = n_lh; in_hh = n_hh;
     }
     if (x) {
         for (int k = 32; k >= 1; k >>= 1) { acc += __shfl_xor(acc, k); bad += __shfl_xor(bad, k); }
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             fin.partial[part] = acc;
             fin.partial_u[part] = bad;
             if (limit && bad) atomicAdd(&fin.jf[frame].bad_seen, bad);
@@ -1580,16 +1705,18 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
         if (r >= first_fused) {
             const int strips = ceil_div(g.rw[r - 1], kL5Pairs);
             // (the top level in more, shorter pieces: a piece is what an infeasible probe can skip)
-            const int pieces = std::max(1, std::min({r == kJ2kRes - 1 ? 8 : 4, kPartials / strips, g.rh[r - 1] / 16}));
+            int pieces = std::max(1, std::min({r == kJ2kRes - 1 ? 8 : 4, kPartials / strips, g.rh[r - 1] / 16}));
+            while (pieces > 1 && (long long) n_frames * pieces > 65535) pieces--;            // (grid y)
+            const int wg = std::min(strips, kL5MaxWaves), groups = ceil_div(strips, wg);    // the strips of a tile: waves of one workgroup
             if (r > 1 && !ll) ll = B;                                   // (the separate passes below left their result in B)
             J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};
             if (r == kJ2kRes - 1) {
                 partials = strips * pieces;
-                hipLaunchKernelGGL(k_j2k_level5_fin<true>, dim3((unsigned) strips * n_frames * pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active,
+                hipLaunchKernelGGL(k_j2k_level5_fin<true>, dim3((unsigned) groups, (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, io, V, jb.d_geom, fs, active,
                                    J2kFinish{data, keep_field ? jb.DEC : nullptr, jb.jf, jb.partial, jb.partial_u, keep_field == 2}, strips, n_frames, pieces);
             } else {
                 io.out = ll == spare ? B : spare;                         // never the buffer the level reads from
-                hipLaunchKernelGGL(k_j2k_level5_fin<false>, dim3((unsigned) strips * n_frames * pieces), dim3(64), 0, s, io, V, jb.d_geom, fs, active, J2kFinish{}, strips, n_frames, pieces);
+                hipLaunchKernelGGL(k_j2k_level5_fin<false>, dim3((unsigned) groups, (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, io, V, jb.d_geom, fs, active, J2kFinish{}, strips, n_frames, pieces);
                 ll = io.out;
             }
             continue;
@@ -1600,6 +1727,17 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
     }
     EBCC_HIP_LAUNCH_CHECK();
     return partials;
+}
+
+// host check of div65535_exact against the division it replaces, for every value it is used on (ebcc_hip_selfcheck)
+int j2k_selfcheck_div65535()
+{
+    int bad = 0;
+    for (int q = 0; q <= 65535; q++) {
+        const volatile float s = (float) q;
+        if (div65535_exact(s) != s / 65535.0f) bad++;
+    }
+    return bad;
 }
 
 }  // namespace ebcc

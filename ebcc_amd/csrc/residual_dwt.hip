@@ -442,11 +442,15 @@ __global__ __launch_bounds__(kStreamT) void k_cols_inv_stream(const float *__res
 // column pass's result nor the grid is written: one write and one read of the padded frame less per probe.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFusePairs = 60;
-__global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__ src, Grid g, size_t np, const int32_t *__restrict__ Cb,
+constexpr int kFuseMaxWaves = 16;
+__global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const float *__restrict__ src, Grid g, size_t np, const int32_t *__restrict__ Cb,
                                                         const uint32_t *__restrict__ sigordb, const uint32_t *__restrict__ lspidxb,
                                                         const unsigned long long *trunc_bits, const int *active, RowUse u, int strips, int n_frames, int pieces)
 {
-    const TileOfBlock tb = xcd_tile_of_block(blockIdx.x, (unsigned) strips, (unsigned) n_frames, (unsigned) pieces);   // (1-D launch: the strips of a tile on one XCD, common.hpp)
+    // workgroup = the strips (one per wave, up to 16) of tile blockIdx.y = piece * n_frames + frame: the column ranges of
+    // neighbouring strips share 128-byte lines and the halo - as waves of one workgroup they run on one CU in step and the
+    // shared lines are fetched once (k_j2k_level5_fin, j2k_analysis.hip, has the measurements)
+    struct { int strip, frame, piece; } tb{(int) blockIdx.x * ((int) blockDim.x >> 6) + ((int) threadIdx.x >> 6), (int) blockIdx.y % n_frames, (int) blockIdx.y / n_frames};
     const int frame = tb.frame;
     if (active && !active[frame]) return;
     const FrameState &fs = u.fs[frame];
@@ -456,10 +460,12 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     __shared__ unsigned int rbase[32], rreach[32];
     if (threadIdx.x < 32) { rbase[threadIdx.x] = fs.refine_base[threadIdx.x]; rreach[threadIdx.x] = fs.step_reached[threadIdx.x]; }
     __syncthreads();
+    if (tb.strip >= strips) return;                                     // (after the only barrier)
+    const int lane = (int) threadIdx.x & 63;
     const int nx = g.nx, ny = g.ny, half = ny >> 1, hx = nx >> 1;
-    const int k = tb.strip * kFusePairs + (int) threadIdx.x - 2;           // this lane's pair of output columns (2k, 2k + 1)
+    const int k = tb.strip * kFusePairs + lane - 2;                         // this lane's pair of output columns (2k, 2k + 1)
     const bool in_range = k >= 0 && k < hx;
-    const bool owner = threadIdx.x >= 2 && threadIdx.x < 2 + kFusePairs && in_range;
+    const bool owner = lane >= 2 && lane < 2 + kFusePairs && in_range;
     const int kc = min(max(k, 0), hx - 1);
     const float *a = src + (size_t) frame * np;
     const int32_t *C = Cb + (size_t) frame * np;
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
     // piece-major over all frames, so most of an infeasible probe's waves never read their strip.
     const float exit_above = fs.exit_above;
     if (exit_above > 0.0f && __uint_as_float(__hip_atomic_load(&u.fs[frame].maxerr_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > exit_above) {
-        if (threadIdx.x == 0) u.partial[part] = 0.0;
+        if (lane == 0) u.partial[part] = 0.0;
         return;
     }
     // the three detail coefficients of a vertical position (ordinal always, value and slot only inside the prefix) + LL
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(64) void k_finest_inv_use(const float *__restrict__
         cur = nxt;
     }
     for (int q = 32; q >= 1; q >>= 1) { acc += __shfl_xor(acc, q); mx = fmaxf(mx, __shfl_xor(mx, q)); }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         u.partial[part] = acc;
         atomicMax(&u.fs[frame].maxerr_bits, __float_as_uint(mx));
     }
@@ -1018,7 +1024,8 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
         cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
         rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
     }
-    const int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
+    int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
+    while (pieces > 1 && (long long) n_frames * pieces > 65535) pieces--;                // (grid y)
     RowUse u{};
     u.data = data; u.decoded = decoded;
     int partials;
@@ -1026,7 +1033,8 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     const int strips = ceil_div(g.nx >> 1, kFusePairs);
     if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
         u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
-        hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) strips * n_frames * pieces), dim3(64), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
+        const int wg = std::min(strips, kFuseMaxWaves);
+        hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
                            d_trunc_bits, d_active, u, strips, n_frames, pieces);
         partials = strips * pieces;
     } else {

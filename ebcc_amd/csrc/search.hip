@@ -60,7 +60,7 @@ __device__ float next_rate_if(const DevChunk &C, const DevRateSearch &R, int k, 
         if (!rs_next(T, cr)) break;
         const DevProbe *rec = find_probe(C, cr);
         const bool known = rec != nullptr || cr == R.want_cr;
-        const bool needs_state = k == 0 && T.phase == 3 && scr != cr;
+        const bool needs_state = (k == 0 && T.phase == 3 && scr != cr) || (T.phase == 3 && rec && !rec->complete);
         if (!known || needs_state) return cr;
         rs_feed(T, rec ? 1. - ((double) rec->nbad / n_pix) : q_hyp);
     }
@@ -118,14 +118,20 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
         rs_feed(R, q);
     };
     if (R.want) {                                                        // the probe asked for in the previous round
-        DevProbe rec{jf[t0].cr, 0, 0ull, 0.0};
+        DevProbe rec{jf[t0].cr, 0, 0ull, 0.0, 1, 0};
         int body = 0;
         for (int t = 0; t < tiles; t++) { rec.nbad += jf[t0 + t].nbad; rec.err_sum += jf[t0 + t].err_sum; body += jf[t0 + t].body_bytes; }
         rec.stream_bytes = kMainHeaderBytes + tiles * 14 + body + 2;     // main header, SOT + SOD per tile, EOC
+        rec.complete = jf[t0].bad_limit == 0 || rec.nbad < jf[t0].bad_limit;   // (a count below the limit: no piece left early)
         // search 0's probes change the layer assignment the codestream is written from; only those that also stored
         // their field leave the engine in the state of one rate (decode and assignment), the others in none
         if (k == 0) C.state_cr = keeps_field(k, R.phase) ? rec.cr : -1.0f;
-        if (!find_probe(C, rec.cr) && C.n_probes < kMaxProbes) C.probes[C.n_probes++] = rec;
+        {
+            DevProbe *have = nullptr;
+            for (int i = 0; i < C.n_probes; i++) if (C.probes[i].cr == rec.cr) have = &C.probes[i];
+            if (have) { if (!have->complete && rec.complete) *have = rec; }      // (a partial record gives way to the whole one)
+            else if (C.n_probes < kMaxProbes) C.probes[C.n_probes++] = rec;
+        }
         R.want = 0;
         if (R.phase == 5) { R.last = rec; R.phase = 6; set_active(0); return; }
         feed(rec);
@@ -137,7 +143,9 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
         float cr;
         if (!rs_next(R, cr)) break;
         const DevProbe *rec = find_probe(C, cr);
-        const bool needs_state = k == 0 && R.phase == 3 && C.state_cr != cr;
+        // ... and the final probe of either search is the search's result (size, count, error sum): a record that may be
+        // partial does not do
+        const bool needs_state = (k == 0 && R.phase == 3 && C.state_cr != cr) || (R.phase == 3 && rec && !rec->complete);
         if (rec && !needs_state) feed(*rec);
         else { R.want = 1; R.want_cr = cr; }
     }
@@ -152,7 +160,8 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
     if (R.want) {
         // the final probe of a search (:590: its size, error sum and count are the search's result) and the probe that
         // restores a decode are exact; every other probe only has to tell feasible from infeasible
-        const bool exact = R.phase == 3 || R.phase == 5 || tiles > 1 || limit_qt <= 0.0;
+        // (so is a doubling step beyond rate 1000: if it is feasible the search ends on it, :571-574, without a final probe)
+        const bool exact = R.phase == 3 || R.phase == 5 || (R.phase == 1 && R.want_cr > 1000.0f) || tiles > 1 || limit_qt <= 0.0;
         const unsigned int limit = exact ? 0u : infeasible_from(limit_qt < R.qt ? limit_qt : R.qt, n_pix);
         for (int t = 0; t < tiles; t++) { jf[t0 + t].cr = R.want_cr; jf[t0 + t].keep = keeps_field(k, R.phase); jf[t0 + t].bad_limit = limit; }
         atomicAdd(unfinished, 1);

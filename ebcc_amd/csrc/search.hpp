@@ -19,6 +19,8 @@ struct DevProbe {                  // outcome of the base layer coded at one rat
     int stream_bytes;
     unsigned long long nbad;       // count(|x - d| > target)
     double err_sum;                // sum(x - d)
+    int complete;                  // 0: the probe may have stopped counting early (J2kFrame::bad_limit): nbad is a lower bound that
+    int pad;                       //    already settles "infeasible", err_sum is partial - a search's RESULT never rests on such a record
 };
 
 // :545-596 as a resumable state machine (phases 0-4 as in the reference's three loops and final encode)

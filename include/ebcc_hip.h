@@ -114,6 +114,9 @@ void ebcc_hip_host_stats(double *out, int reset);
  * 128 KB, or a libzstd that may split blocks).  The encoder uses it to decide the reference's "pure base layer beats base +
  * residual" comparison (src/ebcc_codec.c:838) without compressing prefixes that provably lose it. */
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n);
+/* Host-side check of the arithmetic identities the kernels rely on (the division-free s / 65535.0f of the fused inverse
+ * wavelet level, for every s in [0, 65535]); returns the number of violations: 0. */
+int ebcc_hip_selfcheck(void);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).  Names: "t1_encode",
  * "t1_probe_decode", "t1_decode", "rate_alloc", "j2k_dwt_fwd", "spiht_encode".  Process-wide switch. */

@@ -204,3 +204,12 @@ def test_host_thread_budget_per_rank():
     assert 1 <= one <= share and 1 <= four <= share
     env["EBCC_HOST_THREADS"] = "3"
     assert run()[0] == 3
+
+
+def test_kernel_arithmetic_identities_hold():
+    """ebcc_hip_selfcheck: the fused inverse level maps s in [0, 65535] with fmaf(s, K_hi, s * K_lo) instead of s / 65535.0f."""
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    lib = ctypes.CDLL(L.PRODUCT_SO)
+    lib.ebcc_hip_selfcheck.restype = ctypes.c_int
+    assert lib.ebcc_hip_selfcheck() == 0

@@ -13,6 +13,7 @@ Rank 0 prints ONE JSON line.  `value` = frames * 4 152 960 B / step time summed 
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -94,9 +95,12 @@ def synth_frames(torch, n, device, seed, slope=1.5, amp=2.5, ramp=None):
     return out.contiguous()
 
 
-def cpu_baseline(sample, cores):
+def cpu_baseline(sample, cores, checks=()):
     """Reference CPU codec (oracle/_ref = reference sources + OpenJPEG 2.4.0/zstd) or, if that build cannot
-    be loaded, the oracle port; one process per core, two frames each, median per-frame times."""
+    be loaded, the oracle port; one process per core, two frames each, median per-frame times.
+    `checks`: (tag, frame, sha256 of the MI355X stream) - these frames are among the ones the reference codes, and the
+    hash of what it wrote is compared with the device's: byte parity on the very data the bench timed."""
+    import hashlib
     import multiprocessing as mp
     from tests import _lib as L
     kind = "reference" if os.path.exists(L.REF_SO) else "port"
@@ -105,20 +109,28 @@ def cpu_baseline(sample, cores):
             ctypes.CDLL(L.REF_SO)
     except OSError:
         kind = "port"
-    frames = [np.ascontiguousarray(sample[i % len(sample)]) for i in range(2 * cores)]
+    frames = [np.ascontiguousarray(c[1]) for c in checks]
+    frames += [np.ascontiguousarray(sample[i % len(sample)]) for i in range(max(0, 2 * cores - len(frames)))]
     t0 = time.time()
     with mp.get_context("spawn").Pool(cores) as pool:      # (never fork a process that has initialised HIP)
-        res = pool.map(_cpu_one, [(kind, f) for f in frames], chunksize=2)
+        res = pool.map(_cpu_one, [(kind, f) for f in frames], chunksize=1)
     wall = time.time() - t0
     enc = float(np.median([r[0] for r in res]))
     dec = float(np.median([r[1] for r in res]))
-    return {"value": round(len(frames) * FRAME_BYTES / wall / 1e9, 6), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": f"{len(frames)} frames 721x1440 (base_cr 30, MAX_ERROR 0.5), two per process on {cores} processes, encode+decode; "
-                      f"median {enc:.2f}s enc / {dec:.3f}s dec per frame, {wall:.1f}s wall",
-            "encode_MBps_per_core": round(FRAME_BYTES / enc / 1e6, 3), "decode_MBps_per_core": round(FRAME_BYTES / dec / 1e6, 2)}
+    out = {"value": round(len(frames) * FRAME_BYTES / wall / 1e9, 6), "unit": "GB/s", "cores": cores, "kind": kind,
+           "sample": f"{len(frames)} frames 721x1440 (base_cr 30, MAX_ERROR 0.5), two per process on {cores} processes, encode+decode; "
+                     f"median {enc:.2f}s enc / {dec:.3f}s dec per frame, {wall:.1f}s wall",
+           "encode_MBps_per_core": round(FRAME_BYTES / enc / 1e6, 3), "decode_MBps_per_core": round(FRAME_BYTES / dec / 1e6, 2)}
+    if checks:
+        same = [c[0] for c, r in zip(checks, res) if r[2] == c[2]]
+        diff = [c[0] for c, r in zip(checks, res) if r[2] != c[2]]
+        out["stream_parity"] = {"what": f"sha256 of the MI355X stream == sha256 of the {kind} codec's stream for the same frame",
+                                "identical": same, "different": diff}
+    return out
 
 
 def _cpu_one(arg):
+    import hashlib
     kind, frame = arg
     from tests import _lib as L
     cfg = L.make_config((1, H, W), base_cr=BASE_CR, error=MAX_ERR, residual_type=L.MAX_ERROR)
@@ -132,6 +144,7 @@ def _cpu_one(arg):
         t = time.time()
         n = lib.ebcc_encode(frame.ctypes.data, ctypes.byref(cfg), ctypes.byref(out))
         te = time.time() - t
+        digest = hashlib.sha256(ctypes.string_at(out, n)).hexdigest()
         dec = ctypes.c_void_p()
         t = time.time()
         lib.ebcc_decode(out, n, ctypes.byref(dec))
@@ -140,10 +153,11 @@ def _cpu_one(arg):
         t = time.time()
         s = L.orc_encode(frame, cfg)
         te = time.time() - t
+        digest = hashlib.sha256(s).hexdigest()
         t = time.time()
         L.orc_decode(s)
         td = time.time() - t
-    return te, td
+    return te, td, digest
 
 
 def main():
@@ -194,6 +208,7 @@ def main():
         assert rc == 0, lib.ebcc_hip_last_error()
         t2 = time.perf_counter()
         nbytes = sum(sizes[i] for i in range(n))
+        step.first_hashes = [hashlib.sha256(ctypes.string_at(outs[i], sizes[i])).hexdigest() for i in range(min(n, 2))]
         for i in range(n):
             lib.free_buffer(outs[i])
         return t1 - t0, t2 - t1, nbytes
@@ -253,7 +268,29 @@ def main():
         dist.all_gather_object(hosts, host)
     elapsed = float(t.item())
 
-    def run_batches(data, cfg_, reps=1):
+    parity_checks = []                                              # (tag, frame, sha256 of its MI355X stream) -> cpu_baseline
+
+    def h5_path_rates(frames_):
+        import subprocess
+        import tempfile
+        conda = "/opt/conda/bin/python3.9"
+        if not os.path.exists(conda):
+            return {"skipped": "no interpreter with h5py in this image"}
+        env = dict(os.environ, HDF5_PLUGIN_PATH=os.path.join(ROOT, "ebcc_amd"), HDF5_USE_FILE_LOCKING="FALSE")
+        env.pop("PYTHONPATH", None)
+        try:
+            with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+                r = subprocess.run([conda, os.path.join(ROOT, "tools", "gpu", "h5_rate.py"), tmp, str(frames_), "--json"], env=env,
+                                   capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return {"error": (r.stderr or r.stdout)[-400:]}
+            out_ = json.loads(r.stdout.strip().splitlines()[-1])
+            out_["workload"] = f"{frames_} one-frame chunks 721x1440 (error bound 0.5) through h5py {conda}: filter callback (16 frames) and direct-chunk device batches; file in memory-backed /dev/shm"
+            return out_
+        except Exception as e:                                      # (a report, never a gate)
+            return {"error": repr(e)}
+
+    def run_batches(data, cfg_, reps=1, keep_streams=()):
         """encode + decode of `data` ((m, H, W) on the device) through the engine in batches of n frames; returns
         (encode s, decode s, compressed bytes, frames that keep a residual layer, max abs error; run_batches.per_frame
         holds the max abs error of every frame of the last repetition)."""
@@ -263,6 +300,7 @@ def main():
         nbytes = resid = 0
         worst = 0.0
         per_frame = torch.zeros(m, device=data.device)
+        kept = {}
         for _ in range(reps):
             nbytes = resid = 0
             for lo in range(0, m, n):
@@ -280,10 +318,13 @@ def main():
                 for i in range(k):
                     nbytes += sizes[i]
                     resid += int.from_bytes(ctypes.string_at(outs[i] + 16, 8), "little") > 0        # header: coeffs_size
+                    if lo + i in keep_streams:
+                        kept[lo + i] = hashlib.sha256(ctypes.string_at(outs[i], sizes[i])).hexdigest()
                     lib.free_buffer(outs[i])
                 per_frame[lo:lo + k] = (dec[:k] - part).abs().amax(dim=(1, 2))
                 worst = max(worst, float(per_frame[lo:lo + k].amax()))
         run_batches.per_frame = per_frame
+        run_batches.kept = kept
         return te / reps, td / reps, nbytes, resid, worst
 
     def extra_workloads():
@@ -315,6 +356,26 @@ def main():
                                      "compressed_bytes_per_frame": int(nb / mr), "frames_with_residual_layer": round(resid / mr, 4),
                                      "max_abs_error": round(worst, 5)}
         del data
+        # ---- one GPU's share of BASELINE configs[3] (32768 frames over 8 GPUs): 4096 frames resident in HBM, 16 batches of the
+        #      engine's capacity, encode + decode, the error bound checked on EVERY frame; four of its frames go to the
+        #      reference codec with the CPU baseline below (byte parity of their streams)
+        m4 = 4096 if n >= 256 else 4 * n
+        data = synth_frames(torch, m4, device, seed=4096)
+        te, td, nb, resid, worst = run_batches(data, cfg, keep_streams=(0, m4 // 3, 2 * m4 // 3, m4 - 1))
+        assert worst <= MAX_ERR * 1.01 + 1e-3, worst
+        ex["shard4096"] = {"workload": f"{m4} frames 721x1440 resident in HBM (one GPU's share of BASELINE configs[3]), base_cr=30 MAX_ERROR=0.5, batches of {n}",
+                           "value": round(m4 * FRAME_BYTES / (te + td) / 1e9, 4), "unit": "GB/s",
+                           "encode_GBps": round(m4 * FRAME_BYTES / te / 1e9, 4), "decode_GBps": round(m4 * FRAME_BYTES / td / 1e9, 4),
+                           "compressed_bytes_per_frame": int(nb / m4), "frames_with_residual_layer": round(resid / m4, 4),
+                           "max_abs_error_over_all_frames": round(worst, 5), "frames_within_bound": int((run_batches.per_frame <= MAX_ERR * 1.01 + 1e-3).sum()),
+                           "seconds": round(te + td, 3)}
+        for i, digest in run_batches.kept.items():
+            parity_checks.append((f"shard4096[{i}]", data[i].cpu().numpy(), digest))
+        del data
+        # ---- BASELINE configs[4]'s path: EBCC-filtered HDF5 datasets of one frame per chunk, written and read (i) through the
+        #      plain filter-308 callback (one chunk per call) and (ii) as device batches of pre-filtered chunks
+        #      (ebcc_amd/h5_batch.py: H5Dwrite_chunk / H5Dread_chunk), with the image's conda h5py in a child process
+        ex["h5_path"] = h5_path_rates(n)
         # ---- the reference's host-pointer API: pageable host array in, EBCK container in host memory out (PCIe inclusive)
         host = frames.cpu().numpy()
         ccfg = L.make_config((n, H, W), (1, H, W), base_cr=BASE_CR, error=MAX_ERR, residual_type=L.MAX_ERROR)
@@ -371,17 +432,17 @@ def main():
             return hsh.hexdigest()[:16]
 
         def pmc_traffic(frames_per_launch):
-            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r02_pmc_tier1.json,
+            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r03_pmc_tier1.json,
             tools/gpu/profile.sh: separate FETCH_SIZE and WRITE_SIZE runs of `--frames 64` on one slice = 64 frames per
             dispatch; gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB).  The file names
             the kernel sources it was taken with; a file that predates the last change to them gives no figure."""
             try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_tier1.json")))
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_tier1.json")))
                 if pj.get("kernel_sources_sha") != kernel_sources_sha():
-                    return None, "profiles/r02_pmc_tier1.json predates the current tier-1 kernel sources"
+                    return None, "profiles/r03_pmc_tier1.json predates the current tier-1 kernel sources"
                 per = float(pj["frames_per_dispatch"])
                 per_frame = sum(2.0 * pj["fetch_kb"][k] + pj["write_kb"][k] for k in pj["kernels"]) * 1024.0 / per
-                return int(per_frame * frames_per_launch), "profiles/r02_pmc_tier1.json@" + pj["kernel_sources_sha"]
+                return int(per_frame * frames_per_launch), "profiles/r03_pmc_tier1.json@" + pj["kernel_sources_sha"]
             except Exception as e:
                 return None, "no usable PMC file: " + repr(e)
 
@@ -396,6 +457,28 @@ def main():
             roof = {"bound": "hbm", "kernel": "tier-1 encoder (k_t1_scan + k_t1_rowoffs + k_t1_emit + k_t1_mqrows)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(avg_s * 1e3, 4),
                     "algorithmic_bytes_per_launch": algo, "frames_per_launch": n * args.steps / launches.value}
+        if roof is not None:
+            # HBM bytes of a whole frame round trip (every k_* kernel of encode + decode, counters as above) against the 8.49 MB
+            # a round trip has to move: what the search probes cost
+            try:
+                st = json.load(open(os.path.join(ROOT, "profiles", "r03_step_traffic.json")))
+                roof["step_traffic"] = {"bytes_per_frame_round_trip": st["bytes_per_frame_round_trip"],
+                                        "algorithmic_bytes_per_frame_round_trip": st["algorithmic_bytes_per_frame_round_trip"],
+                                        "source": "profiles/r03_step_traffic.json@" + st.get("kernel_sources_sha", "?"),
+                                        "current_sources": st.get("kernel_sources_sha") == kernel_sources_sha()}
+            except Exception as e:
+                roof["step_traffic"] = None
+        # the decode side's dominant kernel: the tier-1 decoder (one launch per batch): compressed bytes in, int32 samples out
+        roof_dec = None
+        a, c = ctypes.c_double(), ctypes.c_long()
+        lib.ebcc_hip_timing_read(ctx, b"t1_decode", ctypes.byref(a), ctypes.byref(c))
+        if c.value:
+            avg_s = a.value / c.value / 1e3
+            algo = (n * FRAME_BYTES + comp) * args.steps / c.value
+            roof_dec = {"bound": "hbm", "kernel": "tier-1 decoder (k_t1_decode_lds)", "achieved": round(algo / avg_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(algo / avg_s / 1e9 / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4),
+                        "algorithmic_bytes_per_launch": algo, "frames_per_launch": n * args.steps / c.value,
+                        "note": "a serial entropy decoder: latency- and issue-bound by nature; decode_GBps is the phase as a whole"}
         slices = int(os.environ.get("EBCC_HIP_SLICES", "2"))            # (host_codec.hip: default_encode_slices)
         lib.ebcc_hip_host_threads.restype = ctypes.c_int
         line = {
@@ -411,7 +494,7 @@ def main():
             "encode_GBps": round(total_frames * FRAME_BYTES * args.steps / enc_t / 1e9, 4),
             "decode_GBps": round(total_frames * FRAME_BYTES * args.steps / dec_t / 1e9, 4),
             "compressed_bytes_per_frame": int(comp / n), "max_abs_error": round(max_err, 5),
-            "kernels": kern, "roofline": roof,
+            "kernels": kern, "roofline": roof, "roofline_decode": roof_dec,
         }
         # the host side, per rank; and the step time the host alone would allow: every rank's zstd core-seconds over the CPUs
         # the ranks share (the container's quota if there is one) - a run whose ms_per_step sits on it is bound by the host
@@ -421,13 +504,13 @@ def main():
                         "cpus_shared_by_ranks": cpus_shared,
                         "projected_host_bound_ms_per_step": round(sum(h["zstd_core_s_per_step"] for h in hosts) / cpus_shared * 1e3, 2)}
         try:                                                    # HBM-bound kernels, measured alone (tools/gpu/hbm_table.sh): best and worst of the table
-            hk = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_kernels.json")))
+            hk = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_kernels.json")))
             # rows that are HBM measurements: at least 1 MB per frame to move by role, counter traffic within 2x of it either
             # way (below: the input was still in the Infinity Cache; above: re-reads), and not latency-bound by design
             rows = [r for r in hk["kernels"] if r.get("frac_of_6290") is not None and r["algorithmic_bytes"] >= hk["frames_per_dispatch"] * (1 << 20)
                     and 0.5 <= r["counter_over_algorithmic"] <= 2.5 and "latency-bound" not in r.get("what", "")]
             if rows:
-                line["hbm_kernels"] = {"source": "profiles/r02_hbm_kernels.json@" + hk.get("kernel_sources_sha", "?"),
+                line["hbm_kernels"] = {"source": "profiles/r03_hbm_kernels.json@" + hk.get("kernel_sources_sha", "?"),
                                        "best": max(rows, key=lambda r: r["frac_of_6290"]), "worst": min(rows, key=lambda r: r["frac_of_6290"])}
         except Exception:
             pass
@@ -436,7 +519,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:               # (rank 0 at N = 1 only: the other ranks would wait at the end)
             try:
                 cores = min(16, len(os.sched_getaffinity(0)))
-                line["cpu_baseline"] = cpu_baseline(frames[:4].cpu().numpy(), cores)
+                host_frames = frames[:4].cpu().numpy()
+                checks = [(f"configs[1] frame {i}", host_frames[i], h_) for i, h_ in enumerate(getattr(step, "first_hashes", []))] + parity_checks
+                line["cpu_baseline"] = cpu_baseline(host_frames, cores, checks)
             except Exception as e:                              # the baseline is a report, never a gate
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)

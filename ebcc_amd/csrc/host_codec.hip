@@ -1945,6 +1945,35 @@ void ebcc_hip_host_stats(double *out, int reset)
     if (reset) h.reset();
 }
 
+// A pageable host array <-> device memory at PCIe speed: through the engine's two pinned bounce buffers with several host
+// threads copying (copy_pageable) instead of hipMemcpy's single staging thread (~10 GB/s, and a fresh destination's page
+// faults on top) - what ebcc_decode_chunking does for its own output, for callers of the frames API that keep their
+// frames in host memory (ebcc_amd/h5_batch.py).  Return 0 = ok.
+int ebcc_hip_upload(ebcc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    EBCC_API_TRY
+    if (!ctx || !d_dst || !h_src) { set_error("ebcc_hip_upload: null argument"); return 1; }
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    copy_pageable(ctx, const_cast<void *>(h_src), d_dst, bytes, false);
+    return 0;
+    EBCC_API_CATCH(1)
+}
+int ebcc_hip_download(ebcc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    EBCC_API_TRY
+    if (!ctx || !h_dst || !d_src) { set_error("ebcc_hip_download: null argument"); return 1; }
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    if (bytes >= ((size_t) 64 << 20)) {                                   // huge pages where the system grants them: 512 x fewer faults on a fresh array
+        const uintptr_t a = ((uintptr_t) h_dst + ((size_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), e = ((uintptr_t) h_dst + bytes) & ~(((uintptr_t) 2 << 20) - 1);
+        if (e > a) madvise((void *) a, e - a, MADV_HUGEPAGE);
+    }
+    copy_pageable(ctx, h_dst, const_cast<void *>(d_src), bytes, true);
+    return 0;
+    EBCC_API_CATCH(1)
+}
+
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
 {
     EBCC_API_TRY

@@ -1707,7 +1707,9 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
             // (the top level in more, shorter pieces: a piece is what an infeasible probe can skip)
             int pieces = std::max(1, std::min({r == kJ2kRes - 1 ? 8 : 4, kPartials / strips, g.rh[r - 1] / 16}));
             while (pieces > 1 && (long long) n_frames * pieces > 65535) pieces--;            // (grid y)
-            const int wg = std::min(strips, kL5MaxWaves), groups = ceil_div(strips, wg);    // the strips of a tile: waves of one workgroup
+            // the strips of a tile as the waves of one workgroup (tuning: EBCC_HIP_FUSE_WAVES caps the waves per workgroup)
+            static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES") ? std::max(1, std::min(kL5MaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES")))) : kL5MaxWaves;
+            const int wg = std::min(strips, wave_cap), groups = ceil_div(strips, wg);
             if (r > 1 && !ll) ll = B;                                   // (the separate passes below left their result in B)
             J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};
             if (r == kJ2kRes - 1) {

@@ -1033,7 +1033,8 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     const int strips = ceil_div(g.nx >> 1, kFusePairs);
     if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
         u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
-        const int wg = std::min(strips, kFuseMaxWaves);
+        static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES_R") ? std::max(1, std::min(kFuseMaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES_R")))) : kFuseMaxWaves;
+        const int wg = std::min(strips, wave_cap);
         hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
                            d_trunc_bits, d_active, u, strips, n_frames, pieces);
         partials = strips * pieces;

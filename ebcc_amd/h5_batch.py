@@ -53,6 +53,8 @@ class BatchCodec:
                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
         lib.ebcc_hip_decode_frames.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
                                                ctypes.c_size_t, ctypes.c_void_p]
+        lib.ebcc_hip_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ebcc_hip_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         lib.ebcc_hip_last_error.restype = ctypes.c_char_p
         lib.free_buffer.argtypes = [ctypes.c_void_p]
         self.h, self.w, self.max_frames = int(height), int(width), int(max_frames)
@@ -80,7 +82,8 @@ class BatchCodec:
         frames = np.ascontiguousarray(frames, np.float32)
         n = frames.shape[0]
         assert frames.shape[1:] == (self.h, self.w) and 1 <= n <= self.max_frames
-        self.lib.ebcc_hip_memcpy_h2d(self.d_buf, frames.ctypes.data, frames.nbytes)
+        if self.lib.ebcc_hip_upload(self.ctx, self.d_buf, frames.ctypes.data, frames.nbytes):
+            raise RuntimeError("ebcc_hip_upload: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
         outs = (ctypes.c_void_p * n)()
         sizes = (ctypes.c_size_t * n)()
         if self.lib.ebcc_hip_encode_frames(self.ctx, self.d_buf, n, ctypes.byref(cfg), outs, sizes):
@@ -94,17 +97,22 @@ class BatchCodec:
             self.lib.free_buffer(outs[i])
         return res
 
-    def decode(self, streams):
-        """list of EBCC frame streams -> (n, H, W) float32."""
+    def decode(self, streams, out=None):
+        """list of EBCC frame streams (bytes) -> (n, H, W) float32; `out`: a C-contiguous float32 array to decode into
+        (the frames then cross PCIe straight into it - no intermediate array)."""
         n = len(streams)
         assert 1 <= n <= self.max_frames
-        bufs = [ctypes.create_string_buffer(bytes(s), len(s)) for s in streams]
-        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(b, ctypes.c_void_p).value for b in bufs])
+        streams = [s if isinstance(s, bytes) else bytes(s) for s in streams]
+        # (pointers into the bytes objects themselves: they stay alive in `streams` for the duration of the call)
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(s), ctypes.c_void_p).value for s in streams])
         sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
         if self.lib.ebcc_hip_decode_frames(self.ctx, ptrs, sizes, n, self.d_buf):
             raise RuntimeError("ebcc_hip_decode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
-        out = np.empty((n, self.h, self.w), np.float32)
-        self.lib.ebcc_hip_memcpy_d2h(out.ctypes.data, self.d_buf, out.nbytes)
+        if out is None:
+            out = np.empty((n, self.h, self.w), np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == n * self.h * self.w
+        if self.lib.ebcc_hip_download(self.ctx, out.ctypes.data, self.d_buf, out.nbytes):
+            raise RuntimeError("ebcc_hip_download: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
         return out
 
 
@@ -138,15 +146,19 @@ def write_frames(dset, data, base_cr, residual_opt=("none", None), batch=256, co
 
 
 def read_frames(dset, batch=256, codec=None):
-    """Read an EBCC-filtered one-frame-per-chunk dataset by decoding its raw chunks in device batches."""
+    """Read an EBCC-filtered one-frame-per-chunk dataset by decoding its raw chunks in device batches.  The raw chunks of
+    batch k + 1 are fetched from the file (h5py, one call per chunk) on a helper thread while batch k is decoded and
+    downloaded - straight into its place in the result."""
+    import threading
     h, w = dset.shape[-2:]
     lead = dset.shape[:-2]
     n = int(np.prod(lead)) if lead else 1
     out = np.empty((n, h, w), np.float32)
     own = codec is None
     codec = codec or BatchCodec(h, w, min(batch, n))
-    try:
-        for lo in range(0, n, codec.max_frames):
+
+    def fetch(lo, box):
+        try:
             raw = []
             for i in range(lo, min(n, lo + codec.max_frames)):
                 idx = np.unravel_index(i, lead) if lead else ()
@@ -154,7 +166,24 @@ def read_frames(dset, batch=256, codec=None):
                 if mask:
                     raise ValueError(f"chunk {idx} was stored with filters disabled (mask {mask})")
                 raw.append(chunk)
-            out[lo:lo + len(raw)] = codec.decode(raw)
+            box.append(raw)
+        except BaseException as e:                                  # (handed to the caller's thread)
+            box.append(e)
+
+    try:
+        box = []
+        fetch(0, box)
+        for lo in range(0, n, codec.max_frames):
+            raw = box[0]
+            if isinstance(raw, BaseException):
+                raise raw
+            box, t = [], None
+            if lo + codec.max_frames < n:
+                t = threading.Thread(target=fetch, args=(lo + codec.max_frames, box))
+                t.start()
+            codec.decode(raw, out=out[lo:lo + len(raw)])
+            if t:
+                t.join()
     finally:
         if own:
             codec.close()

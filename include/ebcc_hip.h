@@ -95,6 +95,10 @@ int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t 
  * slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
  * n_frames (part of setting a context up, like ebcc_hip_create).  Returns 0. */
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
+/* Pageable host memory <-> device memory through the engine's pinned bounce buffers with several copying host threads
+ * (what the chunking entry points use for their own arrays): ~3x hipMemcpy on a fresh pageable array.  0 = ok. */
+int ebcc_hip_upload(ebcc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int ebcc_hip_download(ebcc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
                            uint8_t **out_streams, size_t *out_sizes);
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,

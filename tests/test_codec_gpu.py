@@ -453,14 +453,15 @@ def test_host_and_device_search_loops_agree(monkeypatch):
         cfg = L.make_config((1, 96, 160), base_cr=40.0, error=err, residual_type=mode)
         got = {}
         for name, env in (("device", {}), ("host", {"EBCC_HIP_HOST_SEARCH": "1"}), ("short", {"EBCC_HIP_SEARCH_ROUNDS": "3"}),
-                          ("plain", {"EBCC_HIP_NO_SPECULATION": "1"}), ("overlap", {"EBCC_HIP_SEARCH2_OVERLAP": "1"})):
+                          ("plain", {"EBCC_HIP_NO_SPECULATION": "1"}), ("serial2", {"EBCC_HIP_SEARCH2_SERIAL": "1"}),
+                          ("exact", {"EBCC_HIP_EXACT_PROBES": "1"}), ("zall", {"EBCC_HIP_ZSTD_ALL": "1"}), ("spin", {"EBCC_HIP_SPIN_SYNC": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             with L.Context(len(frames), 96, 160) as ctx:
                 got[name] = ctx.encode_frames(frames, cfg)
             for k in env:
                 monkeypatch.delenv(k)
-        assert got["device"] == got["host"] == got["short"] == got["plain"] == got["overlap"], mode
+        assert got["device"] == got["host"] == got["short"] == got["plain"] == got["serial2"] == got["exact"] == got["zall"] == got["spin"], mode
         L.oracle().orc_set_j2k_backend(0)
         assert got["device"][3] == L.orc_encode(frames[3], cfg)
 
@@ -476,3 +477,127 @@ def test_tier1_retry_when_decisions_outgrow_their_rows(monkeypatch):
     with L.Context(len(frames), 96, 160) as ctx:
         got = ctx.encode_frames(frames, cfg)
     assert got == want
+
+
+def test_repeated_devices_run_as_separate_blocks_on_host_threads():
+    """The several-devices path of the chunking entry points (run_on_devices: contiguous blocks of the chunk list, one host
+    thread and engine per listed device, /root/reference/src/ebcc_codec.c:1007-1046 is the serial loop) on a one-GPU box:
+    EBCC_HIP_DEVICES_KEEP_REPEATS=1 keeps a device that is named three times as three entries, so three blocks go through three host
+    threads (the per-device lock serialises them) - container and decoded array identical to the one-block result."""
+    shape, chunk = (11, 64, 96), (1, 64, 96)
+    one = _child(env={"EBCC_HIP_DEVICES": "0"}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    assert one.returncode == 0 and "SHA" in one.stdout and "DECODED" in one.stdout, one.stderr[-400:]
+    three = _child(env={"EBCC_HIP_DEVICES": "0,0,0", "EBCC_HIP_DEVICES_KEEP_REPEATS": "1", "EBCC_HIP_PHASE_TIMING": "1"}, shape=shape, chunk=chunk,
+                   fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    assert three.returncode == 0, three.stderr[-400:]
+    assert three.stdout == one.stdout
+    # three blocks were coded: the phase report of encode_batch appears once per block (4 + 4 + 3 chunks)
+    assert three.stderr.count("phase analysis") == 3, three.stderr[-800:]
+    collapsed = _child(env={"EBCC_HIP_DEVICES": "0,0,0", "EBCC_HIP_PHASE_TIMING": "1"}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    assert collapsed.stdout == one.stdout and collapsed.stderr.count("phase analysis") == 1
+
+
+def test_shard_of_many_batches_keeps_the_bound_and_the_bytes(monkeypatch):
+    """One GPU's share of a large stack (BASELINE configs[3] at reduced size): more frames than the engine holds go through
+    ebcc_hip_encode_frames / decode_frames batch after batch; the error bound holds on every frame and a sampled subset is
+    byte-identical to the oracle (bench.py's shard4096 does the same with 4096 full-size frames)."""
+    h, w, cap, m = 64, 96, 8, 37
+    frames = np.stack([L.era5_like(h, w, 2000 + s, 1.0 + 0.1 * (s % 5), 0.5 + 0.1 * (s % 3)) for s in range(m)]).astype(np.float32)
+    cfg = L.make_config((1, h, w), base_cr=25.0, error=0.05, residual_type=L.MAX_ERROR)
+    streams = []
+    dec = np.empty_like(frames)
+    with L.Context(cap, h, w) as ctx:
+        for lo in range(0, m, cap):
+            part = ctx.encode_frames(frames[lo:lo + cap], cfg)
+            streams += part
+            dec[lo:lo + len(part)] = ctx.decode_frames(part).reshape(len(part), h, w)
+    assert np.abs(dec - frames).reshape(m, -1).max(axis=1).max() <= 0.05 * 1.1
+    L.oracle().orc_set_j2k_backend(0)
+    for i in (0, 7, 8, 20, 36):
+        assert streams[i] == L.orc_encode(frames[i], cfg), i
+
+
+_BIG = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from tests import _lib as L
+lib = L.product()
+lib.ebcc_decode_chunking.restype = ctypes.c_size_t
+lib.ebcc_decode_chunking.argtypes = [ctypes.c_void_p, ctypes.c_size_t, L.c_void_pp]
+lib.ebcc_encode_chunking.restype = ctypes.c_size_t
+lib.ebcc_encode_chunking.argtypes = [ctypes.c_void_p, ctypes.POINTER(L.CodecConfig), L.c_void_pp]
+n, h, w = 20, 721, 1440                                     # 83 MB of output: the page-touching threads of the decode run
+base = L.era5_like(h, w, 5)
+data = np.stack([base + 0.01 * k for k in range(n)]).astype(np.float32)
+cfg = L.make_config((n, h, w), (1, h, w), base_cr=60.0, error=0.0, residual_type=L.NONE)
+out = ctypes.c_void_p()
+nb = lib.ebcc_encode_chunking(data.ctypes.data, ctypes.byref(cfg), ctypes.byref(out))
+assert nb > 0
+good = bytearray(ctypes.string_at(out.value, nb))
+# chunk 0's stream starts at 80 + 8: break its magic -> legacy parse -> rejected
+bad = bytearray(good); bad[88:92] = b"XXXX"; bad[100:140] = bytes(40)
+for name, blob in (("bad", bad), ("good", good), ("bad", bad), ("good", good)):
+    d = ctypes.c_void_p()
+    b = (ctypes.c_char * len(blob)).from_buffer(blob)
+    m = lib.ebcc_decode_chunking(b, len(blob), ctypes.byref(d))
+    print(name, "DECODED", m, flush=True)
+    if m:
+        a = np.ctypeslib.as_array(ctypes.cast(d, ctypes.POINTER(ctypes.c_float)), shape=(m,))
+        print("MAXERR", float(np.abs(a.reshape(n, h, w)[::7] - data[::7]).max()), flush=True)
+        lib.free_buffer(d)
+print("ALIVE")
+"""
+
+
+def test_rejected_chunk_of_a_large_container_returns_zero_from_a_live_process():
+    """ebcc_decode_chunking on a >= 64 MB container one of whose chunks is rejected: the output's pages are being touched by
+    helper threads when the error is found - the entry point joins them before it frees the output, returns 0
+    (/root/reference/src/ebcc_codec.c:1326-1449 conventions), and the same process goes on decoding."""
+    import os
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if not k.startswith("EBCC_HIP_")}
+    r = subprocess.run([sys.executable, "-c", _BIG.format(root=L.ROOT)], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and "ALIVE" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+    lines = [l for l in r.stdout.splitlines() if "DECODED" in l]
+    assert lines[0] == "bad DECODED 0" and lines[2] == "bad DECODED 0", lines
+    assert lines[1] == f"good DECODED {20 * 721 * 1440}" and lines[3] == lines[1], lines
+
+
+_TWICE = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from tests import _lib as L
+lib = L.product()
+frames = np.stack([L.era5_like(64, 96, 40 + s, 1.1, 0.7) for s in range(6)]).astype(np.float32)
+cfg = L.make_config((6, 64, 96), (1, 64, 96), base_cr=20.0, error=0.05, residual_type=L.MAX_ERROR)
+import hashlib
+for attempt in range(3):
+    out = ctypes.c_void_p()
+    n = lib.ebcc_encode_chunking(np.ascontiguousarray(frames).ctypes.data, ctypes.byref(cfg), ctypes.byref(out))
+    print("RETURNED", n, hashlib.sha256(ctypes.string_at(out.value, n)).hexdigest() if n else "-", flush=True)
+"""
+
+
+def test_a_call_after_a_failed_allocation_succeeds():
+    """EBCC_HIP_FAIL_ALLOC=<n> fails the n-th device allocation of the process: the call it hits returns 0, and the NEXT call
+    in the same process works (no half-built engine, dangling staging pointer or stale capacity is left in the cache)."""
+    import os
+    import subprocess
+    import sys
+    base = {k: v for k, v in os.environ.items() if not k.startswith("EBCC_HIP_")}
+    ok = subprocess.run([sys.executable, "-c", _TWICE.format(root=L.ROOT)], capture_output=True, text=True, env=base, timeout=600)
+    want = [l for l in ok.stdout.splitlines() if l.startswith("RETURNED")]
+    assert ok.returncode == 0 and len(want) == 3 and len(set(want)) == 1 and " 0 -" not in want[0], (ok.stdout, ok.stderr[-400:])
+    seen_failure = 0
+    for nth in (1, 3, 30, 60, 75, 80, 85, 90):                     # engine workspaces, tier-1 buffers, staging and i/o buffers
+        r = subprocess.run([sys.executable, "-c", _TWICE.format(root=L.ROOT)], capture_output=True, text=True, env=dict(base, EBCC_HIP_FAIL_ALLOC=str(nth)),
+                           timeout=600)
+        got = [l for l in r.stdout.splitlines() if l.startswith("RETURNED")]
+        assert r.returncode == 0 and len(got) == 3, (nth, r.returncode, r.stdout, r.stderr[-600:])
+        assert got[2] == want[0], (nth, got)                       # whatever the first calls met, the process has recovered
+        assert all(g == want[0] or g == "RETURNED 0 -" for g in got), (nth, got)
+        seen_failure += any(g == "RETURNED 0 -" for g in got)
+    assert seen_failure >= 3

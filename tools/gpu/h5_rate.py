@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from ebcc_amd import EBCC_Filter, h5_batch  # noqa: E402
 
 out, N = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 64
+as_json = "--json" in sys.argv
+res = {}
 H, W = 721, 1440
 rng = np.random.default_rng(11)
 y, x = np.mgrid[0:H, 0:W]
@@ -29,8 +31,10 @@ t1 = time.perf_counter()
 with h5py.File(os.path.join(out, "cb.h5"), "r") as f:
     back = f["t"][...]
 t2 = time.perf_counter()
+res["filter_callback"] = {"frames": ncb, "write_GBps": round(data[:ncb].nbytes / 1e9 / (t1 - t0), 4), "read_GBps": round(data[:ncb].nbytes / 1e9 / (t2 - t1), 4),
+                          "max_abs_error": round(float(np.abs(back - data[:ncb]).max()), 5)}
 print(f"filter callback ({ncb} frames): write {data[:ncb].nbytes / 1e9 / (t1 - t0):.3f} GB/s, read {data[:ncb].nbytes / 1e9 / (t2 - t1):.3f} GB/s, "
-      f"max error {float(np.abs(back - data[:ncb]).max()):.4f}", flush=True)
+      f"max error {float(np.abs(back - data[:ncb]).max()):.4f}", flush=True, file=sys.stderr if as_json else sys.stdout)
 
 for rep in range(2):
     t0 = time.perf_counter()
@@ -41,5 +45,10 @@ for rep in range(2):
     with h5py.File(os.path.join(out, "dc.h5"), "r") as f:
         back = h5_batch.read_frames(f["t"])
     t2 = time.perf_counter()
+    res["direct_chunk_batch"] = {"frames": N, "write_GBps": round(gb / (t1 - t0), 4), "read_GBps": round(gb / (t2 - t1), 4),
+                                 "max_abs_error": round(float(np.abs(back - data).max()), 5), "file_MB": round(os.path.getsize(os.path.join(out, "dc.h5")) / 1e6, 2)}
     print(f"direct-chunk batch ({N} frames), rep {rep}: write {gb / (t1 - t0):.3f} GB/s, read {gb / (t2 - t1):.3f} GB/s, "
-          f"max error {float(np.abs(back - data).max()):.4f}, file {os.path.getsize(os.path.join(out, 'dc.h5')) / 1e6:.1f} MB", flush=True)
+          f"max error {float(np.abs(back - data).max()):.4f}, file {os.path.getsize(os.path.join(out, 'dc.h5')) / 1e6:.1f} MB", flush=True, file=sys.stderr if as_json else sys.stdout)
+if as_json:
+    import json
+    print(json.dumps(res), flush=True)

@@ -592,8 +592,8 @@ struct ColPipe {
 // shuffles, four correctly rounded divisions by 65535, four fp64 accumulations) AND moved 1.7-2x its bytes (the strips of
 // a frame are 240-byte column ranges with halo, not multiples of a 128-byte line: the lines two strips share were fetched
 // once per strip, because neighbouring strips ran as independent workgroups on different XCDs or microseconds apart).
-// Now: (1) the strips of a (frame, piece) tile are the WAVES OF ONE WORKGROUP - same CU, same instruction stream, started
-// together - so a shared line is fetched once and found in the CU's L1 by the neighbour; (2) the vertical positions away
+// Now: (1) neighbouring strips of a (frame, piece) tile are waves of one workgroup, four at a time - same CU, same
+// instruction stream, started together - so a line two of them share is fetched once; (2) the vertical positions away
 // from the top and bottom edge take a step without any boundary test (ColPipe::step_interior), (3) neighbours come
 // through v_mov_dpp wave shifts, (4) s / 65535.0f is fmaf(s, K_hi, s * K_lo) - equal to the correctly rounded quotient for
 // every integer s in [0, 65535] (div65535_exact; checked exhaustively by ebcc_hip_selfcheck and tests/test_boundary.py),
@@ -746,6 +746,10 @@ __global__ __launch_bounds__(64 * kL5MaxWaves) void k_j2k_level5_fin(J2kLevelIO 
     // accesses, one row of latency in flight.  32-bit offsets from uniform bases.
     const unsigned c_lo = (unsigned) min(max(i, 0), snh - 1), c_hi = (unsigned) snh + (unsigned) min(max(i, 0), max(dnh - 1, 0));
     const unsigned c0 = (unsigned) min(max(2 * i, 0), nh - 1), c1x = (unsigned) min(max(2 * i + 1, 0), nh - 1);
+    // the 8-byte form reads columns (cp, cp + 1) of a row: the PAIR index is clamped, so that cp + 1 <= nh - 1 (nh is even
+    // there) - clamping the column instead would let an out-of-range halo lane read one sample past the end of the row,
+    // and on the last row of the last frame past the end of the caller's buffer
+    const unsigned cp = 2u * (unsigned) min(max(i, 0), snh - 1);
     // 8-byte accesses of the output pair (and of the frame's samples beside it): even widths and 8-byte aligned bases
     const bool pair_io = (W & 1) == 0 && (nh & 1) == 0 && (n_pix & 1) == 0 && (((size_t) x | (size_t) d | (size_t) o) & 7) == 0 &&
                          (!FIN ? (io.out_pitch & 1) == 0 && (io.out_frame & 1) == 0 : true);
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(64 * kL5MaxWaves) void k_j2k_level5_fin(J2kLevelIO 
         if (x) {
             const unsigned y0 = (unsigned) min(max(2 * (j - 2), 0), nv - 1), y1 = (unsigned) min(max(2 * (j - 2) + 1, 0), nv - 1);
             if (pair_io) {
-                const f32x2 a = *reinterpret_cast<const f32x2 *>(x + (y0 * (unsigned) W + c0)), c = *reinterpret_cast<const f32x2 *>(x + (y1 * (unsigned) W + c0));
+                const f32x2 a = *reinterpret_cast<const f32x2 *>(x + (y0 * (unsigned) W + cp)), c = *reinterpret_cast<const f32x2 *>(x + (y1 * (unsigned) W + cp));
                 x00 = a.x; x01 = a.y; x10 = c.x; x11 = c.y;
             } else {
                 x00 = x[y0 * (unsigned) W + c0]; x01 = x[y0 * (unsigned) W + c1x]; x10 = x[y1 * (unsigned) W + c0]; x11 = x[y1 * (unsigned) W + c1x];
@@ -1707,8 +1711,10 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
             // (the top level in more, shorter pieces: a piece is what an infeasible probe can skip)
             int pieces = std::max(1, std::min({r == kJ2kRes - 1 ? 8 : 4, kPartials / strips, g.rh[r - 1] / 16}));
             while (pieces > 1 && (long long) n_frames * pieces > 65535) pieces--;            // (grid y)
-            // the strips of a tile as the waves of one workgroup (tuning: EBCC_HIP_FUSE_WAVES caps the waves per workgroup)
-            static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES") ? std::max(1, std::min(kL5MaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES")))) : kL5MaxWaves;
+            // neighbouring strips of a tile as the waves of one workgroup, four at a time (measured per 128-frame probe round,
+            // tools/gpu/kstat.sh: 1 wave 231 us, 4 waves 220, 6 waves 258, all 12 strips 264 - a large workgroup needs all
+            // its wave slots free on one CU at once); EBCC_HIP_FUSE_WAVES overrides
+            static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES") ? std::max(1, std::min(kL5MaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES")))) : 4;
             const int wg = std::min(strips, wave_cap), groups = ceil_div(strips, wg);
             if (r > 1 && !ll) ll = B;                                   // (the separate passes below left their result in B)
             J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};

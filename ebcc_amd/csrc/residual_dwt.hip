@@ -447,9 +447,8 @@ __global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const flo
                                                         const uint32_t *__restrict__ sigordb, const uint32_t *__restrict__ lspidxb,
                                                         const unsigned long long *trunc_bits, const int *active, RowUse u, int strips, int n_frames, int pieces)
 {
-    // workgroup = the strips (one per wave, up to 16) of tile blockIdx.y = piece * n_frames + frame: the column ranges of
-    // neighbouring strips share 128-byte lines and the halo - as waves of one workgroup they run on one CU in step and the
-    // shared lines are fetched once (k_j2k_level5_fin, j2k_analysis.hip, has the measurements)
+    // workgroup = `blockDim.x / 64` neighbouring strips (one per wave) of tile blockIdx.y = piece * n_frames + frame;
+    // one by default (launch_prefix_synthesis_stats has the measurements)
     struct { int strip, frame, piece; } tb{(int) blockIdx.x * ((int) blockDim.x >> 6) + ((int) threadIdx.x >> 6), (int) blockIdx.y % n_frames, (int) blockIdx.y / n_frames};
     const int frame = tb.frame;
     if (active && !active[frame]) return;
@@ -1033,7 +1032,9 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     const int strips = ceil_div(g.nx >> 1, kFusePairs);
     if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
         u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
-        static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES_R") ? std::max(1, std::min(kFuseMaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES_R")))) : kFuseMaxWaves;
+        // (one strip per workgroup: with several strips as the waves of one workgroup this kernel got slower - 564 us per
+        //  probe round with 1, 571 with 4, 788 with 6, 898 with all 12, tools/gpu/kstat.sh; EBCC_HIP_FUSE_WAVES_R overrides)
+        static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES_R") ? std::max(1, std::min(kFuseMaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES_R")))) : 1;
         const int wg = std::min(strips, wave_cap);
         hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
                            d_trunc_bits, d_active, u, strips, n_frames, pieces);

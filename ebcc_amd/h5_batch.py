@@ -116,6 +116,30 @@ class BatchCodec:
         return out
 
 
+# Engines are expensive to make (tens of GB of device workspace for 256 frames of 721 x 1440) and cheap to keep: the
+# helpers below share one per (height, width, capacity, device) for the life of the process (close_cached() lets go).
+_codecs = {}
+
+
+def cached_codec(height, width, max_frames=256, device=0):
+    key = (int(height), int(width), int(max_frames), int(device))
+    c = _codecs.get(key)
+    if c is None or not c.ctx:
+        c = _codecs[key] = BatchCodec(height, width, max_frames, device)
+    return c
+
+
+def close_cached():
+    for c in _codecs.values():
+        c.close()
+    _codecs.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(close_cached)
+
+
 def create_dataset(group, name, shape, base_cr, residual_opt=("none", None), **kw):
     """An EBCC-filtered float32 dataset of shape (..., H, W) with one frame per chunk."""
     h, w = shape[-2:]
@@ -132,17 +156,12 @@ def write_frames(dset, data, base_cr, residual_opt=("none", None), batch=256, co
     flat = data.reshape((-1, h, w))
     lead = data.shape[:-2]
     cfg = frame_config(h, w, base_cr, residual_opt)
-    own = codec is None
-    codec = codec or BatchCodec(h, w, min(batch, len(flat)))
-    try:
-        for lo in range(0, len(flat), codec.max_frames):
-            streams = codec.encode(flat[lo:lo + codec.max_frames], cfg)
-            for i, s in enumerate(streams):
-                idx = np.unravel_index(lo + i, lead) if lead else ()
-                dset.id.write_direct_chunk(tuple(int(v) for v in idx) + (0, 0), s, filter_mask=0)
-    finally:
-        if own:
-            codec.close()
+    codec = codec or cached_codec(h, w, min(batch, len(flat)))
+    for lo in range(0, len(flat), codec.max_frames):
+        streams = codec.encode(flat[lo:lo + codec.max_frames], cfg)
+        for i, s in enumerate(streams):
+            idx = np.unravel_index(lo + i, lead) if lead else ()
+            dset.id.write_direct_chunk(tuple(int(v) for v in idx) + (0, 0), s, filter_mask=0)
 
 
 def read_frames(dset, batch=256, codec=None):
@@ -154,8 +173,7 @@ def read_frames(dset, batch=256, codec=None):
     lead = dset.shape[:-2]
     n = int(np.prod(lead)) if lead else 1
     out = np.empty((n, h, w), np.float32)
-    own = codec is None
-    codec = codec or BatchCodec(h, w, min(batch, n))
+    codec = codec or cached_codec(h, w, min(batch, n))
 
     def fetch(lo, box):
         try:
@@ -170,21 +188,19 @@ def read_frames(dset, batch=256, codec=None):
         except BaseException as e:                                  # (handed to the caller's thread)
             box.append(e)
 
-    try:
-        box = []
-        fetch(0, box)
-        for lo in range(0, n, codec.max_frames):
-            raw = box[0]
-            if isinstance(raw, BaseException):
-                raise raw
-            box, t = [], None
-            if lo + codec.max_frames < n:
-                t = threading.Thread(target=fetch, args=(lo + codec.max_frames, box))
-                t.start()
+    box = []
+    fetch(0, box)
+    for lo in range(0, n, codec.max_frames):
+        raw = box[0]
+        if isinstance(raw, BaseException):
+            raise raw
+        box, t = [], None
+        if lo + codec.max_frames < n:
+            t = threading.Thread(target=fetch, args=(lo + codec.max_frames, box))
+            t.start()
+        try:
             codec.decode(raw, out=out[lo:lo + len(raw)])
+        finally:
             if t:
                 t.join()
-    finally:
-        if own:
-            codec.close()
     return out.reshape(dset.shape)

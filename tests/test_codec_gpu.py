@@ -485,15 +485,16 @@ def test_repeated_devices_run_as_separate_blocks_on_host_threads():
     EBCC_HIP_DEVICES_KEEP_REPEATS=1 keeps a device that is named three times as three entries, so three blocks go through three host
     threads (the per-device lock serialises them) - container and decoded array identical to the one-block result."""
     shape, chunk = (11, 64, 96), (1, 64, 96)
-    one = _child(env={"EBCC_HIP_DEVICES": "0"}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    # (one slice per block, so that a block is one pass of the encoder and shows as one phase report)
+    one = _child(env={"EBCC_HIP_DEVICES": "0", "EBCC_HIP_SLICES": "1"}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
     assert one.returncode == 0 and "SHA" in one.stdout and "DECODED" in one.stdout, one.stderr[-400:]
-    three = _child(env={"EBCC_HIP_DEVICES": "0,0,0", "EBCC_HIP_DEVICES_KEEP_REPEATS": "1", "EBCC_HIP_PHASE_TIMING": "1"}, shape=shape, chunk=chunk,
+    three = _child(env={"EBCC_HIP_DEVICES": "0,0,0", "EBCC_HIP_DEVICES_KEEP_REPEATS": "1", "EBCC_HIP_PHASE_TIMING": "1", "EBCC_HIP_SLICES": "1"}, shape=shape, chunk=chunk,
                    fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
     assert three.returncode == 0, three.stderr[-400:]
     assert three.stdout == one.stdout
     # three blocks were coded: the phase report of encode_batch appears once per block (4 + 4 + 3 chunks)
     assert three.stderr.count("phase analysis") == 3, three.stderr[-800:]
-    collapsed = _child(env={"EBCC_HIP_DEVICES": "0,0,0", "EBCC_HIP_PHASE_TIMING": "1"}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    collapsed = _child(env={"EBCC_HIP_DEVICES": "0,0,0", "EBCC_HIP_PHASE_TIMING": "1", "EBCC_HIP_SLICES": "1"}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
     assert collapsed.stdout == one.stdout and collapsed.stderr.count("phase analysis") == 1
 
 

@@ -19,7 +19,7 @@ import os
 import sys
 import time
 
-# The encode path runs its batch as concurrent slices (two by default, host_codec.hip: default_encode_slices), each with two
+# The encode path runs its batch as concurrent slices (three by default, host_codec.hip: default_encode_slices), each with two
 # streams; the HIP runtime has a hardware queue for each when GPU_MAX_HW_QUEUES >= 8 - it reads this when it starts, i.e.
 # before torch loads.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -244,7 +244,7 @@ def main():
     lib.ebcc_hip_host_stats(hstats, 0)
     # host side of this rank over the timed region (per step): what the entropy stage cost, what the process burnt in all
     # its threads, and whether the container's CPU quota throttled it
-    host = {"pool_threads": lib.ebcc_hip_host_threads(int(os.environ.get("EBCC_HIP_SLICES", "2"))) if hasattr(lib, "ebcc_hip_host_threads") else None,
+    host = {"pool_threads": lib.ebcc_hip_host_threads(int(os.environ.get("EBCC_HIP_SLICES", "3"))) if hasattr(lib, "ebcc_hip_host_threads") else None,
             "usable_cpus": int(hstats[0]), "quota_cpus": hstats[1] or None,
             "zstd_core_s_per_step": round(hstats[2] / args.steps, 4), "zstd_wait_ms_per_step": round(hstats[3] / args.steps * 1e3, 2),
             "zstd_MB_per_step": round(hstats[4] / args.steps / 1e6, 3),
@@ -479,7 +479,7 @@ def main():
                         "frac": round(algo / avg_s / 1e9 / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4),
                         "algorithmic_bytes_per_launch": algo, "frames_per_launch": n * args.steps / c.value,
                         "note": "a serial entropy decoder: latency- and issue-bound by nature; decode_GBps is the phase as a whole"}
-        slices = int(os.environ.get("EBCC_HIP_SLICES", "2"))            # (host_codec.hip: default_encode_slices)
+        slices = int(os.environ.get("EBCC_HIP_SLICES", "3"))            # (host_codec.hip: default_encode_slices)
         lib.ebcc_hip_host_threads.restype = ctypes.c_int
         line = {
             "metric": "fp32 GB/s encode+decode, 721x1440 ERA5 frames MAX_ERROR=0.5",

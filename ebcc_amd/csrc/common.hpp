@@ -100,6 +100,17 @@ __device__ inline TileOfBlock xcd_tile_of_block(unsigned b, unsigned strips, uns
     return TileOfBlock{(int) strip, (int) (tile % frames), (int) (tile / frames)};
 }
 
+// value of the lane below / above (lane 0 / lane 63 keep their own): __shfl_up / __shfl_down by one as a single DPP move
+// (v_mov_b32_dpp wave_shr:1 / wave_shl:1, GFX9 family) instead of a trip through the LDS crossbar (ds_bpermute)
+__device__ inline float lane_below(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ inline float lane_above(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+
 // Monotone key for float ordering with -0 == +0 (reference compares with < and >, so the two
 // zeros tie; ties are then broken by index to reproduce "first occurrence wins").
 __host__ __device__ inline uint32_t float_order_key(float f)

@@ -1803,18 +1803,19 @@ int run_on_devices(size_t n_chunks, Fn fn)
 // frames each, created on first use.  Small batches stay on the context's own engine.  More than two slices only
 // pay when the HIP runtime has a hardware queue for each stream (GPU_MAX_HW_QUEUES, default 4, shared with the
 // application's streams; it is read when the runtime starts, so the application sets it): streams that share a
-// queue run one after the other.  Default for encode: TWO slices (default_encode_slices below).
+// queue run one after the other.  Default for encode: THREE slices (default_encode_slices below).
 // Decode runs as ONE slice since round 2: its launch is as long as the longest SPIHT stream of the batch whatever the
 // batch size, and the tier-1 decoder is bound by vector issue slots - two half batches side by side only shared them
 // (A/B on one box, tools/gpu/ab_dec.sh: 33 GB/s with one slice, 27 with two).
 constexpr size_t kDefaultDecodeSlices = 1;
 static size_t default_encode_slices()
 {
-    // Two since the end of round 2 (was four with GPU_MAX_HW_QUEUES >= 8): the search loops no longer leave the GPU idle
-    // between rounds, so two slices keep it busy, and every further slice repeats the latency-bound launches (k_rate,
-    // the MQ pass, the restart decode) for fewer frames each.  Alternating runs on one box (tools/gpu/ab_multi.sh):
-    // encode 8.4-8.5 GB/s with two, 8.1-8.6 with three, 6.8-7.5 with four.
-    return 2;
+    // Four with eight hardware queues in round 1; two at the end of round 2 (the search loops had moved to the device and every
+    // further slice repeated the latency-bound launches for fewer frames: 8.4-8.5 GB/s with two, 6.8-7.5 with four); three
+    // in round 3 - the probes are cheaper (early exits, leaner fused levels) and the host no longer compresses every prefix,
+    // so a third slice finds idle GPU and idle cores again (alternating runs on one box, tools/gpu/host_sweep.sh: 154-160 ms
+    // per step with two, 146-153 with three, 160-165 with four).
+    return 3;
 }
 static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames, const char *env_name, size_t k)
 {
@@ -1928,8 +1929,8 @@ int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) 
 // slices waited for the zstd workers, bytes compressed, entropy batches, prefix bytes whose compression was proved
 // unnecessary - since the last call with reset != 0
 // arithmetic identities the kernels rely on, checked on the host (0 = all hold): the division-free s / 65535.0f of the fused
-// inverse level for every s in [0, 65535]
-int ebcc_hip_selfcheck(void) { return j2k_selfcheck_div65535(); }
+// inverse level for every s in [0, 65535]; v / 255.0f and x / kXi of the residual synthesis (all significands)
+int ebcc_hip_selfcheck(void) { return j2k_selfcheck_div65535() + residual_selfcheck_divisions(); }
 
 // the lower bound of zstd_size_lower_bound (0: not applicable - longer than 128 KB, or a libzstd that may split blocks)
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n) { return zstd_floor_usable() ? zstd_size_lower_bound(src, n) : 0; }

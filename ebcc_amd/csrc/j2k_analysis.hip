@@ -608,15 +608,6 @@ struct J2kLevelIO {
     float *out; int out_pitch; size_t out_frame;         // FIN = false only
     int r;
 };
-// value of the lane below / above (lane 0 / lane 63 keep their own): __shfl_up / __shfl_down by one as a single DPP move
-__device__ inline float lane_below(float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
-}
-__device__ inline float lane_above(float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
-}
 // s / 65535.0f for an integer-valued s in [0, 65535], without the division: K_hi + K_lo = 1 / 65535 to 2^-49, one rounding
 // at the end; the quotient's binary expansion repeats with period 16, so it is never within 2^-40 of a rounding boundary.
 __host__ __device__ inline float div65535_exact(float s)

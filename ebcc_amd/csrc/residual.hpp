@@ -112,4 +112,7 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
                          const unsigned long long *d_num_bits, const ResidualBuffers &rb, int n_frames,
                          const int *d_active, hipStream_t s);
 
+// mismatches of the division-free forms of the residual synthesis against the divisions they replace (0 expected)
+int residual_selfcheck_divisions();
+
 }  // namespace ebcc

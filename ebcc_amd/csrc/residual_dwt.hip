@@ -9,6 +9,8 @@
 // Rows: one row per workgroup iteration, HBM access is full contiguous rows (float2 per lane).
 // Columns: a tile of CW adjacent columns x full height is staged through LDS so that every HBM
 // access is a CW*4-byte row segment; the strided walk happens only in LDS.
+#include <cstring>
+#include <cmath>
 #include <mutex>
 #include "residual.hpp"
 #include "residual_device.hpp"
@@ -344,6 +346,46 @@ __global__ __launch_bounds__(kColThreads) void k_cols_inv(const float *__restric
 // boundary taps (dwt.h:125-139: first low-pass uses O[0] + O[1], last high-pass of step 2 E[h-1] + E[h-2], of step 4
 // (2 alpha) x[n-2]) make the pipeline four positions deep.
 // ------------------------------------------------------------------------------------------------
+// x / kXi without the division sequence (v_div_scale x 2, v_rcp, five fmas, v_div_fmas, v_div_fixup): q0 = x * z with
+// z = RN(1 / kXi), one exact remainder, one correction - the correctly rounded quotient for EVERY fp32 x with
+// |x| >= 2^-96 (checked over all 2^23 significands by ebcc_hip_selfcheck; below that the remainder is subnormal and the
+// division itself is used), and x itself for a zero of either sign.
+__host__ __device__ inline float div_xi(float x)
+{
+    const float z = 0.869864404f;                                      // RN(1 / 1.149604398f)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float q0 = __fmul_rn(x, z);
+    const float q1 = __fmaf_rn(__fmaf_rn(-q0, kXi, x), z, q0);
+    const float ax = fabsf(x);
+    float q = x == 0.0f ? x : q1;
+    if (__builtin_expect(ax < 1.2621774e-29f && ax != 0.0f, 0)) q = x / kXi;
+    return q;
+#else
+    const float q0 = x * z;
+    const float q1 = std::fma(std::fma(-q0, 1.149604398f, x), z, q0);
+    const float ax = std::fabs(x);
+    if (x == 0.0f) return x;
+    if (ax < 1.2621774e-29f) return x / 1.149604398f;
+    return q1;
+#endif
+}
+// v / 255.0f for an integer-valued v in [0, 255] (add_dc's clamp): fmaf(v, K_hi, v * K_lo), equal to the quotient for all 256
+__host__ __device__ inline float div255_exact(float v)
+{
+    const float k_hi = 0.0039215688593685627f, k_lo = -2.3191758236063009e-10f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmaf_rn(v, k_hi, __fmul_rn(v, k_lo));
+#else
+    return std::fma(v, k_hi, v * k_lo);
+#endif
+}
+// residual_value with the clamp as one median and the division replaced
+__device__ inline float residual_value_fast(float a, float dc, float rmin, float rng)
+{
+    const float v = __builtin_amdgcn_fmed3f(floorf(a + dc), 0.0f, 255.0f);
+    return div255_exact(v) * rng + rmin;
+}
+
 struct RPipe {
     float E_1 = 0, O_1 = 0, O_2 = 0;       // inputs (scaled) of positions j - 1, j - 1, j - 2
     float a1 = 0, a2 = 0;                  // after step 1: positions j - 2, j - 3
@@ -352,7 +394,7 @@ struct RPipe {
     // inputs of position j in; finished samples 2 (j - 4), 2 (j - 4) + 1 out (valid when j - 4 is in [0, half))
     __device__ void step(int j, int half, float Ein, float Oin, float &x_even, float &x_odd)
     {
-        const float E0 = Ein / kXi, O0 = Oin * kXi;
+        const float E0 = div_xi(Ein), O0 = Oin * kXi;
         int k = j - 1;                                                  // step 1
         float e1 = 0;
         if (k >= 0 && k < half) e1 = E_1 - kDelta * (O_1 + (k > 0 ? O_2 : O0));
@@ -365,6 +407,20 @@ struct RPipe {
         k = j - 4;                                                      // step 4
         x_even = c1;
         x_odd = (k + 1 < half) ? b2 - kAlpha * (c1 + e2) : b2 - (2 * kAlpha) * c1;
+        O_2 = O_1; O_1 = O0; E_1 = E0;
+        a2 = a1; a1 = e1;
+        b2 = b1; b1 = o1;
+        c1 = e2;
+    }
+    // the same for 4 <= j < half: every neighbour exists, no boundary form, no test
+    __device__ void interior(float Ein, float Oin, float &x_even, float &x_odd)
+    {
+        const float E0 = div_xi(Ein), O0 = Oin * kXi;
+        const float e1 = E_1 - kDelta * (O_1 + O_2);
+        const float o1 = O_2 - kGamma * (a1 + e1);
+        const float e2 = a2 - kBeta * (b1 + b2);
+        x_even = c1;
+        x_odd = b2 - kAlpha * (c1 + e2);
         O_2 = O_1; O_1 = O0; E_1 = E0;
         a2 = a1; a1 = e1;
         b2 = b1; b1 = o1;
@@ -499,51 +555,73 @@ __global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const flo
         det(bot + hx + kc, r.hh);
     };
     auto val = [&](const Det &t) { return prefix_value_of(t.o, t.c, t.l, B, rbase, rreach); };
-    // horizontal synthesis of one finished row: this pair's low-/high-pass samples -> its two output samples
+    // horizontal synthesis of one finished row: this pair's low-/high-pass samples -> its two output samples (neighbours
+    // through DPP wave shifts; the reference's boundary taps at the first and the last pair)
+    const bool first = !(k > 0), last = !(k + 1 < hx);
     auto hsynth = [&](float e_raw, float o_raw, float &even, float &odd) {
-        const float E0 = e_raw / kXi, O0 = o_raw * kXi;
-        const float Ol = __shfl_up(O0, 1), Or = __shfl_down(O0, 1);
-        const float e1 = E0 - kDelta * (O0 + (k > 0 ? Ol : Or));
-        const float e1l = __shfl_up(e1, 1), e1r = __shfl_down(e1, 1);
-        const float o1 = O0 - kGamma * (e1 + (k + 1 < hx ? e1r : e1l));
-        const float o1l = __shfl_up(o1, 1), o1r = __shfl_down(o1, 1);
-        const float e2 = e1 - kBeta * (o1 + (k > 0 ? o1l : o1r));
-        const float e2r = __shfl_down(e2, 1);
+        const float E0 = div_xi(e_raw), O0 = o_raw * kXi;
+        const float Ol = lane_below(O0), Or = lane_above(O0);
+        const float e1 = E0 - kDelta * (O0 + (first ? Or : Ol));
+        const float e1l = lane_below(e1), e1r = lane_above(e1);
+        const float o1 = O0 - kGamma * (e1 + (last ? e1l : e1r));
+        const float o1l = lane_below(o1), o1r = lane_above(o1);
+        const float e2 = e1 - kBeta * (o1 + (first ? o1r : o1l));
+        const float e2r = lane_above(e2);
         even = e2;
-        odd = (k + 1 < hx) ? o1 - kAlpha * (e2 + e2r) : o1 - (2 * kAlpha) * e2;
+        odd = last ? o1 - (2 * kAlpha) * e2 : o1 - kAlpha * (e2 + e2r);
     };
     double acc = 0;
     float mx = 0;
-    auto use = [&](bool mine, int y, int c, float v, float xv, float dv) {
-        if (!(mine && y < u.size_y && c < u.size_x)) return;
-        const float r = residual_value(v, dc, rmin, rng);
-        const float t = xv - (dv + r);
-        acc += (double) t;
-        const float e = fabsf(t);
-        mx = e > mx ? e : mx;
+    // the two finished samples (columns 2k, 2k + 1) of output row y against the frame
+    auto use_row = [&](bool mine, int y, float s0, float s1, float x0, float x1, float d0, float d1) {
+        const bool m0 = mine && y < u.size_y && 2 * k < u.size_x, m1 = mine && y < u.size_y && 2 * k + 1 < u.size_x;
+        const float t0 = x0 - (d0 + residual_value_fast(s0, dc, rmin, rng)), t1 = x1 - (d1 + residual_value_fast(s1, dc, rmin, rng));
+        acc += m0 ? (double) t0 : 0.0;
+        acc += m1 ? (double) t1 : 0.0;
+        mx = m0 ? fmaxf(mx, fabsf(t0)) : mx;
+        mx = m1 ? fmaxf(mx, fabsf(t1)) : mx;
     };
     RPipe pl, ph;
     Raw cur;
     fetch(jstart, cur);
     const int c0 = min(2 * kc, u.size_x - 1), c1 = min(2 * kc + 1, u.size_x - 1);
+    // 8-byte reads of the frame and the base layer (columns cp, cp + 1): even width, 8-byte aligned bases; the PAIR index is
+    // clamped (a clamped column would let a halo lane read one sample past the row, and past the buffer on the last one)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bool pair_io = (u.size_x & 1) == 0 && (u.n_pix & 1) == 0 && (((size_t) x | (size_t) d) & 7) == 0;
+    const unsigned cp = 2u * (unsigned) min(kc, max((u.size_x >> 1) - 1, 0));
     for (int j = jstart; j < kb + 4; j++) {
         Raw nxt;
         fetch(j + 1, nxt);
         // the frame's and the base layer's samples at the four positions this step finishes (clamped: dropped when outside)
-        const int kk = j - 4, y0 = min(max(2 * kk, 0), u.size_y - 1), y1 = min(max(2 * kk + 1, 0), u.size_y - 1);
-        const size_t i00 = (size_t) y0 * u.size_x + c0, i01 = (size_t) y0 * u.size_x + c1, i10 = (size_t) y1 * u.size_x + c0, i11 = (size_t) y1 * u.size_x + c1;
-        const float x00 = x[i00], x01 = x[i01], x10 = x[i10], x11 = x[i11], d00 = d[i00], d01 = d[i01], d10 = d[i10], d11 = d[i11];
+        const int kk = j - 4;
+        const unsigned y0 = (unsigned) min(max(2 * kk, 0), u.size_y - 1), y1 = (unsigned) min(max(2 * kk + 1, 0), u.size_y - 1);
+        float x00, x01, x10, x11, d00, d01, d10, d11;
+        if (pair_io) {
+            const unsigned i0 = y0 * (unsigned) u.size_x + cp, i1 = y1 * (unsigned) u.size_x + cp;
+            const f32x2 xa = *reinterpret_cast<const f32x2 *>(x + i0), xb = *reinterpret_cast<const f32x2 *>(x + i1);
+            const f32x2 da = *reinterpret_cast<const f32x2 *>(d + i0), db = *reinterpret_cast<const f32x2 *>(d + i1);
+            x00 = xa.x; x01 = xa.y; x10 = xb.x; x11 = xb.y; d00 = da.x; d01 = da.y; d10 = db.x; d11 = db.y;
+        } else {
+            const unsigned i00 = y0 * (unsigned) u.size_x + c0, i01 = y0 * (unsigned) u.size_x + c1, i10 = y1 * (unsigned) u.size_x + c0, i11 = y1 * (unsigned) u.size_x + c1;
+            x00 = x[i00]; x01 = x[i01]; x10 = x[i10]; x11 = x[i11]; d00 = d[i00]; d01 = d[i01]; d10 = d[i10]; d11 = d[i11];
+        }
         float le, lo, he, ho;
-        pl.step(j, half, cur.ll, val(cur.lh), le, lo);                   // low-pass column k: rows 2 kk, 2 kk + 1
-        ph.step(j, half, val(cur.hl), val(cur.hh), he, ho);              // high-pass column hx + k
-        float s00, s01, s10, s11;
-        hsynth(le, he, s00, s01);
-        hsynth(lo, ho, s10, s11);
+        if (j >= 4 && j < half) {                                        // (uniform) no boundary form anywhere in the step
+            pl.interior(cur.ll, val(cur.lh), le, lo);                    // low-pass column k: rows 2 kk, 2 kk + 1
+            ph.interior(val(cur.hl), val(cur.hh), he, ho);               // high-pass column hx + k
+        } else {
+            pl.step(j, half, cur.ll, val(cur.lh), le, lo);
+            ph.step(j, half, val(cur.hl), val(cur.hh), he, ho);
+        }
         const bool mine = owner && kk >= ka && kk < kb;
-        use(mine, 2 * kk, 2 * k, s00, x00, d00);
-        use(mine, 2 * kk, 2 * k + 1, s01, x01, d01);
-        use(mine, 2 * kk + 1, 2 * k, s10, x10, d10);
-        use(mine, 2 * kk + 1, 2 * k + 1, s11, x11, d11);
+        if (kk >= ka) {                                                  // (uniform: the warm-up steps of a piece put nothing out)
+            float s00, s01, s10, s11;
+            hsynth(le, he, s00, s01);
+            hsynth(lo, ho, s10, s11);
+            use_row(mine, 2 * kk, s00, s01, x00, x01, d00, d01);
+            use_row(mine, 2 * kk + 1, s10, s11, x10, x11, d10, d11);
+        }
         cur = nxt;
     }
     for (int q = 32; q >= 1; q >>= 1) { acc += __shfl_xor(acc, q); mx = fmaxf(mx, __shfl_xor(mx, q)); }
@@ -1062,6 +1140,23 @@ void launch_emit_image(float *image_out, const ResidualBuffers &rb, int n_frames
     size_t n_pix = (size_t) rb.g.size_x * rb.g.size_y;
     hipLaunchKernelGGL(k_emit_image, dim3(128, n_frames), dim3(256), 0, s, image_out, rb.A, rb.g, n_pix, rb.np, rb.fs);
     EBCC_HIP_LAUNCH_CHECK();
+}
+
+// host check of the division-free forms above against the divisions they replace (ebcc_hip_selfcheck): v / 255 for the 256
+// values it is used on, x / kXi for every significand at several exponents, zeros of both signs, and a sweep of all
+// exponents (the subnormal-remainder range takes the real division)
+int residual_selfcheck_divisions()
+{
+    int bad = 0;
+    for (int q = 0; q <= 255; q++) { const volatile float v = (float) q; if (div255_exact(v) != v / 255.0f) bad++; }
+    auto as_float = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    auto same = [&](float x) { const volatile float want = x / 1.149604398f; const float got = div_xi(x); return memcmp(&got, (const void *) &want, 4) == 0; };
+    for (uint32_t e : {127u, 132u, 110u, 150u})
+        for (uint32_t m = 0; m < (1u << 23); m++) if (!same(as_float((e << 23) | m))) bad++;
+    for (uint32_t e = 0; e < 255; e++)
+        for (uint32_t m = 0; m < (1u << 23); m += 4099) { if (!same(as_float((e << 23) | m))) bad++; if (!same(as_float(0x80000000u | (e << 23) | m))) bad++; }
+    if (!same(0.0f) || !same(-0.0f)) bad++;
+    return bad;
 }
 
 }  // namespace ebcc

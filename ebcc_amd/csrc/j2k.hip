@@ -72,7 +72,20 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->cand_sel = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
     ok &= (jb->have_rate = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
     ok &= (jb->rate_path = (int *) ctx_alloc<int32_t>(ctx, F * 1536 * 3)) != nullptr;
-    ok &= (jb->rate_path_n = (int *) ctx_alloc<int32_t>(ctx, F)) != nullptr;
+    ok &= (jb->rate_path_n = (int *) ctx_alloc<int32_t>(ctx, 2 * F)) != nullptr;          // (second half: RateCache::ok, reset together)
+    {
+        int nodes = 0;
+        for (const J2kGeom &t : jb->geoms) nodes = std::max(nodes, t.tree_nodes);
+        J2kBuffers::RateCache &rc = jb->rate_cache;
+        rc.nodes_cap = (nodes + 3) & ~3;
+        rc.cap = stride * kJ2kMaxPasses;
+        rc.ok = jb->rate_path_n ? jb->rate_path_n + F : nullptr;
+        ok &= (rc.mnmx = ctx_alloc<double>(ctx, F * 2)) != nullptr;
+        ok &= (rc.mval = (short *) ctx_alloc<uint16_t>(ctx, F * (size_t) rc.nodes_cap)) != nullptr;
+        ok &= (rc.off = (int *) ctx_alloc<int32_t>(ctx, F * (size_t) (stride + 1))) != nullptr;
+        ok &= (rc.crate = ctx_alloc<uint16_t>(ctx, F * (size_t) rc.cap)) != nullptr;
+        ok &= (rc.cdisto = ctx_alloc<double>(ctx, F * (size_t) rc.cap)) != nullptr;
+    }
     ok &= (jb->rates = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
     ok &= (jb->disto = ctx_alloc<double>(ctx, groups * 64 * kJ2kMaxPasses)) != nullptr;
     ok &= (jb->cblk_bytes = ctx_alloc<uint8_t>(ctx, groups * 64 * kJ2kCblkBytes)) != nullptr;
@@ -100,7 +113,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_jf, sizeof(J2kFrame) * F));
     EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_table, sizeof(int) * 4 * total));
     EBCC_HIP_CHECK(hipMemsetAsync(jb->jf, 0, sizeof(J2kFrame) * F, s));
-    EBCC_HIP_CHECK(hipMemsetAsync(jb->rate_path_n, 0, sizeof(int) * F, s));
+    EBCC_HIP_CHECK(hipMemsetAsync(jb->rate_path_n, 0, sizeof(int) * 2 * F, s));
     wait_stream(s);
     return true;
 }

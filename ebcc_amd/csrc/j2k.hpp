@@ -147,6 +147,17 @@ struct J2kBuffers {
     int *have_rate;               // [frames] 1: the current layer was taken over from a candidate (k_rate skips the frame)
     int *rate_path;               // [frames][1536][3] packet bytes at the steps of the rate bisection k_rate has visited, as a trie
     int *rate_path_n;             // [frames] nodes in it; reset by the analysis
+    // what every k_rate call for a frame needs and the first one works out (reset by the analysis with the trie): the zero-bit-plane
+    // tree minima, the table offsets, the slope range and the pass tables packed the way they are staged in LDS
+    struct RateCache {
+        int *ok;                  // [frames] 1: filled
+        double *mnmx;             // [frames][2]
+        short *mval;              // [frames][nodes_cap]
+        int *off;                 // [frames][stride + 1]
+        unsigned short *crate;    // [frames][cap] rates, code-block b's passes at off[b] ..
+        double *cdisto;           // [frames][cap]
+        int nodes_cap, cap;
+    } rate_cache;
     uint8_t *cblk_bytes;          // [frames*nblocks][kJ2kCblkBytes]
     uint8_t *stream;              // [frames][stream_cap] codestream
     size_t stream_cap;

@@ -1657,6 +1657,7 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
                          g.rh[kJ2kRes - 1] - g.rh[kJ2kRes - 2] >= 1;
     if (!fwd_top) hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.rate_path_n, 0, sizeof(int) * (size_t) n_frames, s));   // new pass tables: k_rate's record starts over
+    EBCC_HIP_CHECK(hipMemsetAsync(jb.rate_cache.ok, 0, sizeof(int) * (size_t) n_frames, s));  // ... and so does what it keeps of its set-up
     EBCC_HIP_CHECK(hipMemsetAsync(jb.lastnp, 0xFF, sizeof(int) * (size_t) total, s));         // and so does the probe decode's
     timing_begin("j2k_dwt_fwd", s);
     for (int r = kJ2kRes - 1; r >= 1; r--) {                           // opj_dwt_encode_procedure: vertical, then horizontal

@@ -253,19 +253,22 @@ struct PassTab {
 
 // opj_tcd_makelayer for one quality layer
 // opj_tcd_makelayer's greedy walk over the passes of code-block b: passes taken (count returned, bit mask in m0 / m1)
+// `from` > 0: the walk is taken up at pass `from` with passes [0, from) decided already - their mask in m0 / m1 on entry,
+// the last pass taken among them `n_in` (count, 0: none) - see the tail of k_rate's bisection
 template <bool LDS>
 __device__ inline int walk_block(const PassTab &pt, const int *totalpasses, int gid0, int b, double thresh, unsigned long long &m0,
-                                 unsigned long long &m1)
+                                 unsigned long long &m1, int from = 0, int n_in = 0)
 {
-    m0 = m1 = 0;
+    if (from == 0) m0 = m1 = 0;
     int tp;
     if constexpr (LDS) tp = pt.l_off[b + 1] - pt.l_off[b]; else tp = totalpasses[gid0 + b];
     const int base = pt.base_of<LDS>(b);
-    int n = 0;
+    int n = n_in;
     if (thresh < 0) return tp;
     int rbase = 0;                                                   // rate / distortion of the last pass taken
     double dbase = 0;
-    for (int p = 0; p < tp; p++) {
+    if (n_in > 0) { rbase = pt.rate<LDS>(base, n_in - 1); dbase = pt.dist<LDS>(base, n_in - 1); }
+    for (int p = from; p < tp; p++) {
         const int rp = pt.rate<LDS>(base, p);
         const double dp = pt.dist<LDS>(base, p);
         unsigned int dr;
@@ -290,6 +293,62 @@ __device__ inline int walk_block(const PassTab &pt, const int *totalpasses, int 
         }
     }
     return n;
+}
+
+// The thresholds at which a given greedy walk IS the walk: a pass with slope s = fl(dd / dr) is taken iff fl(thresh - s) <
+// DBL_EPSILON, which holds up to a limit T(s) and fails from it on (the difference is monotone in thresh).  So the walk
+// that takes exactly the passes of (m0, m1) from pass `from` on (the passes below it are given: last one taken n_in) is
+// the walk at thresh iff A <= thresh < B, with B the smallest limit of a pass it takes and A the largest limit of a pass
+// it leaves - two numbers per walk instead of a walk per threshold (the tail of k_rate's bisection).
+__device__ inline double next_up(double x)       // the next double above a finite x
+{
+    long long u = __double_as_longlong(x);
+    if (x == 0.0) return __longlong_as_double(1ll);
+    u += x > 0.0 ? 1 : -1;
+    return __longlong_as_double(u);
+}
+__device__ inline double next_down(double x) { return -next_up(-x); }
+__device__ inline double take_limit(double s)
+{
+    double t = s + DBL_EPSILON;                                        // close to the limit; settle on it exactly
+    for (int k = 0; k < 8 && (t - s) < DBL_EPSILON; k++) t = next_up(t);
+    for (int k = 0; k < 8; k++) { const double d = next_down(t); if ((d - s) < DBL_EPSILON) break; t = d; }
+    return t;
+}
+// [tlo, thi]: the bracket the thresholds to come lie in.  A pass whose slope is clearly outside it (by 1e-9 relative; only
+// used when the bracket is far above DBL_EPSILON) either does not constrain them at all or rules the walk out for all of
+// them - its exact limit is not needed, nor the division that gives its slope.
+template <bool LDS>
+__device__ inline void walk_interval(const PassTab &pt, const int *totalpasses, int gid0, int b, unsigned long long m0, unsigned long long m1,
+                                     int from, int n_in, double tlo, double thi, double &A, double &B)
+{
+    int tp;
+    if constexpr (LDS) tp = pt.l_off[b + 1] - pt.l_off[b]; else tp = totalpasses[gid0 + b];
+    const int base = pt.base_of<LDS>(b);
+    int n = n_in, rbase = 0;
+    double dbase = 0;
+    if (n_in > 0) { rbase = pt.rate<LDS>(base, n_in - 1); dbase = pt.dist<LDS>(base, n_in - 1); }
+    A = -DBL_MAX; B = DBL_MAX;
+    const bool coarse = tlo >= 1e-4;
+    for (int p = from; p < tp; p++) {
+        const int rp = pt.rate<LDS>(base, p);
+        const double dp = pt.dist<LDS>(base, p);
+        const unsigned int dr = n == 0 ? (unsigned int) rp : (unsigned int) (rp - rbase);
+        const double dd = n == 0 ? dp : dp - dbase;
+        const bool taken = p < 64 ? (m0 >> p) & 1ull : (m1 >> (p - 64)) & 1ull;
+        if (dr) {
+            const double fdr = (double) dr;
+            if (coarse && dd > thi * fdr * 1.000000001) {                // limit above every threshold to come
+                if (!taken) A = DBL_MAX;
+            } else if (coarse && dd < tlo * fdr * 0.999999999) {         // limit below every threshold to come
+                if (taken) B = -DBL_MAX;
+            } else {
+                const double lim = take_limit(dd / fdr);
+                if (taken) B = lim < B ? lim : B; else A = lim > A ? lim : A;
+            }
+        } else if (taken != (dd != 0)) { A = DBL_MAX; B = -DBL_MAX; }    // (cannot happen for a walk that was walked: never matches)
+        if (taken) { n = p + 1; rbase = rp; dbase = dp; }
+    }
 }
 
 // `path` (optional): [2][nblocks] bit masks of the passes taken, i.e. the whole greedy walk and not just its end;
@@ -504,7 +563,8 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                                                         int *__restrict__ npass_out, const J2kGeom *geom, J2kFrame *jf,
                                                         const FrameState *fs, const int *active, int pass_capacity,
                                                         int *__restrict__ path_bytes, int *__restrict__ path_n,
-                                                        const float *cand_cr, int *cand_out, size_t cand_stride, const int *have_rate)
+                                                        const float *cand_cr, int *cand_out, size_t cand_stride, const int *have_rate,
+                                                        J2kBuffers::RateCache cache)
 {
     extern __shared__ unsigned char lds_raw[];
     __shared__ int s_sum, s_changed;
@@ -530,7 +590,28 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     const int gid0 = frame * g.stride;
     RateLds L;
     L.carve(lds_raw, g.nblocks, g.tree_nodes);
-    trees_static<kRateThreads>(g, L, numbps, gid0, lane);
+#ifdef EBCC_RATE_PROFILE
+    long long t_s[5] = {0, 0, 0, 0, 0};
+    t_s[0] = wall_clock64() - t_start;
+#endif
+    // Set-up that is the same at every call for this frame - the trees' static minima, the table offsets, the slope range,
+    // the pass tables in the order they are staged - is worked out by the frame's first (recording) call and kept in
+    // global memory (J2kBuffers::RateCache, reset by the analysis): 58 us of every later call had been this.
+    const bool cached = cache.ok[frame] != 0;
+    short *const c_mval = cache.mval + (size_t) frame * cache.nodes_cap;
+    int *const c_off = cache.off + (size_t) frame * (size_t) (g.stride + 1);
+    unsigned short *const c_rate = cache.crate + (size_t) frame * (size_t) cache.cap;
+    double *const c_disto = cache.cdisto + (size_t) frame * (size_t) cache.cap;
+    if (cached) {
+        for (int i = lane; i < g.tree_nodes; i += kRateThreads) L.mval0[i] = c_mval[i];
+        __syncthreads();
+    } else {
+        trees_static<kRateThreads>(g, L, numbps, gid0, lane);
+        if (record) for (int i = lane; i < g.tree_nodes; i += kRateThreads) c_mval[i] = L.mval0[i];
+    }
+#ifdef EBCC_RATE_PROFILE
+    t_s[1] = wall_clock64() - t_start;
+#endif
     for (int b = lane; b < g.nblocks; b += kRateThreads) L.prev[b] = -1;
     // pass tables into LDS (behind the RateLds carve-up) when they fit
     __shared__ int s_fit;
@@ -543,15 +624,35 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     unsigned char *frozen = (unsigned char *) (p_hi + 2 * g.nblocks);
     double *l_disto = (double *) (frozen + (((size_t) g.nblocks + 7) & ~(size_t) 7));
     for (int b = lane; b < g.nblocks; b += kRateThreads) frozen[b] = 0;
-    for (int b = lane; b < g.nblocks; b += kRateThreads) l_off[b] = totalpasses[gid0 + b];
-    __syncthreads();
-    if (lane == 0) {
-        int acc = 0;
-        for (int b = 0; b < g.nblocks; b++) { const int tp = l_off[b]; l_off[b] = acc; acc += tp; }
-        l_off[g.nblocks] = acc;
-        s_fit = acc <= pass_capacity ? acc : -1;
+    // table offsets: exclusive prefix sums of the pass counts (block scan: wave shuffles + one LDS round per 512 code-blocks;
+    // a single lane walking the ~300 counts cost 8 us of every call)
+    if (cached) {
+        for (int b = lane; b <= g.nblocks; b += kRateThreads) l_off[b] = c_off[b];
+        if (lane == 0) { const int running = c_off[g.nblocks]; s_fit = running <= pass_capacity ? running : -1; }
+    } else {
+        __shared__ int s_scan[kRateThreads / 64];
+        int running = 0;
+        for (int base = 0; base < g.nblocks; base += kRateThreads) {
+            const int b = base + lane;
+            const int tp = b < g.nblocks ? totalpasses[gid0 + b] : 0;
+            int x = tp;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((lane & 63) >= d) x += y; }
+            if ((lane & 63) == 63) s_scan[lane >> 6] = x;
+            __syncthreads();
+            int before = running, tot = 0;
+            for (int w = 0; w < kRateThreads / 64; w++) { const int v = s_scan[w]; if (w < (lane >> 6)) before += v; tot += v; }
+            if (b < g.nblocks) l_off[b] = before + x - tp;
+            running += tot;
+            __syncthreads();
+        }
+        if (lane == 0) { l_off[g.nblocks] = running; s_fit = running <= pass_capacity ? running : -1; }
+        __syncthreads();
+        if (record) for (int b = lane; b <= g.nblocks; b += kRateThreads) c_off[b] = l_off[b];
     }
     __syncthreads();
+#ifdef EBCC_RATE_PROFILE
+    t_s[2] = wall_clock64() - t_start;
+#endif
     const int n_entries = s_fit;
     unsigned short *l_rate = (unsigned short *) (l_disto + (n_entries > 0 ? n_entries : 0));
     typedef __attribute__((address_space(3))) double lds_double;
@@ -559,16 +660,33 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     typedef __attribute__((address_space(3))) unsigned short lds_ushort;
     PassTab pt{rates + (size_t) gid0 * kJ2kMaxPasses, disto + (size_t) gid0 * kJ2kMaxPasses, (const lds_double *) l_disto,
                (const lds_ushort *) l_rate, (const lds_int *) l_off, n_entries >= 0};
-    if (pt.lds) {
-        for (int b = lane; b < g.nblocks; b += kRateThreads) {
-            const int tp = totalpasses[gid0 + b], o = l_off[b];
-            for (int p = 0; p < tp; p++) {
-                l_rate[o + p] = (unsigned short) pt.rates[(size_t) b * kJ2kMaxPasses + p];
-                l_disto[o + p] = pt.disto[(size_t) b * kJ2kMaxPasses + p];
+    if (pt.lds && cached) {
+        // (packed by the first call: a straight copy)
+        for (int i = lane; i < n_entries; i += kRateThreads) { l_rate[i] = c_rate[i]; l_disto[i] = c_disto[i]; }
+        __syncthreads();
+    } else if (pt.lds) {
+        // all threads over all (code-block, pass) slots of the frame's tables: consecutive threads read consecutive
+        // entries, nothing depends on the previous load (one thread per code-block copying its ~40 passes one after the
+        // other was 30 us of every call)
+        const int slots = g.nblocks * kJ2kMaxPasses;
+#pragma unroll 4
+        for (int idx = lane; idx < slots; idx += kRateThreads) {
+            // (the loads do not wait for the test: slots past a code-block's last pass exist and are simply not kept)
+            const int r_ = pt.rates[idx];
+            const double d_ = pt.disto[idx];
+            const int b = idx / kJ2kMaxPasses, p = idx - b * kJ2kMaxPasses;
+            const int o = l_off[b];
+            if (p < l_off[b + 1] - o) {
+                l_rate[o + p] = (unsigned short) r_;
+                l_disto[o + p] = d_;
+                if (record) { c_rate[o + p] = (unsigned short) r_; c_disto[o + p] = d_; }
             }
         }
         __syncthreads();
     }
+#ifdef EBCC_RATE_PROFILE
+    t_s[3] = wall_clock64() - t_start;
+#endif
     int prev_bytes = 0;
     // size of the current assignment; identical assignments (late bisection steps) reuse the previous result
     auto sized = [&]() -> int {
@@ -602,11 +720,15 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
 
     // slope range over consecutive passes (opj_tcd_rateallocate)
     double mn = DBL_MAX, mx = 0;
+    if (cached) { mn = cache.mnmx[2 * frame]; mx = cache.mnmx[2 * frame + 1]; }
+    else {
     for (int b = lane; b < g.nblocks; b += kRateThreads) {
-        const int tp = totalpasses[gid0 + b];
+        const int tp = l_off[b + 1] - l_off[b], o = l_off[b];
         int rprev = 0; double dprev = 0;
         for (int p = 0; p < tp; p++) {
-            const int rp = pt.rates[(size_t) b * kJ2kMaxPasses + p]; const double dp = pt.disto[(size_t) b * kJ2kMaxPasses + p];
+            // (from the LDS copies when there are any: the same values)
+            const int rp = pt.lds ? (int) l_rate[o + p] : pt.rates[(size_t) b * kJ2kMaxPasses + p];
+            const double dp = pt.lds ? l_disto[o + p] : pt.disto[(size_t) b * kJ2kMaxPasses + p];
             const int dr = rp - rprev; const double dd = dp - dprev;
             rprev = rp; dprev = dp;
             if (dr == 0) continue;
@@ -622,9 +744,12 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     if ((lane & 63) == 0) { s_min[lane >> 6] = mn; s_max[lane >> 6] = mx; }
     __syncthreads();
     for (int i = 0; i < kRateThreads / 64; i++) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
+    // the first recording call leaves all of the above for the later ones (the flag last: they are later launches)
+    if (record && lane == 0) { cache.mnmx[2 * frame] = mn; cache.mnmx[2 * frame + 1] = mx; if (pt.lds) cache.ok[frame] = 1; }
+    }
 
 #ifdef EBCC_RATE_PROFILE
-    long long t_setup = wall_clock64() - t_start, t_ml = 0, t_sz = 0; int n_it = 0, n_real = 0;
+    long long t_setup = wall_clock64() - t_start, t_ml = 0, t_sz = 0, t_replay_end = 0, t_tail = 0, t_loop_end = 0; int n_it = 0, n_real = 0, n_replayed = 0, n_tail = 0;
 #define RP_T0 const long long rp0 = wall_clock64()
 #define RP_ADD(acc) acc += wall_clock64() - rp0
 #else
@@ -655,6 +780,9 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             if (i > 0 && thresh == prev) break;                      // the remaining iterations would repeat this one
             prev = thresh;
             if (cur >= 0) {
+#ifdef EBCC_RATE_PROFILE
+                n_replayed++;
+#endif
                 const int bytes = trie[3 * cur];
                 const int f = (long long) bytes <= maxlen;
                 if (f) { hi = thresh; stable = thresh; bytes_hi = bytes; hi_from_rec = true; hi_seen = false; }
@@ -664,6 +792,9 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                 cur = nxt > 0 ? nxt : -1;                            //  this one are never followed, see below)
                 continue;
             }
+#ifdef EBCC_RATE_PROFILE
+            if (!t_replay_end) t_replay_end = wall_clock64();
+#endif
             // the walks at bracket ends that came from the record (needed to tell settled code-blocks)
             if (hi_from_rec) { make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, hi, lane, p_hi); hi_seen = true; hi_from_rec = false; }
             if (lo_from_rec) { make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, lo, lane, p_lo); lo_seen = true; lo_from_rec = false; }
@@ -723,20 +854,44 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
             // each, until the thresholds repeat or a step produces a third assignment, which goes back through the
             // block-wide path above.
             if (lo_seen && hi_seen && s_nun <= 64) {
+                RP_T0;
                 if (lane < 64) {
                     const int nb = g.nblocks, b = lane < s_nun ? s_list[lane] : -1;
                     double tlo = lo, thi = hi, tprev = prev, tstable = stable, tthresh = thresh;
                     int ti = i, tn = n_nodes, tparent = parent, tpdir = pdir, status = 0;
+                    // The two end walks of an open code-block agree on the passes below the first one they differ in, and
+                    // so does the walk at every threshold in between (the monotonicity argument above, applied to the
+                    // code-block cut off at that pass): a step only has to walk from there - the last pass or two of
+                    // ~40 - with the common part's mask and its last taken pass as the start state.
+                    int from = 0, n_in = 0;
+                    unsigned long long c0 = 0, c1 = 0;
+                    if (b >= 0) {
+                        const unsigned long long d0 = p_lo[b] ^ p_hi[b], d1 = p_lo[nb + b] ^ p_hi[nb + b];
+                        from = d0 ? __builtin_ctzll(d0) : (d1 ? 64 + __builtin_ctzll(d1) : 0);
+                        if (from > 0) {
+                            c0 = from >= 64 ? p_lo[b] : p_lo[b] & ((1ull << from) - 1ull);
+                            c1 = from > 64 ? p_lo[nb + b] & ((1ull << (from - 64)) - 1ull) : 0ull;
+                            n_in = c1 ? 128 - __builtin_clzll(c1) : (c0 ? 64 - __builtin_clzll(c0) : 0);   // (1 + index of the last pass taken)
+                        }
+                    }
+                    // ... and which thresholds give exactly the walk of the lower end, which exactly that of the upper
+                    // end, is worked out once per code-block (walk_interval): a step is then two comparisons per lane.
+                    double a_lo = -DBL_MAX, b_lo = DBL_MAX, a_hi = -DBL_MAX, b_hi = DBL_MAX;
+                    if (b >= 0) {
+                        if (pt.lds) {
+                            walk_interval<true>(pt, totalpasses, gid0, b, p_lo[b], p_lo[nb + b], from, n_in, tlo, thi, a_lo, b_lo);
+                            walk_interval<true>(pt, totalpasses, gid0, b, p_hi[b], p_hi[nb + b], from, n_in, tlo, thi, a_hi, b_hi);
+                        } else {
+                            walk_interval<false>(pt, totalpasses, gid0, b, p_lo[b], p_lo[nb + b], from, n_in, tlo, thi, a_lo, b_lo);
+                            walk_interval<false>(pt, totalpasses, gid0, b, p_hi[b], p_hi[nb + b], from, n_in, tlo, thi, a_hi, b_hi);
+                        }
+                    }
+                    (void) c0; (void) c1;
                     for (int j = i + 1; j < 128; j++) {
                         const double t = (tlo + thi) / 2;
                         if (t == tprev) { tthresh = t; break; }      // the bisection has ended
-                        unsigned long long m0 = 0, m1 = 0;
-                        if (b >= 0) {
-                            if (pt.lds) walk_block<true>(pt, totalpasses, gid0, b, t, m0, m1);
-                            else walk_block<false>(pt, totalpasses, gid0, b, t, m0, m1);
-                        }
-                        const int all_lo = __all(b < 0 || (m0 == p_lo[b] && m1 == p_lo[nb + b]));
-                        const int all_hi = __all(b < 0 || (m0 == p_hi[b] && m1 == p_hi[nb + b]));
+                        const int all_lo = __all(b < 0 || (t >= a_lo && t < b_lo));
+                        const int all_hi = __all(b < 0 || (t >= a_hi && t < b_hi));
                         if (!all_lo && !all_hi) { status = 1; break; }   // a third assignment: not committed here
                         tthresh = t; tprev = t; ti = j;
                         const int bytes = all_lo ? bytes_lo : bytes_hi;
@@ -763,11 +918,18 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
                 i = s_ti[0]; n_nodes = s_ti[1]; parent = s_ti[2]; pdir = s_ti[3];
                 const int status = s_ti[4];
                 __syncthreads();                                     // (s_td / s_ti are written again on the next visit)
+                RP_ADD(t_tail);
+#ifdef EBCC_RATE_PROFILE
+                n_tail++;
+#endif
                 if (status == 0) break;                              // ended in the tail: thresh, stable as the loop leaves them
             }
         }
         good = stable == 0 ? thresh : stable;
     }
+#ifdef EBCC_RATE_PROFILE
+    t_loop_end = wall_clock64();
+#endif
     if (!converged) make_layer<kRateThreads>(g, L, totalpasses, pt, gid0, good, lane);
     const int body = sized();
     for (int b = lane; b < g.nblocks; b += kRateThreads) npass_out[gid0 + b] = L.npass[b];
@@ -780,8 +942,10 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
         jf[frame].stream_bytes = kMainHeaderBytes + 12 + 2 + body + 2;
         jf[frame].maxlen = (int) (rate > 0.0f ? ceil((double) rate) : 0);
 #ifdef EBCC_RATE_PROFILE
-        if (frame == 0) printf("k_rate frame0: setup %lld us, make_layer %lld us, sized %lld us, iterations %d (real sizings %d), total %lld us\n",
-                               t_setup / 100, t_ml / 100, t_sz / 100, n_it, n_real, (wall_clock64() - t_start) / 100);
+        if (frame == 0) printf("k_rate frame0 setup: entry %lld, trees %lld, offsets %lld, tables %lld us\n", t_s[0] / 100, t_s[1] / 100, t_s[2] / 100, t_s[3] / 100);
+        if (frame == 0) printf("k_rate frame0: setup %lld us, %d replayed steps until %lld us, make_layer %lld us, sized %lld us, computed iterations %d (real sizings %d), tail %lld us in %d visits, loop ends at %lld us, total %lld us\n",
+                               t_setup / 100, n_replayed, t_replay_end ? (t_replay_end - t_start) / 100 : -1, t_ml / 100, t_sz / 100, n_it, n_real, t_tail / 100, n_tail,
+                               (t_loop_end - t_start) / 100, (wall_clock64() - t_start) / 100);
 #endif
     }
 }
@@ -1375,7 +1539,7 @@ static void rate_launch(const J2kBuffers &jb, int n_frames, const int *d_active,
     });
     hipLaunchKernelGGL(k_rate, dim3(n_frames, candidates ? 2 : 1), dim3(kRateThreads), lds, s, jb.numbps, jb.totalpasses, jb.rates,
                        jb.disto, candidates ? jb.cand_npass : jb.npass, jb.d_geom, jb.jf, jb.fs, d_active, (int) want, jb.rate_path, jb.rate_path_n,
-                       candidates ? jb.cand_cr : nullptr, jb.cand_out, (size_t) jb.max_frames * (size_t) jb.geom.stride, have_rate);
+                       candidates ? jb.cand_cr : nullptr, jb.cand_out, (size_t) jb.max_frames * (size_t) jb.geom.stride, have_rate, jb.rate_cache);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

@@ -46,7 +46,7 @@ hipError_t device_malloc(void **p, size_t bytes);
 
 // Host wait for a stream.  By default through an event created with hipEventBlockingSync: the waiting thread sleeps
 // instead of spinning (hipStreamSynchronize spins on a core for as long as the GPU works - two slice threads waiting are
-// two of the container's CPUs, taken from the zstd workers).  EBCC_HIP_SPIN_SYNC=1 restores hipStreamSynchronize.
+// two of the container's CPUs, taken from the zstd workers).
 void wait_stream(hipStream_t s);
 
 constexpr int kWave = 64;             // CDNA wavefront

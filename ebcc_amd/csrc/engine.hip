@@ -29,8 +29,6 @@ void set_error(const char *fmt, ...)
 
 void wait_stream(hipStream_t s)
 {
-    static const bool spin = getenv("EBCC_HIP_SPIN_SYNC") && atoi(getenv("EBCC_HIP_SPIN_SYNC")) != 0;
-    if (spin) { EBCC_HIP_CHECK(hipStreamSynchronize(s)); return; }
     // events come from a per-device free list (an event belongs to the device that was current when it was made; slice
     // threads are short-lived, so nothing is kept per thread)
     static std::mutex m;

@@ -335,7 +335,7 @@ static void host_copy_parallel(void *dst, const void *src, size_t bytes)
 }
 static void copy_pageable(ebcc_hip_ctx *ctx, void *host, void *dev, size_t bytes, bool to_host)
 {
-    if (bytes < 2 * kBounceBytes || getenv("EBCC_HIP_PLAIN_COPIES")) {
+    if (bytes < 2 * kBounceBytes) {
         EBCC_HIP_CHECK(hipMemcpy(to_host ? host : dev, to_host ? dev : host, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
         return;
     }
@@ -840,14 +840,14 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
     int *const d_active = lane ? ctx->d_active + ctx->max_frames : b.d_active;
     hipStream_t s = lane ? second_stream(ctx) : b.s;
     J2kBuffers &jb = b.jb;
-    const int forced = getenv("EBCC_HIP_NO_SPECULATION") ? 0 : (getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1);
+    const int forced = getenv("EBCC_HIP_SPECULATION") ? atoi(getenv("EBCC_HIP_SPECULATION")) != 0 : -1;
     const bool speculate = lane == 0 && (forced >= 0 ? forced != 0 : slices <= 1);   // (lane 1 runs on the stream the candidates would use)
     hipStream_t s2 = nullptr;
-    // probes that only steer the search stop counting once they are certainly infeasible (search.hpp); EBCC_HIP_EXACT_PROBES=1
+    // probes that only steer the search stop counting once they are certainly infeasible (search.hpp); EBCC_HIP_NO_SHORTCUTS=1
     // and TRACE logging (which prints every probe's count) keep every probe exact
     double jobs_qt0 = 0.0;                                               // the error-bounded search's quantile target (0: it never ran)
     for (size_t f = 0; f < n; f++) if (!jobs[f].const_field) { jobs_qt0 = jobs[f].rs[0].qt; break; }
-    const double limit_qt = getenv("EBCC_HIP_EXACT_PROBES") || g_log_level <= 0 ? 0.0 : std::min(jobs_qt0, 1.0);
+    const double limit_qt = getenv("EBCC_HIP_NO_SHORTCUTS") || g_log_level <= 0 ? 0.0 : std::min(jobs_qt0, 1.0);
     auto advance = [&]() {
         launch_search_advance(d, jb.jf, d_active, (int) n, (int) b.tiles, k, (double) n_pix, d_counter, s,
                               speculate ? jb.cand_cr : nullptr, speculate ? jb.cand_sel : nullptr, limit_qt);
@@ -887,7 +887,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
     EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, s));
     EBCC_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(int) * 4, s));
     // a round = the probe the previous advance asked for (rate allocation + decode of the active chunks), then the advance
-    // that takes it in and asks for the next one.  Speculative rate allocation (EBCC_HIP_NO_SPECULATION=1 turns it off): a
+    // that takes it in and asks for the next one.  Speculative rate allocation: a
     // step of the search can go two ways, so the layers of both rates it may ask for next are worked out on the engine's
     // second stream while the first stream decodes the current probe; the advance then takes the matching one over
     // (k_rate_publish) and the round's own k_rate only runs for the frames whose rate was not among the guesses.
@@ -979,11 +979,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         push_frame_states(ctx, nt);
     }
     launch_j2k_analysis(d_frames, jb, (int) nt, s);
-    if (next) {                                   // the next slice may start: this one's first stage is queued
-        const char *e = getenv("EBCC_HIP_SLICE_GATE");
-        if (e && atoi(e) == 1) { wait_stream(s); }
-        next->release(); release_on_exit.g = nullptr;
-    }
+    if (next) { next->release(); release_on_exit.g = nullptr; }       // the next slice may start: this one's first stage is queued
     fetch_frame_states(ctx, nt);
     b.fetch_jf();
     if (j2k_tier1_retry(jb, (int) nt, b.tjf, s)) b.fetch_jf();        // (a group's decisions outgrew the segmented encoder's buffer)
@@ -1064,8 +1060,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         //      layer and the truncation search; it is taken up again where the reference runs it (below).  Round 2 measured
         //      this slower - the search was hidden behind the level-22 zstd of every prefix then; with the entropy stage cut
         //      down to the prefixes whose size can matter, the search was what the slice waited for, and its sizes are what
-        //      decides which prefixes those are.  EBCC_HIP_SEARCH2_SERIAL=1: in the reference's place.
-        const bool overlap2 = want_pure && tiles == 1 && rc == ctx && !getenv("EBCC_HIP_HOST_SEARCH") && !getenv("EBCC_HIP_SEARCH2_SERIAL");
+        //      decides which prefixes those are.  (With EBCC_HIP_HOST_SEARCH=1 it runs in the reference's place.)
+        const bool overlap2 = want_pure && tiles == 1 && rc == ctx && !getenv("EBCC_HIP_HOST_SEARCH");
         struct DrainSecond {               // an error return between here and the take-up must not leave rounds in flight
             ebcc_hip_ctx *c; bool armed;
             ~DrainSecond() { if (armed && c->stream2) hipStreamSynchronize(c->stream2); }
@@ -1272,7 +1268,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         };
         std::vector<size_t> with_prefix;
         for (size_t f = 0; f < n; f++) if (jobs[f].coeffs_size > 0) with_prefix.push_back(f);
-        const bool use_floor = want_pure && zstd_floor_usable() && !getenv("EBCC_HIP_ZSTD_ALL");
+        const bool use_floor = want_pure && zstd_floor_usable() && !getenv("EBCC_HIP_NO_SHORTCUTS");
         std::vector<size_t> cand;
         if (!want_pure) {
             longest_first(with_prefix);
@@ -1548,7 +1544,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     // The residual layer (SPIHT decode + synthesis: one wave per frame, latency-bound) does not depend on the
     // base layer until the final addition, so it runs on the engine's second stream beside the tier-1 decode.
     hipStream_t s2 = s;
-    if (any_resid && !getenv("EBCC_HIP_SERIAL_DECODE")) {
+    if (any_resid) {
         s2 = second_stream(ctx);
         if (!ctx->ev_a) {
             EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));

@@ -851,9 +851,8 @@ int dwt_cols(float *B, const J2kBuffers &jb, int r, int n_frames, const FrameSta
     const int n = max_rows(jb, r), cols = jb.geom.rw[r];
     if (n <= 1) return 0;
     if constexpr (FIN && !FWD) {
-        // plain frames (every column starts with a low-pass sample): the streaming form; EBCC_HIP_FIN_LDS=1 keeps the LDS tiles
-        const bool lds_form = getenv("EBCC_HIP_FIN_LDS") != nullptr;
-        if (jb.geom.period == 1 && jb.geom.ry0[r] % 2 == 0 && !lds_form) {
+        // plain frames (every column starts with a low-pass sample): the streaming form
+        if (jb.geom.period == 1 && jb.geom.ry0[r] % 2 == 0) {
             hipLaunchKernelGGL(k_j2k_cols_fin, dim3(ceil_div(cols, kFinT), n_frames), dim3(kFinT), 0, s, B, jb.d_geom, r, fs, active, fin);
             return ceil_div(cols, kFinT);
         }
@@ -1291,14 +1290,14 @@ struct RowSrcDev {
     }
 };
 struct HandDev {
-    uint32_t buf;                  // LDS byte address of this lane's word 0 of row 0 of buffer 0: [row % (2 kRowChunk)][j][lane] 16-bit words
+    uint32_t buf;                  // LDS byte address of this lane's word 0 of row 0 of buffer 0: [row % (2 kRowChunk)][j][lane] 32-bit words
     __device__ void put(uint32_t row, int j, uint32_t word) const
     {
-        *(__attribute__((address_space(3))) unsigned short *) (uintptr_t) (buf + ((row % (2 * kRowChunk)) * 16u + (uint32_t) j) * 128u) = (unsigned short) word;
+        *(__attribute__((address_space(3))) uint32_t *) (uintptr_t) (buf + ((row % (2 * kRowChunk)) * 16u + (uint32_t) j) * 256u) = word;
     }
     __device__ uint32_t get(uint32_t row, int j) const
     {
-        return *(const __attribute__((address_space(3))) unsigned short *) (uintptr_t) (buf + ((row % (2 * kRowChunk)) * 16u + (uint32_t) j) * 128u);
+        return *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (buf + ((row % (2 * kRowChunk)) * 16u + (uint32_t) j) * 256u);
     }
 };
 struct MqSinkLds {
@@ -1328,15 +1327,15 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
                                                     const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows)
 {
     __shared__ uint2 tab_store[128];
-    __shared__ uint32_t ctxw[CtxLds2::kBytes / 4];
+    __shared__ uint32_t ctxw[CtxSlotsLds::kBytes / 4];
     __shared__ uint32_t bring[17 * 64];
     __shared__ uint4 rowbuf[2 * kRowChunk * 64];
-    __shared__ unsigned short handbuf[2 * kRowChunk * 16 * 64];
+    __shared__ uint32_t handbuf[2 * kRowChunk * 16 * 64];
     __shared__ uint32_t a_end[64];
     const int lane = (int) threadIdx.x & 63;
     const bool code_wave = threadIdx.x >= 64;
-    fill_mq_table2(tab_store);
-    const LdsTable2 tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
+    fill_mq_table_next(tab_store);
+    const LdsTableNext tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
     const size_t grp = blockIdx.x;
     const int gid = (int) (grp * 64) + lane;
     const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
@@ -1350,12 +1349,18 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
     const bool on = nrows > 0;
     const int P = on ? l.P : 0, nstr = (l.h + 3) >> 2;
     CkObserver ck{J2kCkptView::of(ckpt, (size_t) gid), nullptr, (uint32_t) lane * 8u};
-    const HandDev hand{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned short *) handbuf + (uint32_t) lane * 2u};
+    const HandDev hand{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) handbuf + (uint32_t) lane * 4u};
     const uint32_t nchunks = (wrows + kRowChunk - 1) / kRowChunk;
     if (!code_wave) {
         RowSrcDev src{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint4 *) rowbuf + (uint32_t) lane * 16u, nrows, wrows};
-        const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + (uint32_t) lane * 2u;
-        a_end[lane] = t1::mq_rows_interval(src, CtxLds2{ctx_base}, P, nstr, hand, ck, tab);
+        const uint32_t ctx_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + (uint32_t) lane * 4u;
+#if defined(EBCC_MQ_EXPERIMENT_SKIP_INTERVAL)
+        for (uint32_t row = 0; row < wrows; row++) { src.sync(row); if (row < nrows) { uint32_t w[4]; src.load(row, w); for (int j = 0; j < 16; j++) hand.put(row, j, (w[j >> 2] >> (8 * (j & 3))) & 0x1F); } }
+        src.finish();
+        a_end[lane] = 0x8000u;                                           // (timing experiment: no interval chain)
+#else
+        a_end[lane] = t1::mq_rows_interval(src, CtxSlotsLds{ctx_base}, P, nstr, hand, ck, tab);
+#endif
         __syncthreads();                                                 // (a_end, and this wave's checkpoint stores, before the other wave's epilogue)
         return;
     }
@@ -1391,7 +1396,11 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
                     uint32_t hw[16];
 #pragma unroll
                     for (int j = 0; j < 16; j++) hw[j] = hand.get(row, j);
-                    chain.row(hw, nstr, myrates, sink, ck, tab, [](bool b) { return __any(b) != 0; });
+#if defined(EBCC_MQ_EXPERIMENT_SKIP_CODE)
+                    if (hw[0] == 0x12345u) chain.row(hw, nstr, myrates, sink, ck, [](bool b) { return __any(b) != 0; });   // (timing experiment: the code chain never runs)
+#else
+                    chain.row(hw, nstr, myrates, sink, ck, [](bool b) { return __any(b) != 0; });
+#endif
                 }
             }
         }
@@ -1652,8 +1661,8 @@ void launch_j2k_analysis(const float *data, const J2kBuffers &jb, int n_frames, 
     const size_t n_pix = (size_t) g.W * g.H;
     const int total = n_frames * g.stride;
     hipLaunchKernelGGL(k_jf_reset, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, jb.jf, n_frames);
-    // plain frames: scaling, DC shift and the top level's column pass in one streaming kernel (EBCC_HIP_FWD_SPLIT=1: separate)
-    const bool fwd_top = !getenv("EBCC_HIP_FWD_SPLIT") && g.period == 1 && g.ry0[kJ2kRes - 1] % 2 == 0 && g.rh[kJ2kRes - 2] >= 2 &&
+    // plain frames: scaling, DC shift and the top level's column pass in one streaming kernel
+    const bool fwd_top = g.period == 1 && g.ry0[kJ2kRes - 1] % 2 == 0 && g.rh[kJ2kRes - 2] >= 2 &&
                          g.rh[kJ2kRes - 1] - g.rh[kJ2kRes - 2] >= 1;
     if (!fwd_top) hipLaunchKernelGGL(k_scale_shift, dim3(128, n_frames), dim3(256), 0, s, data, jb.B, n_pix, fs);
     EBCC_HIP_CHECK(hipMemsetAsync(jb.rate_path_n, 0, sizeof(int) * (size_t) n_frames, s));   // new pass tables: k_rate's record starts over
@@ -1684,14 +1693,12 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
     int partials = 0;
     // plain frames: every level in one fused pass (k_j2k_level5_fin: horizontal synthesis in registers, vertical register
     // pipeline), alternating between the tile buffer and jb.B2 from the first level that is large enough; the levels
-    // below it, tiles at odd offsets and EBCC_HIP_L5_SPLIT=1 use the separate LDS-staged row / column passes in place.
-    // EBCC_HIP_LEVELS_SPLIT=1: only the top level fused (round 2's first state).
-    const bool split5 = getenv("EBCC_HIP_L5_SPLIT") != nullptr, split_low = getenv("EBCC_HIP_LEVELS_SPLIT") != nullptr;
+    // below it and tiles at odd offsets use the separate LDS-staged row / column passes in place.
     const J2kGeom &g = jb.geom;
     const size_t n_pix = (size_t) g.W * g.H;
     auto fusable = [&](int r) {
-        return !split5 && V && g.period == 1 && g.ry0[r] % 2 == 0 && g.rw[r - 1] >= 2 && g.rh[r - 1] >= 1 &&
-               (r == kJ2kRes - 1 ? ceil_div(g.rw[r - 1], kL5Pairs) <= kPartials : (!split_low && jb.B2 != nullptr));
+        return V && g.period == 1 && g.ry0[r] % 2 == 0 && g.rw[r - 1] >= 2 && g.rh[r - 1] >= 1 &&
+               (r == kJ2kRes - 1 ? ceil_div(g.rw[r - 1], kL5Pairs) <= kPartials : jb.B2 != nullptr);
     };
     int first_fused = kJ2kRes;                                          // levels first_fused .. top are fused (sizes grow with r)
     for (int r = kJ2kRes - 1; r >= 1 && fusable(r); r--) first_fused = r;
@@ -1705,8 +1712,8 @@ int j2k_inverse_dwt(float *B, const int32_t *V, const float *data, const J2kBuff
             while (pieces > 1 && (long long) n_frames * pieces > 65535) pieces--;            // (grid y)
             // neighbouring strips of a tile as the waves of one workgroup, four at a time (measured per 128-frame probe round,
             // tools/gpu/kstat.sh: 1 wave 231 us, 4 waves 220, 6 waves 258, all 12 strips 264 - a large workgroup needs all
-            // its wave slots free on one CU at once); EBCC_HIP_FUSE_WAVES overrides
-            static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES") ? std::max(1, std::min(kL5MaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES")))) : 4;
+            // its wave slots free on one CU at once)
+            const int wave_cap = 4;
             const int wg = std::min(strips, wave_cap), groups = ceil_div(strips, wg);
             if (r > 1 && !ll) ll = B;                                   // (the separate passes below left their result in B)
             J2kLevelIO io{ll, g.W, n_pix, nullptr, g.W, n_pix, r};

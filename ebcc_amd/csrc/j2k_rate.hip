@@ -13,7 +13,6 @@
 
 #include "j2k.hpp"
 #include "t1_core.hpp"
-#include "t1_decode.hpp"
 #include "t1_device.hpp"
 
 namespace ebcc {
@@ -1137,33 +1136,7 @@ struct DecSrc {
 
 // Decodes the segments located by the host-side packet parser (dec_table): offset, length, numbps, passes.
 // (Rate probes do not come through here: they restart from checkpoints, k_t1_resume below.)
-__global__ __launch_bounds__(64) void k_t1_decode(unsigned long long *T1S, const uint8_t *bytes, size_t stream_cap,
-                                                   const int *dec_table, int32_t *V, const J2kGeom *geom,
-                                                   const J2kBlock *blocks, const FrameState *fs, int total, int lpw)
-{
-    EBCC_LDS_MQ_TABLE(tab);
-    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
-    const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
-    const int gid = gid0 + threadIdx.x;
-    if (gid >= total) return;
-    const int nb = geom->stride;
-    const int frame = gid / nb, bi = gid - frame * nb;
-    if (fs[frame].const_field) return;
-    blocks = j2k_frame_blocks(geom, blocks, frame);
-    geom = &j2k_frame_geom(geom, frame);
-    const int *e = dec_table + (size_t) gid * 4;
-    const int len = e[1], P = e[2], np = e[3];
-    const uint8_t *src = bytes + (size_t) frame * stream_cap + e[0];
-    if (np <= 0 || P <= 0) return;
-    const J2kBlock blk = blocks[bi];
-    const size_t grp = (size_t) (gid0 >> 6);
-    DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (uint32_t) ((gid0 & 63) + threadIdx.x) * 8u,
-                V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
-    t1::decode_block(st, DecSrc{src, len}, blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
-}
-
-
-// ---- the same decoder with its state next to the SIMD: the four row-mask arrays of a code-block (S, NEG, VIS, REF: 258
+// ---- the decoder with its state next to the SIMD: the four row-mask arrays of a code-block (S, NEG, VIS, REF: 258
 // rows of 8 bytes) live in LDS, not in jb.T1S, and the segment's bytes come through a register window that is one
 // 16-byte chunk ahead of the decoder.  A stripe of a coding pass starts with 16-20 row loads and ends with 12 row stores:
 // from HBM/L2 every one of the ~500 stripe-passes of a code-block cost a round trip (and a load also waits for the value
@@ -1287,82 +1260,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     t1::decode_block(st, DecSrcAhead(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
 }
 
-
-// ---- the same decode with the segment-locked decoder (t1_decode.hpp): one wave per group of 64 code-blocks, a
-// code-block per lane, every lane in the same (bit-plane, pass, stripe).  The bytes of a code-block's segment come
-// through a 256-byte ring per lane in LDS that the wave tops up at the start of every coding pass (and whenever a lane
-// runs short): the decision loops read LDS only.
-constexpr int kRingBytes = 256, kRingStride = 272;                       // (16-byte aligned rows for the 128-bit LDS stores)
-struct RingBytes {
-    const uint8_t *base;           // 16-byte aligned address at or before the segment's first byte
-    uint32_t ring;                 // LDS byte address of this lane's ring
-    int a0, len, filled;           // offset of the first byte inside its aligned chunk; segment bytes; bytes (from base) in the ring
-    __device__ uint32_t get(int i) const
-    {
-        if (i >= len) return 0xFFu;                                     // C.3.4: past the end of the segment
-        return *(const __attribute__((address_space(3))) unsigned char *) (uintptr_t) (ring + (((uint32_t) (i + a0)) & (kRingBytes - 1)));
-    }
-    // 16-byte chunks from global memory while the ring has room behind the decoder's position `pos`
-    __device__ void top_up(int pos)
-    {
-        while (filled < len + a0 && filled + 16 - (pos + a0) <= kRingBytes) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = *(const u32x4 *) (base + filled);
-            *(__attribute__((address_space(3))) u32x4 *) (uintptr_t) (ring + ((uint32_t) filled & (kRingBytes - 1))) = v;
-            filled += 16;
-        }
-    }
-};
-struct DecEnv {
-    RingBytes src;
-    __device__ bool any(bool b) const { return __any(b) != 0; }
-    __device__ RingBytes &bytes() { return src; }
-    __device__ bool starved(int pos) const { return pos + src.a0 >= src.filled && src.filled < src.len + src.a0; }
-    __device__ void refill_point(int pos) { src.top_up(pos); }
-    __device__ void pass_point(int pos) { src.top_up(pos); }
-};
-
-__global__ __launch_bounds__(64) void k_t1_decode_seg(unsigned long long *T1S, const uint8_t *bytes, size_t stream_cap,
-                                                       const int *dec_table, int32_t *V, const J2kGeom *geom,
-                                                       const J2kBlock *blocks, const FrameState *fs, int total)
-{
-    __shared__ uint2 tab_store[128];
-    __shared__ uint32_t ctxw[CtxLds2::kBytes / 4];
-    __shared__ uint32_t rings[64 * kRingStride / 4];
-    fill_mq_table2(tab_store);
-    __syncthreads();
-    const LdsTable2 tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
-    const size_t grp = blockIdx.x;
-    const int gid = (int) (grp * 64) + (int) threadIdx.x;
-    int len = 0, P = 0, np = 0, w = 1, h = 1, orient = 0;
-    const uint8_t *src = bytes;
-    int32_t *v = V;
-    int W = 1;
-    if (gid < total) {
-        const int nb = geom->stride;
-        const int frame = gid / nb, bi = gid - frame * nb;
-        if (!fs[frame].const_field) {
-            const J2kGeom &g = j2k_frame_geom(geom, frame);
-            const J2kBlock blk = j2k_frame_blocks(geom, blocks, frame)[bi];
-            const int *e = dec_table + (size_t) gid * 4;
-            len = e[1]; P = e[2]; np = e[3];
-            if (np <= 0 || P <= 0) { P = 0; np = 0; len = 0; }
-            src = bytes + (size_t) frame * stream_cap + e[0];
-            w = blk.w; h = blk.h; orient = g.bands[blk.band].orient; W = g.W;
-            v = V + (size_t) frame * g.W * g.H + (size_t) blk.y * g.W + blk.x;
-        }
-    }
-    int pmax = P;
-    for (int d = 32; d >= 1; d >>= 1) pmax = max(pmax, __shfl_xor(pmax, d));
-    pmax = __builtin_amdgcn_readfirstlane(pmax);
-    if (pmax <= 0) return;
-    DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), threadIdx.x * 8u, v, W};
-    CtxLds2 cx{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) ctxw + threadIdx.x * 2u};
-    const int a0 = (int) ((uintptr_t) src & 15);
-    DecEnv env{RingBytes{src - a0, (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint32_t *) rings + threadIdx.x * kRingStride, a0, len, 0}};
-    env.src.top_up(0);                                                   // (the decoder's first bytes)
-    t1::decode_block_segments(st, cx, tab, env, w, h, orient, P, np, pmax);
-}
 
 // ================================================================================================
 // rate-probe decode, restarted at the last coding pass the layer keeps
@@ -1618,43 +1515,27 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     const int total = n_frames * jb.geom.stride;
     const size_t groups = ((size_t) total + 63) / 64;
     EBCC_HIP_CHECK(hipMemsetAsync(jb.V, 0, (size_t) n_frames * n_pix * sizeof(int32_t), s));
-    const bool seg_decoder = getenv("EBCC_HIP_T1_DECODE_SEG") != nullptr;
-    const bool global_state = getenv("EBCC_HIP_T1_DECODE_GLOBAL") != nullptr;         // (the decoder with its state in jb.T1S)
-    int lpw = t1_lanes_per_wave(T1_DECODE);
+    int lpw = std::min(16, t1_lanes_per_wave(T1_DECODE));              // (the state row masks of a wave's code-blocks live in LDS: at most 16)
     // few code-blocks (a frame or a few decoded alone, e.g. from an HDF5 filter callback): there are wave slots to spare and
     // a wave per code-block ends soonest (one 721 x 1440 frame through ebcc_decode: 16.8 -> 8.6 ms)
-    const bool few_blocks = !getenv("EBCC_T1_LPW") && !getenv("EBCC_T1_DEC_MIX") && total <= 4096;
+    const bool few_blocks = !getenv("EBCC_T1_LPW") && total <= 4096;
     if (few_blocks) lpw = 1;
-    const bool lds_state = !seg_decoder && !global_state && lpw <= 16;
-    if (!lds_state) EBCC_HIP_CHECK(hipMemsetAsync(jb.T1S, 0, groups * kT1StateWords * 64 * sizeof(unsigned long long), s));
     timing_begin("t1_decode", s);
-    // EBCC_HIP_T1_DECODE_SEG=1: the segment-locked decoder (t1_decode.hpp) - identical results, 64 code-blocks per wave;
-    // measured 67 ms per 256 frames against 29 ms for the per-sample decoder at 4 code-blocks per wave (its decision loop
-    // is still ~600 instructions), so it is not the default
-    if (seg_decoder) {
-        hipLaunchKernelGGL(k_t1_decode_seg, dim3((unsigned) groups), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap, jb.dec_table, jb.V,
-                           jb.d_geom, jb.d_blocks, jb.fs, total);
-    } else {
-        if (lds_state) {
-            int *counters = jb.dec_order + groups * 64;
-            EBCC_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * kDecClasses * sizeof(int), s));
-            hipLaunchKernelGGL(k_dec_hist, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, total);
-            hipLaunchKernelGGL(k_dec_offsets, dim3(1), dim3(kDecClasses), 0, s, counters);
-            hipLaunchKernelGGL(k_dec_place, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, jb.dec_order, total);
-            // EBCC_T1_DEC_MIX = "<d>,<n>": the longest 1/d of the code-blocks at `lpw` lanes per wave, the rest at n (default 32,4;
-            // 256 frames: 27.3 ms all at 2 lanes, 23.5 ms with 32,4, 34 ms with 16,8 - tools/gpu/dec_mix.sh)
-            int den = 32, lpw_small = 4;
-            if (const char *e = getenv("EBCC_T1_DEC_MIX")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && (b == 1 || b == 2 || b == 4 || b == 8 || b == 16)) { den = a; lpw_small = b; } }
-            if (few_blocks) lpw_small = 1;
-            if (lpw_small < lpw) lpw_small = lpw;
-            const int n_big = lpw_small == lpw ? total : std::min(total, ceil_div(ceil_div(total, den), lpw) * lpw);
-            const unsigned waves = (unsigned) (ceil_div(n_big, lpw) + ceil_div(total - n_big, lpw_small));
-            hipLaunchKernelGGL(k_t1_decode_lds, dim3(waves), dim3(64), (size_t) kDecStateRows * std::max(lpw, lpw_small) * 8, s, jb.stream,
-                               jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw, n_big, lpw_small);
-        }
-        else
-            hipLaunchKernelGGL(k_t1_decode, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.stream, jb.stream_cap,
-                               jb.dec_table, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw);
+    {
+        int *counters = jb.dec_order + groups * 64;
+        EBCC_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * kDecClasses * sizeof(int), s));
+        hipLaunchKernelGGL(k_dec_hist, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, total);
+        hipLaunchKernelGGL(k_dec_offsets, dim3(1), dim3(kDecClasses), 0, s, counters);
+        hipLaunchKernelGGL(k_dec_place, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, jb.dec_order, total);
+        // the longest 1/32 of the code-blocks at `lpw` lanes per wave, the rest at 4 (256 frames: 27.3 ms all at 2 lanes,
+        // 23.5 ms with this mix, 34 ms with 1/16 and 8 lanes - measured in round 2)
+        const int den = 32;
+        int lpw_small = few_blocks ? 1 : 4;
+        if (lpw_small < lpw) lpw_small = lpw;
+        const int n_big = lpw_small == lpw ? total : std::min(total, ceil_div(ceil_div(total, den), lpw) * lpw);
+        const unsigned waves = (unsigned) (ceil_div(n_big, lpw) + ceil_div(total - n_big, lpw_small));
+        hipLaunchKernelGGL(k_t1_decode_lds, dim3(waves), dim3(64), (size_t) kDecStateRows * std::max(lpw, lpw_small) * 8, s, jb.stream,
+                           jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw, n_big, lpw_small);
     }
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);

@@ -1083,13 +1083,12 @@ void launch_synthesis_stats(const float *data, const float *decoded, const Resid
 
 // launch_reconstruct + launch_synthesis_stats for the probes of the truncation search, without the finest level's
 // detour through the grid: coarse quadrant reconstructed, coarser levels as usual, then k_cols_inv_stream and the
-// consuming row pass.  (EBCC_HIP_RESIDUAL_SPLIT=1: the separate kernels.)
+// consuming row pass.
 void launch_prefix_synthesis_stats(const float *data, const float *decoded, const ResidualBuffers &rb, int n_frames,
                                    const unsigned long long *d_trunc_bits, const int *d_active, hipStream_t s)
 {
-    const bool split = getenv("EBCC_HIP_RESIDUAL_SPLIT") != nullptr;
     const Grid &g = rb.g;
-    if (split || g.stages < 2 || g.ny < 32) {
+    if (g.stages < 2 || g.ny < 32) {
         launch_reconstruct(rb, n_frames, d_trunc_bits, d_active, s);
         launch_synthesis_stats(data, decoded, rb, n_frames, d_active, s);
         return;
@@ -1106,13 +1105,12 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     RowUse u{};
     u.data = data; u.decoded = decoded;
     int partials;
-    const bool unfused = getenv("EBCC_HIP_RESIDUAL_UNFUSED") != nullptr;  // (column stream + consuming row pass as two kernels)
     const int strips = ceil_div(g.nx >> 1, kFusePairs);
-    if (!unfused && strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
+    if (strips * pieces <= kPartials && (g.nx >> 1) >= 2) {
         u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = rb.fs; u.partial = rb.partial;
         // (one strip per workgroup: with several strips as the waves of one workgroup this kernel got slower - 564 us per
-        //  probe round with 1, 571 with 4, 788 with 6, 898 with all 12, tools/gpu/kstat.sh; EBCC_HIP_FUSE_WAVES_R overrides)
-        static const int wave_cap = getenv("EBCC_HIP_FUSE_WAVES_R") ? std::max(1, std::min(kFuseMaxWaves, atoi(getenv("EBCC_HIP_FUSE_WAVES_R")))) : 1;
+        //  probe round with 1, 571 with 4, 788 with 6, 898 with all 12, tools/gpu/kstat.sh)
+        const int wave_cap = 1;
         const int wg = std::min(strips, wave_cap);
         hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
                            d_trunc_bits, d_active, u, strips, n_frames, pieces);

@@ -1384,6 +1384,26 @@ T1_HD void mq_entry2(int st7, uint32_t &qe, uint32_t &next)
 struct ConstTable2 {
     T1_HD void operator()(uint32_t code, uint32_t &qe, uint32_t &next) const { mq_entry2((int) mq_code_state(code), qe, next); }
 };
+// The row coder keeps every context as ONE word, qe | code << 16 - Qe of its current state is in a register the moment the
+// slot is read - and a table entry holds what a transition needs: both successor codes and both successors' Qe:
+//     entry(code): n[0] = code(nmps) | code(nlps) << 16     n[1] = qe(nmps) | qe(nlps) << 16
+T1_HD uint32_t mq_slot_word(uint32_t code)
+{
+    uint32_t qe, nxt;
+    mq_entry2((int) mq_code_state(code), qe, nxt);
+    return qe | (code << 16);
+}
+T1_HD void mq_entry_next(uint32_t code, uint32_t &nxt, uint32_t &nqes)
+{
+    uint32_t qe, qm, ql, t;
+    mq_entry2((int) mq_code_state(code), qe, nxt);
+    mq_entry2((int) mq_code_state(nxt & 0xFFFFu), qm, t);
+    mq_entry2((int) mq_code_state(nxt >> 16), ql, t);
+    nqes = qm | (ql << 16);
+}
+struct ConstTableNext {
+    T1_HD void operator()(uint32_t code, uint32_t &nxt, uint32_t &nqes) const { mq_entry_next(code, nxt, nqes); }
+};
 
 // Row format of the decision streams: a code-block's decisions, segment after segment in coding order, in ROWS of
 // 16 bytes; every segment starts a new row (at least one, even when it has no decision), so a row never straddles
@@ -1402,25 +1422,34 @@ T1_HD uint32_t seg_rows(uint32_t decisions) { return decisions ? (decisions + 15
 // a 16-bit word per decision handed over through LDS (mq_rows_interval / MqCodeChain).  A lone wave issues one
 // instruction every ~4-6 cycles whatever it does; two waves halve what each has to issue per decision.
 //
-// Hand-over word: bits 0..6 state (6-bit index | mps << 6) before the decision, bit 7 = nothing is added to C,
-// bits 8..11 = k, bit 15 (first decision of a row only) = the row starts a segment.
-constexpr uint32_t kHandNoAdd = 0x80u, kHandStart = 0x8000u;
+// Hand-over word (32 bits): bits 0..15 Qe of the decision, bits 16..19 = k, bit 20 = nothing is added to C, bit 21 (first
+// decision of a row only) = the row starts a segment.  (Round 2 handed the state over in 16 bits and the code chain
+// looked Qe up again: a table read and its wait per decision on that wave too.)
+constexpr uint32_t kHandNoAdd = 1u << 20, kHandStart = 1u << 21;
 
 // RowSrc: uint32_t rows()                      rows of this lane's code-block
 //         uint32_t wave_rows()                 the most rows any lane of the wave has (uniform)
 //         void sync(uint32_t row)              called by every lane before row `row` is loaded (a uniform point)
 //         void load(uint32_t row, uint32_t w[4])
-// CtxMem: uint32_t handle(uint32_t ctx) (an address on the device), uint32_t ld(handle) / void st(handle, code): the state
-//         codes (contexts 0 .. 31; 19 is the null context), void words(uint32_t out[5]): the 19 context states as
-//         bytes (state | mps << 6), four per word - the checkpoint format
+// Slots:  uint32_t handle(uint32_t ctx) (an address on the device), uint32_t ld(handle) / void st(handle, word): the slot
+//         words (qe | code << 16) of contexts 0 .. 19 (19 is the null context), void words(uint32_t out[5]): the 19
+//         context states as bytes (state | mps << 6), four per word - the checkpoint format
+// Table:  void operator()(code, nxt, nqes): mq_entry_next
 // Hand:   void put(uint32_t row, int j, uint32_t word)
 // CkArray: store_interval(p, s, a, shifts, cx[5])
-template <class RowSrc, class CtxMem, class Hand, class CkArray, class Table = ConstTable2>
-T1_HD uint32_t mq_rows_interval(RowSrc src, CtxMem cx, int P, int nstr, Hand hand, CkArray &ck, Table tab = Table())
+//
+// The wave is an in-order machine: whatever a decision waits for, it waits for in full.  Round 2 read the context's state
+// and then its table entry, one after the other, at the head of every decision (~650 cycles per decision for a lone
+// wave).  Now nothing a decision needs at its head comes out of LDS at that moment: Qe and the code are one slot word
+// that was asked for a decision earlier (or is forwarded from the decision before when it used the same context), the
+// table entry - only needed at the END of the decision, for the transition - is asked for at the end of the decision
+// before, and the slot store that follows a transition depends on no read at all (the successor's Qe is in the entry).
+template <class RowSrc, class Slots, class Hand, class CkArray, class Table = ConstTableNext>
+T1_HD uint32_t mq_rows_interval(RowSrc src, Slots cx, int P, int nstr, Hand hand, CkArray &ck, Table tab = Table())
 {
     uint32_t a = 0x8000, shifts = 0;
-    for (uint32_t i = 0; i < 32; i++)
-        cx.st(cx.handle(i), i >= (uint32_t) NCTX ? kNullCode : mq_code(i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u))));
+    for (uint32_t i = 0; i <= kCtxNull; i++)
+        cx.st(cx.handle(i), mq_slot_word(i >= (uint32_t) NCTX ? kNullCode : mq_code(i == CTX_UNI ? 46u : (i == CTX_AGG ? 3u : (i == CTX_ZC0 ? 4u : 0u)))));
     const uint32_t nrows = P > 0 ? src.rows() : 0u, wrows = src.wave_rows();
     int pass = 0, stripe = 0;
     for (uint32_t row = 0; row < wrows; row++) {
@@ -1436,30 +1465,36 @@ T1_HD uint32_t mq_rows_interval(RowSrc src, CtxMem cx, int P, int nstr, Hand han
                 if (++stripe == nstr) { stripe = 0; pass++; }
             }
             uint32_t h = cx.handle(w[0] & 31u);
-            uint32_t code = cx.ld(h);
+            uint32_t s0 = cx.ld(h);                                       // qe | code << 16 of this decision's context
+            uint32_t nxt, nqes;
+            tab(s0 >> 16, nxt, nqes);                                     // its transition (needed at the end of the decision)
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const uint32_t wj = w[j >> 2] >> (8 * (j & 3));           // this decision's byte in bits 0..7
-                uint32_t qe, nxt;
-                tab(code, qe, nxt);
-                uint32_t hn = 0, coden = 0;
+                uint32_t hn = 0, sn = 0;
                 if (j < 15) {
                     hn = cx.handle((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31u);
-                    coden = cx.ld(hn);                                    // (issued before this decision's state store)
+                    sn = cx.ld(hn);                                       // (issued before this decision's slot store)
                 }
+                const uint32_t qe = s0 & 0xFFFFu, code = s0 >> 16;
                 const bool lps = (((wj << 4) ^ code) & 0x200u) != 0;      // decision bit (bit 5) against the mps (bit 9 of the code)
                 a -= qe;
                 const bool small = a < 0x8000u;
                 const bool lower = (a < qe) != lps;                       // which sub-interval the symbol is coded in
                 a = lower ? qe : a;
                 const uint32_t ncode = lps ? nxt >> 16 : (small ? nxt & 0xFFFFu : code);
-                cx.st(h, ncode);
-                if (j < 15 && hn == h) coden = ncode;                     // the next decision uses the same context
+                const uint32_t nqe = lps ? nqes >> 16 : (small ? nqes & 0xFFFFu : qe);
+                const uint32_t nword = nqe | (ncode << 16);
+                cx.st(h, nword);
+                if (j < 15) {
+                    if (hn == h) sn = nword;                              // the next decision uses the same context
+                    tab(sn >> 16, nxt, nqes);                             // the next decision's transition: a whole decision to arrive
+                }
                 const int k = renorm_shifts(a);                           // 0 when bit 15 is set
                 shifts += (uint32_t) k;
                 a <<= k;
-                hand.put(row, j, mq_code_state(code) | (lower ? kHandNoAdd : 0u) | ((uint32_t) k << 8) | ((j == 0 && start) ? kHandStart : 0u));
-                h = hn; code = coden;
+                hand.put(row, j, qe | ((uint32_t) k << 16) | (lower ? kHandNoAdd : 0u) | ((j == 0 && start) ? kHandStart : 0u));
+                h = hn; s0 = sn;
             }
         }
     }
@@ -1467,7 +1502,7 @@ T1_HD uint32_t mq_rows_interval(RowSrc src, CtxMem cx, int P, int nstr, Hand han
     return a;                                                             // (the code chain's FLUSH needs it)
 }
 
-// The code chain of one lane.  Table as above (Qe from the state code).
+// The code chain of one lane (Qe comes with the hand-over word).
 // Sink:   void put(int index, uint32_t byte) (index -1 ignored; an index may be written again until a higher one
 //         has been), void row_end(int n) (a uniform point: bytes below n are final and may leave), void finish(int n)
 // CkArray: store_code(p, s, c16)
@@ -1491,8 +1526,8 @@ struct MqCodeChain {
         ct = stuff ? 7 : 8;
     }
     // one row of hand-over words (hw[j], j = 0..15); any(b): true if b holds for any lane of the wave
-    template <class Sink, class CkArray, class Table, class Any>
-    T1_HD void row(const uint32_t hw[16], int nstr, int *rates, Sink &sink, CkArray &ck, const Table &tab, Any any)
+    template <class Sink, class CkArray, class Any>
+    T1_HD void row(const uint32_t hw[16], int nstr, int *rates, Sink &sink, CkArray &ck, Any any)
     {
         if (hw[0] & kHandStart) {
             if (stripe == 0 && pass > 0) rates[pass - 1] = (int) ((uint32_t) n + 3u);
@@ -1501,9 +1536,8 @@ struct MqCodeChain {
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            uint32_t qe, nxt;
-            tab(mq_code(hw[j] & 0x7Fu), qe, nxt);
-            const int k = (int) ((hw[j] >> 8) & 15u);
+            const uint32_t qe = hw[j] & 0xFFFFu;
+            const int k = (int) ((hw[j] >> 16) & 15u);
             c += (hw[j] & kHandNoAdd) ? 0u : qe;
             const bool need = k >= ct;                                    // a byte leaves when the down-counter runs out (selects, no branch)
             const int sh1 = need ? ct : k;

@@ -7,7 +7,6 @@
 #include <vector>
 
 #include "../ebcc_amd/csrc/t1_core.hpp"
-#include "../ebcc_amd/csrc/t1_decode.hpp"
 
 extern "C" {
 int orc_j2k_t1_encode(const int32_t *q, int w, int h, int orient, int level, float stepsize, uint8_t *out, int out_cap,
@@ -121,9 +120,9 @@ struct RowSrcHost {               // one code-block's row stream (t1_core.hpp: r
     void sync(uint32_t) const {}
     void finish() const {}
 };
-struct HostHand { std::vector<uint16_t> *v; void put(uint32_t row, int j, uint32_t word) { size_t i = (size_t) row * 16 + j; if (v->size() <= i) v->resize(i + 1); (*v)[i] = (uint16_t) word; } };
-struct CtxCodes { uint16_t *b; uint32_t handle(uint32_t c) const { return c; } uint32_t ld(uint32_t h) const { return b[h]; } void st(uint32_t h, uint32_t v) { b[h] = (uint16_t) v; }
-                  void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) x[j] = 0; for (int i = 0; i < NCTX; i++) x[i >> 2] |= mq_code_state(b[i]) << (8 * (i & 3)); } };
+struct HostHand { std::vector<uint32_t> *v; void put(uint32_t row, int j, uint32_t word) { size_t i = (size_t) row * 16 + j; if (v->size() <= i) v->resize(i + 1); (*v)[i] = word; } };
+struct CtxSlots { uint32_t *b; uint32_t handle(uint32_t c) const { return c; } uint32_t ld(uint32_t h) const { return b[h]; } void st(uint32_t h, uint32_t v) { b[h] = v; }
+    void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) { uint32_t v = 0; for (int k = 0; k < 4; k++) if (4 * j + k < NCTX) v |= mq_code_state(b[4 * j + k] >> 16) << (8 * k); x[j] = v; } } };
 struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end(int) {} void finish(int n) { v->resize((size_t) n); } };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
 struct HostEnv { BufSrc src; bool any(bool b) const { return b; } BufSrc &bytes() { return src; } bool starved(int) const { return false; } void refill_point(int) {} void pass_point(int) {} };
@@ -248,7 +247,7 @@ int main(int argc, char **argv)
                 memset(ck3, 0, sizeof ck3);
                 CkView ckv3{ck3, nstr};
                 int rates3[kMaxPasses];
-                uint16_t ctxb3[32] = {0};
+                uint32_t ctxb3[32] = {0};
                 std::vector<uint8_t> bytes3;
                 std::vector<uint32_t> rowsw;                                // the segments as rows, in coding order
                 for (int sg = 0; sg < kSegCount; sg++) {
@@ -267,15 +266,14 @@ int main(int argc, char **argv)
                             rowsw.push_back(word);
                         }
                 }
-                std::vector<uint16_t> handv;
-                const uint32_t a_end = mq_rows_interval(RowSrcHost{&rowsw}, CtxCodes{ctxb3}, numbps, nstr, HostHand{&handv}, ckv3);
+                std::vector<uint32_t> handv;
+                const uint32_t a_end = mq_rows_interval(RowSrcHost{&rowsw}, CtxSlots{ctxb3}, numbps, nstr, HostHand{&handv}, ckv3);
                 MqCodeChain chain;
                 VecSink3 sink3{&bytes3};
-                ConstTable2 tab3;
                 for (size_t rr = 0; rr * 16 < handv.size(); rr++) {
                     uint32_t hw[16];
                     for (int j = 0; j < 16; j++) hw[j] = handv[rr * 16 + j];
-                    chain.row(hw, nstr, rates3, sink3, ckv3, tab3, [](bool b_) { return b_; });
+                    chain.row(hw, nstr, rates3, sink3, ckv3, [](bool b_) { return b_; });
                 }
                 EncodeResult r3 = chain.finish(a_end, numbps > 0 ? 3 * numbps - 2 : 0, rates3, sink3, VecAt{&bytes3});
                 finalize_checkpoints(ckv3, r3.totalpasses, nstr, BufSrc{bytes3.data(), r3.length});
@@ -319,21 +317,6 @@ int main(int argc, char **argv)
             ds.out = d2.data(); ds.w = w;
             decode_block(ds, BufSrc{bytes.data(), len}, w, h, orient, numbps, np);
             if (d1 != d2) { printf("trial %d DECODE mismatch np %d/%d\n", t, np, opasses); bad++; break; }
-            {                                                             // the segment-locked decoder (t1_decode.hpp)
-                std::vector<int32_t> d4((size_t) w * h, 0);
-                HostStore ss;
-                ss.out = d4.data(); ss.w = w;
-                uint16_t codes[32];
-                CtxCodes cc{codes};
-                HostEnv env{BufSrc{bytes.data(), len}};
-                ConstTable2 tab2;
-                decode_block_segments(ss, cc, tab2, env, w, h, orient, numbps, np, numbps + (int) (rng() % 3));
-                if (d1 != d4) {
-                    size_t k2 = 0; while (k2 < d1.size() && d1[k2] == d4[k2]) k2++;
-                    printf("trial %d SEGMENT DECODER mismatch np %d/%d (w %d h %d orient %d P %d) first at (%zu,%zu): %d vs %d\n", t, np, opasses, w, h, orient, numbps, k2 % w, k2 / w, d1[k2], d4[k2]);
-                    bad++; break;
-                }
-            }
             // ---- resume at the last coded plane from a checkpoint of the FULL-segment decode
             static Obs obs;
             obs.nstr = nstr;

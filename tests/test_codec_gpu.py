@@ -237,10 +237,9 @@ def test_tuning_knobs_do_not_change_results(monkeypatch):
         assert any(int.from_bytes(s[16:24], "little") > 0 for s in base)      # some frames carry a residual layer
     L.oracle().orc_set_j2k_backend(0)
     assert base[0] == L.orc_encode(frames[0], cfg) and base[16] == L.orc_encode(frames[16], cfg)
-    for env in ({"EBCC_HOST_THREADS": "3"}, {"EBCC_T1_LPW": "8"}, {"EBCC_T1_LPW": "16,32,1,2"}, {"EBCC_HIP_SLICES": "3", "EBCC_HIP_DECODE_SLICES": "3"},
-                {"EBCC_HIP_T1_DECODE_SEG": "1"}, {"EBCC_HIP_T1_DECODE_GLOBAL": "1"}, {"EBCC_HIP_FIN_LDS": "1"}, {"EBCC_HIP_L5_SPLIT": "1"},
-                {"EBCC_HIP_LEVELS_SPLIT": "1"}, {"EBCC_HIP_FWD_SPLIT": "1"}, {"EBCC_T1_DEC_MIX": "1,2"}, {"EBCC_T1_DEC_MIX": "4,8"}, {"EBCC_HIP_RESIDUAL_SPLIT": "1"}, {"EBCC_HIP_RESIDUAL_UNFUSED": "1"}, {"EBCC_HIP_HOST_SEARCH": "1"},
-                {"EBCC_HIP_SLICES": "2", "EBCC_HIP_SPECULATION": "1"}, {"EBCC_HIP_SEARCH2_OVERLAP": "1"}):
+    for env in ({"EBCC_HOST_THREADS": "3"}, {"EBCC_T1_LPW": "8"}, {"EBCC_T1_LPW": "16,32,1,2"}, {"EBCC_HIP_SLICES": "2", "EBCC_HIP_DECODE_SLICES": "3"},
+                {"EBCC_HIP_SLICES": "4"}, {"EBCC_HIP_HOST_SEARCH": "1"}, {"EBCC_HIP_NO_SHORTCUTS": "1"}, {"EBCC_HIP_SLICES": "2", "EBCC_HIP_SPECULATION": "1"},
+                {"EBCC_HIP_SLICES": "1", "EBCC_HIP_SPECULATION": "0"}, {"EBCC_HOST_CPU_QUOTA": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with L.Context(len(frames), 96, 160) as ctx:
@@ -453,15 +452,14 @@ def test_host_and_device_search_loops_agree(monkeypatch):
         cfg = L.make_config((1, 96, 160), base_cr=40.0, error=err, residual_type=mode)
         got = {}
         for name, env in (("device", {}), ("host", {"EBCC_HIP_HOST_SEARCH": "1"}), ("short", {"EBCC_HIP_SEARCH_ROUNDS": "3"}),
-                          ("plain", {"EBCC_HIP_NO_SPECULATION": "1"}), ("serial2", {"EBCC_HIP_SEARCH2_SERIAL": "1"}),
-                          ("exact", {"EBCC_HIP_EXACT_PROBES": "1"}), ("zall", {"EBCC_HIP_ZSTD_ALL": "1"}), ("spin", {"EBCC_HIP_SPIN_SYNC": "1"})):
+                          ("plain", {"EBCC_HIP_SPECULATION": "0"}), ("spec", {"EBCC_HIP_SPECULATION": "1"}), ("exact", {"EBCC_HIP_NO_SHORTCUTS": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             with L.Context(len(frames), 96, 160) as ctx:
                 got[name] = ctx.encode_frames(frames, cfg)
             for k in env:
                 monkeypatch.delenv(k)
-        assert got["device"] == got["host"] == got["short"] == got["plain"] == got["serial2"] == got["exact"] == got["zall"] == got["spin"], mode
+        assert got["device"] == got["host"] == got["short"] == got["plain"] == got["spec"] == got["exact"], mode
         L.oracle().orc_set_j2k_backend(0)
         assert got["device"][3] == L.orc_encode(frames[3], cfg)
 

@@ -113,12 +113,13 @@ Zstd &zstd()
 //     they cost at least their empirical entropy m log2 m - sum_s c_s log2 c_s, and that function only grows when further
 //     literals join the multiset: the uncoverable positions alone bound it from below;
 //   * libzstd before 1.5 cuts the input into blocks of min(128 KB, window) bytes and nothing finer (no block splitter,
-//     no target block size unless asked for): inputs of at most 128 KB are ONE block, which is the case used here -
-//     zstd_floor_usable() checks the library's version, tests/test_zstd_floor.py checks the single block and the bound
-//     itself against the library on the fixtures and on random material.
+//     no target block size unless asked for): the bound is taken block by block at those boundaries (one block up to
+//     128 KB) - zstd_floor_usable() checks the library's version, tests/test_zstd_floor.py checks the block structure and
+//     the bound itself against the library on the fixtures and on random material.
 // Cost: one pass with a 2^24-bit table of the three-byte strings seen, a few microseconds per KB.
 // ------------------------------------------------------------------------------------------------
-constexpr size_t kZstdFloorMaxBytes = (size_t) 128 << 10;
+constexpr size_t kZstdBlockBytes = (size_t) 128 << 10;                  // ZSTD_BLOCKSIZE_MAX: libzstd < 1.5 cuts longer inputs into blocks of this size
+constexpr size_t kZstdFloorMaxBytes = (size_t) 4 << 20;
 bool zstd_floor_usable()
 {
     return zstd().ok && zstd().version && zstd().version() < 10500;
@@ -131,6 +132,8 @@ size_t zstd_size_lower_bound(const uint8_t *src, size_t n)
     if (seen.empty()) seen.assign((size_t) 1 << 18, 0);
     cov.assign(n, 0);
     auto tri = [&](size_t q) { return ((uint32_t) src[q] << 16) | ((uint32_t) src[q + 1] << 8) | (uint32_t) src[q + 2]; };
+    // (matches reach back across block boundaries - the window holds the whole input - so the strings seen are kept for
+    //  the whole input; a match itself lies inside one block, which only makes fewer positions coverable than counted here)
     for (size_t q = 0; q + 3 <= n; q++) {
         const uint32_t t = tri(q);
         uint64_t &w = seen[t >> 6];
@@ -138,15 +141,21 @@ size_t zstd_size_lower_bound(const uint8_t *src, size_t n)
         if (w & bit) { cov[q] = cov[q + 1] = cov[q + 2] = 1; } else w |= bit;
     }
     for (size_t q = 0; q + 3 <= n; q++) { const uint32_t t = tri(q); seen[t >> 6] = 0; }     // (leave the table clean for the next call)
-    size_t cnt[256] = {0}, m = 0;
-    for (size_t i = 0; i < n; i++) if (!cov[i]) { cnt[src[i]]++; m++; }
-    if (m == 0) return 9;
-    double bits = (double) m * std::log2((double) m);
-    for (size_t c : cnt) if (c) bits -= (double) c * std::log2((double) c);
-    if (!(bits > 0)) return 9;
-    // (a byte less than the arithmetic gives: the logarithms are rounded)
-    const double bytes = std::floor(bits / 8.0) - 1.0;
-    return 9 + (bytes > 0 ? (size_t) bytes : 0);
+    // the literals of every block under that block's own prefix code: the entropy of its uncoverable bytes
+    double bits_total = 0;
+    size_t blocks = 0;
+    for (size_t b0 = 0; b0 < n; b0 += kZstdBlockBytes, blocks++) {
+        const size_t b1 = std::min(n, b0 + kZstdBlockBytes);
+        size_t cnt[256] = {0}, m = 0;
+        for (size_t i = b0; i < b1; i++) if (!cov[i]) { cnt[src[i]]++; m++; }
+        if (m == 0) continue;
+        double bits = (double) m * std::log2((double) m);
+        for (size_t c : cnt) if (c) bits -= (double) c * std::log2((double) c);
+        if (bits > 0) bits_total += bits;
+    }
+    // magic, frame header, a 3-byte header per block; a byte less per block than the arithmetic gives (rounded logarithms)
+    const double bytes = std::floor(bits_total / 8.0) - (double) blocks;
+    return 6 + 3 * blocks + (bytes > 0 ? (size_t) bytes : 0);
 }
 
 // ================================================================================================
@@ -1342,6 +1351,12 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             if (pt.on) fprintf(stderr, "ebcc-mi355x zstd: %.1f ms of core time for %lld bytes, longest job %.1f ms; floors %.1f ms; %lld of %zu prefixes (%lld bytes) not compressed\n",
                                zstd_us.load() / 1e3, zstd_bytes.load(), zstd_max_us.load() / 1e3, bound_us.load() / 1e3, skipped, with_prefix.size(), skipped_bytes);
             host_stats().skipped_bytes += skipped_bytes;
+            if (pt.on && getenv("EBCC_HIP_ZSTD_TRACE"))
+                for (size_t f : with_prefix) {
+                    const Job &j = jobs[f];
+                    const long long x = (long long) j.last[1].stream_bytes - (long long) j.len1;
+                    fprintf(stderr, "zstd-trace c %zu floor %zu X %lld z %zu state %d need_pure %d\n", j.coeffs_size, zfloor[f], x, j.zbytes.size(), (int) zstate[f].load(), (int) j.need_pure);
+                }
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];

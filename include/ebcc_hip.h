@@ -115,7 +115,7 @@ int ebcc_hip_host_threads(int slices);
 void ebcc_hip_host_stats(double *out, int reset);
 /* Lower bound (bytes) of the zstd frame ZSTD_compress writes for [src, src + n) at any level, from the format alone (the
  * literals no match can cover cost at least their entropy; host_codec.hip: zstd_size_lower_bound); 0 = no bound (n above
- * 128 KB, or a libzstd that may split blocks).  The encoder uses it to decide the reference's "pure base layer beats base +
+ * 4 MB, or a libzstd that may split blocks).  The encoder uses it to decide the reference's "pure base layer beats base +
  * residual" comparison (src/ebcc_codec.c:838) without compressing prefixes that provably lose it. */
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n);
 /* Host-side check of the arithmetic identities the kernels rely on (the division-free s / 65535.0f of the fused inverse

@@ -114,7 +114,7 @@ def test_floor_never_exceeds_what_libzstd_writes_and_small_inputs_are_one_block(
             assert floor > 0.8 * len(data)                                          # incompressible input: the bound is close to the size
             tight += 1
         if kind in ("zeros", "period7"):
-            assert floor <= 16
+            assert floor <= 16 + 3 * (len(data) // 131072)
     assert tight >= 5
     assert lib.ebcc_hip_zstd_floor(bytes((4 << 20) + 1), (4 << 20) + 1) == 0          # above 4 MB: not applicable
 

@@ -1520,6 +1520,21 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
     // a wave per code-block ends soonest (one 721 x 1440 frame through ebcc_decode: 16.8 -> 8.6 ms)
     const bool few_blocks = !getenv("EBCC_T1_LPW") && total <= 4096;
     if (few_blocks) lpw = 1;
+    if (getenv("EBCC_HIP_T1_STATS")) {                                   // diagnostics: the code-blocks with the longest segments
+        std::vector<int> h((size_t) total * 4);
+        EBCC_HIP_CHECK(hipMemcpyAsync(h.data(), jb.dec_table, h.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<int> idx(total);
+        for (int i = 0; i < total; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return h[(size_t) a * 4 + 1] > h[(size_t) b * 4 + 1]; });
+        long long sum = 0;
+        for (int i = 0; i < total; i++) sum += h[(size_t) i * 4 + 1];
+        fprintf(stderr, "ebcc-mi355x t1 decode: %d code-blocks, %lld bytes; longest:", total, sum);
+        for (int i = 0; i < std::min(total, 12); i++) fprintf(stderr, " [blk %d len %d P %d np %d]", idx[i] % jb.geom.stride, h[(size_t) idx[i] * 4 + 1], h[(size_t) idx[i] * 4 + 2], h[(size_t) idx[i] * 4 + 3]);
+        fprintf(stderr, "; percentiles of len:");
+        for (int q : {50, 90, 99}) fprintf(stderr, " p%d %d", q, h[(size_t) idx[(size_t) total * (100 - q) / 100] * 4 + 1]);
+        fprintf(stderr, "\n");
+    }
     timing_begin("t1_decode", s);
     {
         int *counters = jb.dec_order + groups * 64;

@@ -232,6 +232,22 @@ struct MqEncoder {
 // ------------------------------------------------------------------------------------------------
 // MQ decoder (C.3).  Source: uint32_t get(int index) returning 0xFF past the end
 // ------------------------------------------------------------------------------------------------
+#ifdef T1_RUN_STATS
+static unsigned long t1_run_stats[64];
+#endif
+// x / q for x < 2^16, 0 < q < 2^16 (the GPU has no integer divider: a reciprocal, then the two possible corrections)
+T1_HD uint32_t div_u16(uint32_t x, uint32_t q)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t k = (uint32_t) ((float) x * __frcp_rn((float) q));
+    if (k * q > x) k--;
+    if ((k + 1) * q <= x) k++;
+    return k;
+#else
+    return x / q;
+#endif
+}
+
 template <class Source, class Table = ConstTable>
 struct MqDecoder {
     uint32_t a, c;
@@ -292,6 +308,27 @@ struct MqDecoder {
             }
         }
         return d;
+    }
+    // Up to n decisions in a row on the run-length context that all come out 0, in one step.  While the context's MPS is 0
+    // a decision that takes neither the exchange nor the renormalisation branch of decode_in() is `a -= qe, c -= qe << 16`
+    // and leaves the context alone, so the next k of them are one update of the two registers: decision j (from 0)
+    // stays on that branch while (c >> 16) - j * qe >= qe and a - (j + 1) * qe >= 0x8000.  Returns k (0: the next
+    // decision needs decode_agg()).  The cleanup pass of a sparse code-block is almost only such decisions - one per
+    // all-zero column of four - which made it the bulk of the decoder's instructions.
+    T1_HD int agg_zero_run(int n)
+    {
+        const uint32_t st = cx.template get_in<1>(CTX_AGG - 9);
+        if (st >> 6) return 0;
+        const uint32_t qe = tab((int) (st & 0x3F)) & 0xFFFF;
+        const uint32_t ka = div_u16(a - 0x8000u, qe), kc = div_u16(c >> 16, qe);
+        uint32_t k = ka < kc ? ka : kc;
+        if (k > (uint32_t) n) k = (uint32_t) n;
+#ifdef T1_RUN_STATS
+        t1_run_stats[k > 63 ? 63 : k]++;
+#endif
+        a -= k * qe;
+        c -= (k * qe) << 16;
+        return (int) k;
     }
     T1_HD int decode_zc(int ctx) { return decode_in<0>(ctx - CTX_ZC0); }
     T1_HD int decode_sc(int ctx) { return decode_in<1>(ctx - 9); }
@@ -486,6 +523,7 @@ struct Passes {
 #pragma unroll
             for (int r = 0; r < 6; r++) nb |= sp.s[r];
             u64 pending = (nb | (nb << 1) | (nb >> 1)) & sp.wmask;
+            if (!pending) continue;                                      // nothing significant in or around the stripe: no candidate, nothing to store
             while (pending) {
                 T1_STAT(0);
                 int x = ctz64(pending);
@@ -529,8 +567,9 @@ struct Passes {
             load(sp, y0);
             u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
             if constexpr (ENC) { b0 = st.BP(plane, y0); b1 = st.BP(plane, y0 + 1); b2 = st.BP(plane, y0 + 2); b3 = st.BP(plane, y0 + 3); }
-            u64 r0 = st.REF(y0), r1 = st.REF(y0 + 1), r2 = st.REF(y0 + 2), r3 = st.REF(y0 + 3);
             u64 pending = (sp.s[1] & ~sp.vis[0]) | (sp.s[2] & ~sp.vis[1]) | (sp.s[3] & ~sp.vis[2]) | (sp.s[4] & ~sp.vis[3]);
+            if (!pending) continue;
+            u64 r0 = st.REF(y0), r1 = st.REF(y0 + 1), r2 = st.REF(y0 + 2), r3 = st.REF(y0 + 3);
             const u64 n0 = neighbours(sp.s[0], sp.s[1], sp.s[2]), n1 = neighbours(sp.s[1], sp.s[2], sp.s[3]),
                       n2 = neighbours(sp.s[2], sp.s[3], sp.s[4]), n3 = neighbours(sp.s[3], sp.s[4], sp.s[5]);
             while (pending) {
@@ -577,6 +616,16 @@ struct Passes {
             if (sp.nrows > 2) pending |= ~(sp.s[3] | sp.vis[2]);
             if (sp.nrows > 3) pending |= ~(sp.s[4] | sp.vis[3]);
             pending &= sp.wmask;
+            // decoder: the run-length columns as of the start of the stripe.  What is coded in column x changes the
+            // neighbourhood of columns x and x + 1 only, so when the scan reaches column x the bits above x still hold.
+            u64 aggmask = 0;
+            if constexpr (!ENC) {
+                if (full) {
+                    u64 anys = sp.s[0] | sp.s[1] | sp.s[2] | sp.s[3] | sp.s[4] | sp.s[5];
+                    anys |= (anys << 1) | (anys >> 1);
+                    aggmask = ~(anys | sp.vis[0] | sp.vis[1] | sp.vis[2] | sp.vis[3]) & sp.wmask;
+                }
+            }
             while (pending) {
                 T1_STAT(2);
                 int x = ctz64(pending);
@@ -600,6 +649,13 @@ struct Passes {
                         mq.encode_uni(run & 1);
                         start = run;
                     } else {
+                        // this column and the run-length columns right after it, as many as come out 0 in one step
+                        const u64 after = x < 63 ? aggmask >> (x + 1) : 0ull;
+                        const int k = mq.agg_zero_run(1 + ctz64(~after));
+                        if (k) {
+                            if (k > 1) pending &= ~((k >= 64 ? ~0ull : (1ull << k) - 1) << x);
+                            continue;
+                        }
                         if (!mq.decode_agg()) continue;
                         start = mq.decode_uni();
                         start = (start << 1) | mq.decode_uni();

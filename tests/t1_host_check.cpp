@@ -136,13 +136,14 @@ int main(int argc, char **argv)
         int w = (t % 5 == 0) ? 64 : 1 + rng() % 64, h = (t % 7 == 0) ? 64 : 1 + rng() % 64;
         int orient = rng() % 4;
         int maxbits = 7 + rng() % 16;                  // q6 magnitude bits (6 fractional)
-        int style = rng() % 4;
+        int style = rng() % 5;                        // 4: a few coefficients in an empty code-block (long run-length runs)
         std::vector<int32_t> q((size_t) w * h);
         std::vector<int32_t> &qvals = q;
         for (int i = 0; i < w * h; i++) {
             int32_t m;
             if (style == 0) m = (int32_t) (rng() % (1u << maxbits));
             else if (style == 1) m = (rng() % 8 == 0) ? (int32_t) (rng() % (1u << maxbits)) : (int32_t) (rng() % 64);
+            else if (style == 4) m = (rng() % 300 == 0) ? (int32_t) (rng() % (1u << maxbits)) : 0;
             else if (style == 2) { int b = rng() % (maxbits + 1); m = (int32_t) (rng() % (1u << b)); }
             else { int x = i % w, y = i / w; m = (int32_t) ((((x * x + 3 * y * y) % 4099) * (1u << maxbits)) / 4099); }
             q[i] = (rng() & 1) ? -m : m;

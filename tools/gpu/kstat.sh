@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: average duration of selected kernels of the default bench (one slice) under environment variants.
-#   gpurun -- 'bash tools/gpu/kstat.sh "k_j2k_level5_fin|k_finest_inv_use" "A=1" "EBCC_HIP_FUSE_WAVES=6" ...'
+#   gpurun -- 'bash tools/gpu/kstat.sh "k_j2k_level5_fin|k_finest_inv_use" "A=1" "EBCC_T1_TWO_PHASE=0" ...'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 PAT=$1; shift
 for V in "$@"; do

@@ -1957,6 +1957,31 @@ void ebcc_hip_host_stats(double *out, int reset)
     if (reset) h.reset();
 }
 
+// A fresh allocation of hundreds of MB is unmapped pages: a download into it would fault them in one by one on the copying
+// threads.  A few host threads ask for huge pages and touch them meanwhile (while the GPU decodes).
+struct Prefault {
+    std::vector<std::thread> pool;
+    Prefault(void *p, size_t bytes)
+    {
+        const size_t nthreads = bytes >= ((size_t) 64 << 20) ? std::min<size_t>(16, std::max(1u, (unsigned) entropy_threads(1))) : 0;
+        if (nthreads) {                                             // huge pages where the system grants them: 512 x fewer faults
+            const uintptr_t a = ((uintptr_t) p + ((size_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), e = ((uintptr_t) p + bytes) & ~(((uintptr_t) 2 << 20) - 1);
+            if (e > a) madvise((void *) a, e - a, MADV_HUGEPAGE);
+        }
+        try {
+            for (size_t t = 0; t < nthreads; t++)
+                pool.emplace_back([=]() {
+                    volatile char *c = (volatile char *) p;
+                    const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
+                    for (size_t i = lo; i < hi; i += 4096) c[i] = 0;
+                });
+        } catch (const std::exception &) {}                         // (no thread to be had: the download faults the pages in itself)
+    }
+    std::mutex m;                                                   // (one device thread per device may come here)
+    void join() { std::lock_guard<std::mutex> g(m); for (auto &t : pool) if (t.joinable()) t.join(); }
+    ~Prefault() { join(); }
+};
+
 // A pageable host array <-> device memory at PCIe speed: through the engine's two pinned bounce buffers with several host
 // threads copying (copy_pageable) instead of hipMemcpy's single staging thread (~10 GB/s, and a fresh destination's page
 // faults on top) - what ebcc_decode_chunking does for its own output, for callers of the frames API that keep their
@@ -1982,6 +2007,18 @@ int ebcc_hip_download(ebcc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t 
         if (e > a) madvise((void *) a, e - a, MADV_HUGEPAGE);
     }
     copy_pageable(ctx, h_dst, const_cast<void *>(d_src), bytes, true);
+    return 0;
+    EBCC_API_CATCH(1)
+}
+
+// The pages of a host array that is about to receive a download, mapped by several threads (huge pages where granted);
+// returns when they are.  Meant to run on a caller's thread beside ebcc_hip_decode_frames.  Return 0 = ok.
+int ebcc_hip_prefault(void *h_dst, size_t bytes)
+{
+    EBCC_API_TRY
+    if (!h_dst) { set_error("ebcc_hip_prefault: null argument"); return 1; }
+    Prefault pf(h_dst, bytes);
+    pf.join();
     return 0;
     EBCC_API_CATCH(1)
 }
@@ -2250,28 +2287,7 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
     float *h_chunks = in_place ? o : chunks.data();
     // a fresh allocation of this size is unmapped pages: the download would fault them in one by one on the copying thread.
     // A few host threads touch them while the GPU decodes (the reference-compatible output must be a malloc'd buffer).
-    struct Prefault {
-        std::vector<std::thread> pool;
-        Prefault(void *p, size_t bytes)
-        {
-            const size_t nthreads = bytes >= ((size_t) 64 << 20) ? std::min<size_t>(16, std::max(1u, (unsigned) entropy_threads(1))) : 0;
-            if (nthreads) {                                             // huge pages where the system grants them: 512 x fewer faults
-                const uintptr_t a = ((uintptr_t) p + ((size_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), e = ((uintptr_t) p + bytes) & ~(((uintptr_t) 2 << 20) - 1);
-                if (e > a) madvise((void *) a, e - a, MADV_HUGEPAGE);
-            }
-            try {
-                for (size_t t = 0; t < nthreads; t++)
-                    pool.emplace_back([=]() {
-                        volatile char *c = (volatile char *) p;
-                        const size_t lo = bytes / nthreads * t, hi = t + 1 == nthreads ? bytes : bytes / nthreads * (t + 1);
-                        for (size_t i = lo; i < hi; i += 4096) c[i] = 0;
-                    });
-            } catch (const std::exception &) {}                         // (no thread to be had: the download faults the pages in itself)
-        }
-        std::mutex m;                                                   // (one device thread per device may come here)
-        void join() { std::lock_guard<std::mutex> g(m); for (auto &t : pool) if (t.joinable()) t.join(); }
-        ~Prefault() { join(); }
-    } prefault(in_place ? (void *) o : nullptr, in_place ? total * sizeof(float) : 0);
+    Prefault prefault(in_place ? (void *) o : nullptr, in_place ? total * sizeof(float) : 0);
     const size_t tiles = cd[0];
     const int rcode = run_on_devices(nchunks, [&](int device, size_t first, size_t count) {
         try {

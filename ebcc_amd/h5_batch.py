@@ -11,6 +11,10 @@ written through the callback are read here.
 Only numpy and ctypes are needed (h5py objects are passed in by the caller).
 """
 import ctypes
+import os
+import sys
+import threading
+import time
 
 import numpy as np
 
@@ -55,6 +59,8 @@ class BatchCodec:
                                                ctypes.c_size_t, ctypes.c_void_p]
         lib.ebcc_hip_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         lib.ebcc_hip_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ebcc_hip_prefault.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        lib.ebcc_hip_prefault.restype = ctypes.c_int
         lib.ebcc_hip_last_error.restype = ctypes.c_char_p
         lib.free_buffer.argtypes = [ctypes.c_void_p]
         self.h, self.w, self.max_frames = int(height), int(width), int(max_frames)
@@ -106,13 +112,32 @@ class BatchCodec:
         # (pointers into the bytes objects themselves: they stay alive in `streams` for the duration of the call)
         ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(s), ctypes.c_void_p).value for s in streams])
         sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
-        if self.lib.ebcc_hip_decode_frames(self.ctx, ptrs, sizes, n, self.d_buf):
-            raise RuntimeError("ebcc_hip_decode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
         if out is None:
             out = np.empty((n, self.h, self.w), np.float32)
         assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == n * self.h * self.w
+        # the destination's pages are mapped on a second thread while the GPU decodes (ctypes releases the GIL)
+        timing = os.environ.get("EBCC_H5_TIMING")
+        t0 = time.perf_counter()
+        tp = [t0]
+
+        def prefault():
+            self.lib.ebcc_hip_prefault(ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.nbytes))
+            tp[0] = time.perf_counter()
+
+        pre = threading.Thread(target=prefault)
+        pre.start()
+        try:
+            if self.lib.ebcc_hip_decode_frames(self.ctx, ptrs, sizes, n, self.d_buf):
+                raise RuntimeError("ebcc_hip_decode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+            t1 = time.perf_counter()
+        finally:
+            pre.join()
+        t2 = time.perf_counter()
         if self.lib.ebcc_hip_download(self.ctx, out.ctypes.data, self.d_buf, out.nbytes):
             raise RuntimeError("ebcc_hip_download: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+        if timing:
+            print(f"h5_batch.decode: {n} frames, decode {1e3 * (t1 - t0):.1f} ms, pages mapped after {1e3 * (tp[0] - t0):.1f} ms, "
+                  f"download {1e3 * (time.perf_counter() - t2):.1f} ms", file=sys.stderr, flush=True)
         return out
 
 
@@ -189,7 +214,10 @@ def read_frames(dset, batch=256, codec=None):
             box.append(e)
 
     box = []
+    t0 = time.perf_counter()
     fetch(0, box)
+    if os.environ.get("EBCC_H5_TIMING"):
+        print(f"h5_batch.read_frames: first batch of chunks fetched in {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr, flush=True)
     for lo in range(0, n, codec.max_frames):
         raw = box[0]
         if isinstance(raw, BaseException):

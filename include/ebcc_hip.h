@@ -99,6 +99,12 @@ int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
  * (what the chunking entry points use for their own arrays): ~3x hipMemcpy on a fresh pageable array.  0 = ok. */
 int ebcc_hip_upload(ebcc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ebcc_hip_download(ebcc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* Maps the pages of a host array that is about to receive a download (a fresh allocation of hundreds of MB is unmapped:
+ * the download would fault it in page by page): asks for huge pages and touches every page from several threads, returns
+ * when done.  DESTINATION arrays only - a zero is written to every page.  Meant to run on a second thread of the caller
+ * beside ebcc_hip_decode_frames, as ebcc_decode_chunking (/root/reference/src/ebcc_codec.c:1322-1449) does for the
+ * array it returns.  0 = ok. */
+int ebcc_hip_prefault(void *h_dst, size_t bytes);
 int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
                            uint8_t **out_streams, size_t *out_sizes);
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,

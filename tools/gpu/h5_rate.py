@@ -41,6 +41,7 @@ for rep in range(2):
     with h5py.File(os.path.join(out, "dc.h5"), "w") as f:
         d = h5_batch.create_dataset(f, "t", data.shape, base_cr=30, residual_opt=opt)
         h5_batch.write_frames(d, data, 30, opt)
+    back = None                                  # (the previous result - 1 GB to unmap - is not part of the read being timed)
     t1 = time.perf_counter()
     with h5py.File(os.path.join(out, "dc.h5"), "r") as f:
         back = h5_batch.read_frames(f["t"])

@@ -37,11 +37,11 @@ print(f"filter callback ({ncb} frames): write {data[:ncb].nbytes / 1e9 / (t1 - t
       f"max error {float(np.abs(back - data[:ncb]).max()):.4f}", flush=True, file=sys.stderr if as_json else sys.stdout)
 
 for rep in range(2):
+    back = None                                  # (the previous repetition's result - 1 GB to unmap - is not part of what is timed)
     t0 = time.perf_counter()
     with h5py.File(os.path.join(out, "dc.h5"), "w") as f:
         d = h5_batch.create_dataset(f, "t", data.shape, base_cr=30, residual_opt=opt)
         h5_batch.write_frames(d, data, 30, opt)
-    back = None                                  # (the previous result - 1 GB to unmap - is not part of the read being timed)
     t1 = time.perf_counter()
     with h5py.File(os.path.join(out, "dc.h5"), "r") as f:
         back = h5_batch.read_frames(f["t"])

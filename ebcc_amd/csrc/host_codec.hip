@@ -927,6 +927,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
         enqueue_rounds(6);
     }
     log_trace("rate search %d: %d probes of chunks over the rounds", k, h_counter[0]);
+    if (getenv("EBCC_HIP_T1_STATS") && slices <= 1) j2k_probe_hist_dump(k == 0 ? "search #1" : "search #2");
     for (size_t f = 0; f < n; f++) {
         Job &j = jobs[f];
         if (j.const_field) continue;

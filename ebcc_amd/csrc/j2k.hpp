@@ -195,6 +195,7 @@ void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool si
 bool j2k_tier1_retry(const J2kBuffers &jb, int n_frames, const J2kFrame *host_jf, hipStream_t s);
 // rate allocation for jf[f].cr (opj_tcd_rateallocate) -> npass, jf.body_bytes/stream_bytes
 void launch_j2k_rate(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s, const int *have_rate = nullptr);
+void j2k_probe_hist_dump(const char *what);                          // EBCC_HIP_T1_STATS=1 diagnostics (j2k_rate.hip)
 // the same for the candidate rates jb.cand_cr (two per frame) into the candidate slots; launch_j2k_rate_publish makes
 // candidate jb.cand_sel[f] the frame's current layer and sets jb.have_rate
 void launch_j2k_rate_candidates(const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s);

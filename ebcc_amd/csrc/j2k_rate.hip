@@ -1271,9 +1271,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 //   k_t1_resume  : one code-block per lane: state masks from the bit-plane / suffix-OR / visited masks, MQ
 //                  registers from the checkpoint, then only passes r .. n-1 on the truncated bytes
 // ================================================================================================
+// EBCC_HIP_T1_STATS=1: which code-blocks a probe changes.  Per round of a search: the frames probed, by the coarsest
+// resolution in which one of their code-blocks has other passes than in the frame's previous probe (0 = LL .. 5 = the finest
+// detail bands; 6 = nothing changed), and the number of changed finest-level code-blocks of the frames in class 5.
+constexpr int kProbeHistRounds = 96, kProbeHistFrames = 4096;
+__device__ unsigned int g_probe_hist[kProbeHistRounds][8];
+__device__ unsigned int g_probe_round;
+__device__ int g_probe_minres[kProbeHistFrames];
+__device__ unsigned int g_probe_fine_changed[kProbeHistFrames];
+__global__ void k_probe_hist_round(int n_frames, const FrameState *fs, const int *active)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int round = min(g_probe_round, (unsigned int) kProbeHistRounds - 1);
+    if (f < n_frames && f < kProbeHistFrames && !((active && !active[f]) || fs[f].const_field)) {
+        const int m = g_probe_minres[f];
+        atomicAdd(&g_probe_hist[round][m > 5 ? 6 : m], 1u);
+        if (m == 5) atomicAdd(&g_probe_hist[round][7], g_probe_fine_changed[f]);
+    }
+    if (f < kProbeHistFrames) { g_probe_minres[f] = 99; g_probe_fine_changed[f] = 0; }
+}
+__global__ void k_probe_hist_next() { g_probe_round++; }
+
 __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restrict__ npass, const int *__restrict__ rates,
                              void *ckpt, int *__restrict__ rpass, int *__restrict__ lastnp, const J2kGeom *geom,
-                             const J2kBlock *blocks, const FrameState *fs, const int *active, int total)
+                             const J2kBlock *blocks, const FrameState *fs, const int *active, int total, int stats)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -1283,6 +1304,11 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
     // a code-block that keeps the passes it had in the frame's previous probe keeps its decoded values: V still
     // holds them (later bisection steps move few code-blocks)
     if (lastnp[gid] == n) { rpass[gid] = -2; return; }
+    if (stats && frame < kProbeHistFrames && lastnp[gid] != -1) {       // (the first probe of a frame changes everything: not counted)
+        const int res = j2k_frame_geom(geom, frame).bands[j2k_frame_blocks(geom, blocks, frame)[gid - frame * geom->stride].band].res;
+        atomicMin(&g_probe_minres[frame], res);
+        if (res == 5) atomicAdd(&g_probe_fine_changed[frame], 1u);
+    }
     lastnp[gid] = n;
     int plan = -1;
     if (n > 0 && P > 0) {
@@ -1494,8 +1520,13 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
 {
     const int total = n_frames * jb.geom.stride;
     void *ck = jb.ckpt;
+    static const bool stats = getenv("EBCC_HIP_T1_STATS") != nullptr;
     hipLaunchKernelGGL(k_probe_plan, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.numbps, jb.npass, jb.rates, ck, jb.qplane,
-                       jb.lastnp, jb.d_geom, jb.d_blocks, jb.fs, d_active, total);
+                       jb.lastnp, jb.d_geom, jb.d_blocks, jb.fs, d_active, total, stats ? 1 : 0);
+    if (stats) {
+        hipLaunchKernelGGL(k_probe_hist_round, dim3(ceil_div(std::max(n_frames, kProbeHistFrames), 256)), dim3(256), 0, s, n_frames, jb.fs, d_active);
+        hipLaunchKernelGGL(k_probe_hist_next, dim3(1), dim3(1), 0, s);
+    }
     hipLaunchKernelGGL(k_probe_init, dim3(jb.geom.stride, n_frames), dim3(256), 0, s, jb.Q6, jb.qplane, jb.numbps, jb.SPS, jb.V,
                        jb.d_geom, jb.d_blocks, jb.fs, d_active);
     timing_begin("t1_probe_decode", s);
@@ -1507,6 +1538,25 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
     decode_tail(data, jb, n_frames, d_active, true, s, keep_field);
     EBCC_HIP_LAUNCH_CHECK();
     EBCC_HIP_LAUNCH_CHECK();
+}
+
+// EBCC_HIP_T1_STATS=1: prints and resets the histogram above (the stream must be idle)
+void j2k_probe_hist_dump(const char *what)
+{
+    unsigned int h[kProbeHistRounds][8], rounds = 0, zero = 0;
+    EBCC_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_hist), sizeof h));
+    EBCC_HIP_CHECK(hipMemcpyFromSymbol(&rounds, HIP_SYMBOL(g_probe_round), sizeof rounds));
+    fprintf(stderr, "ebcc-mi355x probes of %s, per round: frames by the coarsest resolution with a changed code-block [0 1 2 3 4 5 none] (changed finest code-blocks per frame of class 5)\n", what);
+    for (unsigned int r = 0; r < std::min(rounds, (unsigned int) kProbeHistRounds); r++) {
+        unsigned int n = 0;
+        for (int k = 0; k < 7; k++) n += h[r][k];
+        if (!n) continue;
+        fprintf(stderr, "ebcc-mi355x   round %2u: %4u %4u %4u %4u %4u %4u %4u  (%.1f)\n", r, h[r][0], h[r][1], h[r][2], h[r][3], h[r][4], h[r][5], h[r][6],
+                h[r][5] ? (double) h[r][7] / h[r][5] : 0.0);
+    }
+    static unsigned int zeros[kProbeHistRounds][8];
+    EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_hist), zeros, sizeof zeros));
+    EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_round), &zero, sizeof zero));
 }
 
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)

@@ -1279,6 +1279,8 @@ __device__ unsigned int g_probe_hist[kProbeHistRounds][8];
 __device__ unsigned int g_probe_round;
 __device__ int g_probe_minres[kProbeHistFrames];
 __device__ unsigned int g_probe_fine_changed[kProbeHistFrames];
+__device__ unsigned int g_probe_tiles[kProbeHistFrames][4];             // 12 x 8 tiles of 120 columns x H/8 rows a changed code-block reaches
+__device__ unsigned long long g_probe_dirty[kProbeHistRounds];          // their number, summed over the round's frames
 __global__ void k_probe_hist_round(int n_frames, const FrameState *fs, const int *active)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1287,8 +1289,9 @@ __global__ void k_probe_hist_round(int n_frames, const FrameState *fs, const int
         const int m = g_probe_minres[f];
         atomicAdd(&g_probe_hist[round][m > 5 ? 6 : m], 1u);
         if (m == 5) atomicAdd(&g_probe_hist[round][7], g_probe_fine_changed[f]);
+        atomicAdd(&g_probe_dirty[round], (unsigned long long) (__popc(g_probe_tiles[f][0]) + __popc(g_probe_tiles[f][1]) + __popc(g_probe_tiles[f][2])));
     }
-    if (f < kProbeHistFrames) { g_probe_minres[f] = 99; g_probe_fine_changed[f] = 0; }
+    if (f < kProbeHistFrames) { g_probe_minres[f] = 99; g_probe_fine_changed[f] = 0; g_probe_tiles[f][0] = g_probe_tiles[f][1] = g_probe_tiles[f][2] = 0; }
 }
 __global__ void k_probe_hist_next() { g_probe_round++; }
 
@@ -1308,6 +1311,16 @@ __global__ void k_probe_plan(const int *__restrict__ numbps, const int *__restri
         const int res = j2k_frame_geom(geom, frame).bands[j2k_frame_blocks(geom, blocks, frame)[gid - frame * geom->stride].band].res;
         atomicMin(&g_probe_minres[frame], res);
         if (res == 5) atomicAdd(&g_probe_fine_changed[frame], 1u);
+        // the samples the code-block reaches: its rectangle in the band, scaled to the frame, plus the synthesis filters'
+        // reach (4 samples per level, i.e. < 5 x the scale in all)
+        const J2kGeom &g = j2k_frame_geom(geom, frame);
+        const J2kBlock &b = j2k_frame_blocks(geom, blocks, frame)[gid - frame * geom->stride];
+        const J2kBand &bd = g.bands[b.band];
+        const int sc = 1 << (res == 0 ? 5 : 6 - res), bx = b.x - bd.offx, by = b.y - bd.offy;
+        const int x0 = max(0, (bx - 5) * sc), x1 = min(g.W - 1, (bx + b.w + 5) * sc), y0 = max(0, (by - 5) * sc), y1 = min(g.H - 1, (by + b.h + 5) * sc);
+        const int th = (g.H + 7) / 8;
+        for (int ty = y0 / th; ty <= y1 / th; ty++)
+            for (int tx = x0 / 120; tx <= x1 / 120; tx++) { const int t = ty * 12 + tx; if (t < 96) atomicOr(&g_probe_tiles[frame][t >> 5], 1u << (t & 31)); }
     }
     lastnp[gid] = n;
     int plan = -1;
@@ -1544,16 +1557,20 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
 void j2k_probe_hist_dump(const char *what)
 {
     unsigned int h[kProbeHistRounds][8], rounds = 0, zero = 0;
+    unsigned long long dirty[kProbeHistRounds];
     EBCC_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_hist), sizeof h));
+    EBCC_HIP_CHECK(hipMemcpyFromSymbol(dirty, HIP_SYMBOL(g_probe_dirty), sizeof dirty));
     EBCC_HIP_CHECK(hipMemcpyFromSymbol(&rounds, HIP_SYMBOL(g_probe_round), sizeof rounds));
     fprintf(stderr, "ebcc-mi355x probes of %s, per round: frames by the coarsest resolution with a changed code-block [0 1 2 3 4 5 none] (changed finest code-blocks per frame of class 5)\n", what);
     for (unsigned int r = 0; r < std::min(rounds, (unsigned int) kProbeHistRounds); r++) {
         unsigned int n = 0;
         for (int k = 0; k < 7; k++) n += h[r][k];
         if (!n) continue;
-        fprintf(stderr, "ebcc-mi355x   round %2u: %4u %4u %4u %4u %4u %4u %4u  (%.1f)\n", r, h[r][0], h[r][1], h[r][2], h[r][3], h[r][4], h[r][5], h[r][6],
-                h[r][5] ? (double) h[r][7] / h[r][5] : 0.0);
+        fprintf(stderr, "ebcc-mi355x   round %2u: %4u %4u %4u %4u %4u %4u %4u  (%.1f)  tiles reached %.1f %%\n", r, h[r][0], h[r][1], h[r][2], h[r][3], h[r][4], h[r][5], h[r][6],
+                h[r][5] ? (double) h[r][7] / h[r][5] : 0.0, 100.0 * (double) dirty[r] / (96.0 * n));
     }
+    static unsigned long long zd[kProbeHistRounds];
+    EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_dirty), zd, sizeof zd));
     static unsigned int zeros[kProbeHistRounds][8];
     EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_hist), zeros, sizeof zeros));
     EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_round), &zero, sizeof zero));

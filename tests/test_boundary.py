@@ -213,3 +213,20 @@ def test_kernel_arithmetic_identities_hold():
     lib = ctypes.CDLL(L.PRODUCT_SO)
     lib.ebcc_hip_selfcheck.restype = ctypes.c_int
     assert lib.ebcc_hip_selfcheck() == 0
+
+
+def test_prefault_maps_a_destination_array():
+    """ebcc_hip_prefault (host only: no device call): a fresh array's pages are touched by several threads, a small or
+    null one is left alone."""
+    import numpy as np
+    if not os.path.exists(L.PRODUCT_SO):
+        pytest.skip("library not built")
+    lib = ctypes.CDLL(L.PRODUCT_SO)
+    lib.ebcc_hip_prefault.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.ebcc_hip_prefault.restype = ctypes.c_int
+    a = np.empty(96 << 20, np.uint8)                                 # above the 64 MB threshold
+    assert lib.ebcc_hip_prefault(a.ctypes.data, a.nbytes) == 0
+    assert int(a[::4096].max()) == 0                                 # (a zero was written to every page)
+    b = np.full(1 << 20, 7, np.uint8)                                # small: nothing is touched
+    assert lib.ebcc_hip_prefault(b.ctypes.data, b.nbytes) == 0 and int(b.min()) == 7
+    assert lib.ebcc_hip_prefault(None, 0) != 0

@@ -332,6 +332,7 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (ebcc_hip_ctx *c : ctx->lanes) ebcc_hip_destroy(c);
     ctx->lanes.clear();
+    if (ctx->twin) { ebcc_hip_destroy(ctx->twin); ctx->twin = nullptr; }
     j2k_destroy(ctx);
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->h_u64a) hipHostFree(ctx->h_u64a);

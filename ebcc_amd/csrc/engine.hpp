@@ -36,6 +36,7 @@ struct ebcc_hip_ctx {
     // Sub-batch engines of the frames API: a batch is cut into a few slices that run concurrently, each on its
     // own stream and host thread (the kernels of one slice are latency-bound and leave most of the chip idle).
     std::vector<ebcc_hip_ctx *> lanes;
+    ebcc_hip_ctx *twin = nullptr;           // second engine set of ebcc_hip_encode_shard (batch k + 1 computes while batch k is in its entropy stage)
     // Staging for the many small per-frame transfers (codestreams, SPIHT bytes): the pieces are packed by a kernel
     // into one device buffer and cross PCIe as one copy into / out of one pinned buffer (engine.hip: stage_*).
     uint8_t *h_stage = nullptr, *d_stage = nullptr;

@@ -955,10 +955,31 @@ void rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices)
 // ------------------------------------------------------------------------------------------------
 // `n` chunks of `tiles` frames each (tiles == 1: the frame-per-chunk case); `rctx`: residual engine for the stacked
 // chunk image when tiles > 1.
+// A shard is coded batch after batch (ebcc_hip_encode_shard).  A batch ends with host work - the level-22 zstd of the kept
+// prefixes, ~a quarter of its time - during which its engines have nothing to do, so two engine sets alternate: one batch at
+// a time is in its GPU phase (GpuPhase), and the next one enters it the moment every slice of the current one has reached
+// its entropy stage (PhaseNote).
+struct GpuPhase {
+    std::mutex m;
+    std::condition_variable cv;
+    bool busy = false;
+    void acquire() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !busy; }); busy = true; }
+    void release() { { std::lock_guard<std::mutex> l(m); busy = false; } cv.notify_one(); }
+};
+struct PhaseNote {
+    GpuPhase *phase = nullptr;
+    std::atomic<int> total{0}, done{0};
+    std::atomic<bool> released{false};
+    void expect(int slices) { int e = 0; total.compare_exchange_strong(e, slices); }
+    void slice_done() { if (++done == total.load()) release_once(); }
+    void release_once() { bool e = false; if (phase && released.compare_exchange_strong(e, true)) phase->release(); }
+};
+
 int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
-                 SliceGate *next = nullptr, size_t tiles = 1, ebcc_hip_ctx *rctx = nullptr, unsigned slices = 1)
+                 SliceGate *next = nullptr, size_t tiles = 1, ebcc_hip_ctx *rctx = nullptr, unsigned slices = 1, PhaseNote *note = nullptr)
 {
     struct Release { SliceGate *g; ~Release() { if (g) g->release(); } } release_on_exit{next};   // (error paths too)
+    struct NoteOnce { PhaseNote *n; void tell() { if (n) { n->slice_done(); n = nullptr; } } ~NoteOnce() { tell(); } } gpu_phase_over{note};   // (every path reports once)
     const EncodeEnv env;
     const double q_target = 1 - env.base_error_quantile;
     const int mode = (int) cfg->residual_compression_type;
@@ -1317,6 +1338,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchFinish);              // :836
                 drain2.armed = false;
                 pt.mark("rate search 2");
+                gpu_phase_over.tell();                                                        // (what follows is host work and one small launch)
                 if (!zjoin()) return 1;                                                       // (the floors)
             } else {
                 start_search2();
@@ -1330,6 +1352,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 }
                 if (host_loop) run_search(b, 1, jobs, n_pix); else device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchFinish);   // :836
                 pt.mark("rate search 2");
+                gpu_phase_over.tell();
             }
             long long skipped_bytes = 0, skipped = 0;
             for (size_t f : cand) {
@@ -1749,8 +1772,45 @@ struct ChunkBox {
     }
 };
 
-int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes);
+int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
+                      GpuPhase *phase = nullptr);
 int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *d_out);
+
+// n_frames one-frame chunks in batches of the context's capacity, alternately on the context's engines and on a second set
+// (ebcc_hip_ctx::twin, made on first use; without memory for it the batches run one after the other on the first):
+// one batch at a time is in its GPU phase, the next enters it when every slice of the current one has reached its
+// entropy stage (GpuPhase / PhaseNote).  stage(set, first frame, count) -> where the batch's frames are on the device
+// (a host array is uploaded there: that copy runs beside the other batch's kernels too).
+template <class Stage>
+int encode_batches_alternating(ebcc_hip_ctx *ctx, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes, Stage stage)
+{
+    const size_t cap = ctx->max_frames, batches = (n_frames + cap - 1) / cap;
+    if (batches == 1) return run_encode_slices(ctx, stage(ctx, (size_t) 0, n_frames), n_frames, cfg, outs, sizes);
+    if (!ctx->twin) ctx->twin = ebcc_hip_create(ctx->device, cap, (size_t) ctx->height, (size_t) ctx->width);
+    ebcc_hip_ctx *const set[2] = {ctx, ctx->twin};
+    GpuPhase phase;
+    std::atomic<int> worst{0};
+    std::string err[2];
+    auto work = [&](int t) {
+        try {
+            EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+            for (size_t b = (size_t) t; b < batches && !worst.load(); b += set[1] ? 2 : 1) {
+                const size_t lo = b * cap, cnt = std::min(cap, n_frames - lo);
+                const int r = run_encode_slices(set[t], stage(set[t], lo, cnt), cnt, cfg, outs + lo, sizes + lo, &phase);
+                if (r) { err[t] = ebcc_hip_last_error(); int e = 0; worst.compare_exchange_strong(e, r); }
+            }
+        } catch (const std::exception &e) { err[t] = e.what(); int z = 0; worst.compare_exchange_strong(z, 1); }
+    };
+    if (set[1]) {
+        std::thread second(work, 1);
+        work(0);
+        second.join();
+    } else {
+        work(0);
+    }
+    if (worst.load()) set_error("%s", (err[0].empty() ? err[1] : err[0]).c_str());
+    return worst.load();
+}
 
 // host-pointer convenience used by the reference-compatible entry points
 // n chunks of `tiles` frames of H x W each, contiguous in host memory, on device `device`.  Returns 0 ok, 1 error (logged),
@@ -1765,16 +1825,21 @@ int encode_host_frames(int device, const float *data, size_t n, int H, int W, co
         const size_t cap = std::min(n, batch_capacity(n_pix));
         ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
         if (!chunk_engines(device, H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
+        // (a batch is uploaded in one go: uploads issued from inside the slices slow every slice down - measured in round 1 with
+        //  pageable copies, 5.6 against 3.7 GB/s, and again in round 2 through the bounce buffers, 7.1 against 6.5)
+        if (tiles == 1 && ctx->max_frames == cap)                   // one-frame chunks: concurrent slices, batches on alternating engine sets
+            return encode_batches_alternating(ctx, n, cfg, outs, sizes, [&](ebcc_hip_ctx *set, size_t lo, size_t cnt) {
+                float *d = io_buffer(set, cap * n_pix * sizeof(float));
+                copy_pageable(set, const_cast<float *>(data + lo * n_pix), d, cnt * n_pix * sizeof(float), false);
+                return (const float *) d;
+            });
         float *d = io_buffer(ctx, cap * n_pix * sizeof(float));
         size_t done = 0;
         while (done < n) {
             size_t k = std::min(cap, n - done);
-            int rcode;
-            // (the whole batch in one go: uploads issued from inside the slices slow every slice down - measured in round 1 with
-            //  pageable copies, 5.6 against 3.7 GB/s, and again in round 2 through the bounce buffers, 7.1 against 6.5)
             copy_pageable(ctx, const_cast<float *>(data + done * n_pix), d, k * n_pix * sizeof(float), false);
-            if (tiles == 1) rcode = run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done);   // one-frame chunks: concurrent slices
-            else rcode = encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
+            const int rcode = tiles == 1 ? run_encode_slices(ctx, d, k, cfg, outs + done, sizes + done)
+                                         : encode_batch(ctx, d, k, cfg, outs + done, sizes + done, nullptr, tiles, rc);
             if (rcode) return rcode;
             done += k;
         }
@@ -1887,11 +1952,17 @@ static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env
 namespace {
 
 // n_frames one-frame chunks as concurrent slices
-int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
+int run_encode_slices(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *cfg, uint8_t **outs, size_t *sizes,
+                      GpuPhase *phase)
 {
     const size_t n_pix = ctx->n_pix;
+    PhaseNote note;
+    note.phase = phase;
+    struct Over { PhaseNote &n; ~Over() { n.release_once(); } } over{note};                 // (whatever happened to the slices)
+    if (phase) phase->acquire();
     return run_slices(ctx, n_frames, [&](ebcc_hip_ctx *c, size_t lo, size_t cnt, SliceGate *next, unsigned slices) {
-        return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next, 1, nullptr, slices);
+        note.expect((int) slices);
+        return encode_batch(c, d_frames + lo * n_pix, cnt, cfg, outs + lo, sizes + lo, next, 1, nullptr, slices, phase ? &note : nullptr);
     }, "EBCC_HIP_SLICES", default_encode_slices());
 }
 
@@ -2053,6 +2124,32 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
     if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
     for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }   // on error: free the non-null ones
     return run_encode_slices(ctx, d_frames, n_frames, config, out_streams, out_sizes);
+    EBCC_API_CATCH(1)
+}
+
+// Any number of frames resident on the device, coded in batches of the context's capacity on two alternating engine sets
+// (GpuPhase above): the entropy stage of batch k runs beside the kernels of batch k + 1.  Same streams as
+// ebcc_hip_encode_frames batch by batch.  On error every stream made so far is freed and the call returns 1.
+int ebcc_hip_encode_shard(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
+                          uint8_t **out_streams, size_t *out_sizes)
+{
+    EBCC_API_TRY
+    if (!ctx || !d_frames || !config || !out_streams || !out_sizes || n_frames < 1) { set_error("ebcc_hip_encode_shard: bad arguments"); return 1; }
+    if (config->dims[0] != 1 || (int) config->dims[1] != ctx->height || (int) config->dims[2] != ctx->width) {
+        set_error("ebcc_hip_encode_shard: config dims must be (1, %d, %d)", ctx->height, ctx->width);
+        return 1;
+    }
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    log_set_level_from_env();
+    if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+    for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }
+    const size_t n_pix = ctx->n_pix;
+    const int rc = encode_batches_alternating(ctx, n_frames, config, out_streams, out_sizes,
+                                              [&](ebcc_hip_ctx *, size_t lo, size_t) { return d_frames + lo * n_pix; });
+    if (rc)
+        for (size_t f = 0; f < n_frames; f++) { free(out_streams[f]); out_streams[f] = nullptr; out_sizes[f] = 0; }
+    return rc;
     EBCC_API_CATCH(1)
 }
 

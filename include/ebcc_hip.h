@@ -109,6 +109,15 @@ int ebcc_hip_encode_frames(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fr
                            uint8_t **out_streams, size_t *out_sizes);
 int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                            float *d_frames_out);
+/* One GPU's share of a large array (BASELINE configs[3]: 4096 frames per GPU): any number of device-resident frames, coded
+ * in batches of the context's capacity - the loop a caller of ebcc_hip_encode_frames would write, which is also what
+ * ebcc_encode_chunking (/root/reference/src/ebcc_codec.c:1007-1046) does chunk by chunk - but on two alternating engine
+ * sets, so that the host part of batch k (the level-22 zstd of the kept residual prefixes, about a quarter of a batch's
+ * time, during which its kernels have nothing to do) runs beside the kernels of batch k + 1.  The second engine set is
+ * created on first use and lives as long as the context; without memory for it the batches run one after the other.
+ * Streams are identical to those of ebcc_hip_encode_frames.  0 = ok; on error every stream made so far has been freed. */
+int ebcc_hip_encode_shard(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
+                          uint8_t **out_streams, size_t *out_sizes);
 
 /* Worker threads of the process-wide host pool that runs the entropy stage (level-22 zstd of the residual prefixes) of
  * every slice of every call: EBCC_HOST_THREADS, else the CPUs the process may really use - its affinity mask cut down to

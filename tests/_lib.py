@@ -188,6 +188,9 @@ def product():
                                                    ctypes.POINTER(CodecConfig), c_void_pp, c_size_p]
             lib.ebcc_hip_decode_frames.argtypes = [ctypes.c_void_p, c_void_pp, c_size_p, ctypes.c_size_t,
                                                    ctypes.c_void_p]
+        if hasattr(lib, "ebcc_hip_encode_shard"):
+            lib.ebcc_hip_encode_shard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                  ctypes.POINTER(CodecConfig), c_void_pp, c_size_p]
         for name in ("ebcc_encode", "ebcc_encode_chunking", "ebcc_encode_chunking_compat"):
             if hasattr(lib, name):
                 f = getattr(lib, name)
@@ -360,6 +363,24 @@ class Context:
             res.append(ctypes.string_at(outs[f], sizes[f]))
             self.lib.free_buffer(outs[f])
         d.free()
+        return res
+
+    def encode_shard(self, frames, cfg):
+        """any number of frames through ebcc_hip_encode_shard (batches of the context's capacity on two engine sets)"""
+        frames = np.ascontiguousarray(frames, np.float32)
+        n = frames.shape[0]
+        d = DeviceArray(frames)
+        outs = (ctypes.c_void_p * n)()
+        sizes = (ctypes.c_size_t * n)()
+        rc = self.lib.ebcc_hip_encode_shard(self.ptr, d.ptr, n, ctypes.byref(cfg), outs, sizes)
+        d.free()
+        if rc:
+            assert all(not outs[f] for f in range(n))                  # (freed by the library)
+            return None
+        res = []
+        for f in range(n):
+            res.append(ctypes.string_at(outs[f], sizes[f]))
+            self.lib.free_buffer(outs[f])
         return res
 
     def decode_frames(self, streams):

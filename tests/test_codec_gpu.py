@@ -444,6 +444,18 @@ def test_device_selection_and_multi_device_chunking():
         assert r.stdout == runs["dev0"]
 
 
+def test_chunking_in_several_batches_gives_the_same_container():
+    """EBCC_HIP_MAX_BATCH below the number of chunks: ebcc_encode_chunking uploads and codes batch after batch on two
+    alternating engine sets (encode_batches_alternating), ebcc_decode_chunking decodes batch after batch - same container,
+    same array as in one batch."""
+    shape, chunk = (11, 64, 96), (1, 64, 96)
+    one = _child(env={}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+    assert one.returncode == 0 and "SHA" in one.stdout, one.stderr[-400:]
+    for cap in ("4", "2", "10"):
+        r = _child(env={"EBCC_HIP_MAX_BATCH": cap}, shape=shape, chunk=chunk, fn="ebcc_encode_chunking", dfn="ebcc_decode_chunking")
+        assert r.returncode == 0 and r.stdout == one.stdout, (cap, r.stdout, r.stderr[-400:])
+
+
 def test_host_and_device_search_loops_agree(monkeypatch):
     """The device-side state machines of the rate search and the truncation bisection (search.hpp) against the host
     loops they replace, and batches of rounds too short for a search (more rounds are enqueued then)."""
@@ -514,6 +526,69 @@ def test_shard_of_many_batches_keeps_the_bound_and_the_bytes(monkeypatch):
     L.oracle().orc_set_j2k_backend(0)
     for i in (0, 7, 8, 20, 36):
         assert streams[i] == L.orc_encode(frames[i], cfg), i
+
+
+def test_shard_entry_point_alternates_engine_sets_and_gives_the_same_streams(monkeypatch):
+    """ebcc_hip_encode_shard: batches on two alternating engine sets, the entropy stage of one beside the kernels of the
+    next - the streams are those of ebcc_hip_encode_frames batch by batch, for a ragged last batch, for a shard of one batch,
+    with the residual layer kept and without; when the second engine set cannot be made the batches run on the first."""
+    h, w, cap, m = 64, 96, 8, 29
+    frames = np.stack([L.era5_like(h, w, 2100 + s, 1.0 + 0.1 * (s % 5), 0.5 + 0.1 * (s % 3)) for s in range(m)]).astype(np.float32)
+    for cfg in (L.make_config((1, h, w), base_cr=25.0, error=0.05, residual_type=L.MAX_ERROR),
+                L.make_config((1, h, w), base_cr=40.0, error=2e-3, residual_type=L.RELATIVE_ERROR),
+                L.make_config((1, h, w), base_cr=50.0, error=0.0, residual_type=L.NONE)):
+        with L.Context(cap, h, w) as ctx:
+            want = []
+            for lo in range(0, m, cap):
+                want += ctx.encode_frames(frames[lo:lo + cap], cfg)
+            assert ctx.encode_shard(frames, cfg) == want
+            assert ctx.encode_shard(frames, cfg) == want                # (both engine sets warm)
+            assert ctx.encode_shard(frames[:5], cfg) == want[:5]        # one batch: no second set involved
+
+
+_SHARD = r"""
+import ctypes, hashlib, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from tests import _lib as L
+lib = L.product()
+h, w, cap, m = 64, 96, 8, 20
+frames = np.stack([L.era5_like(h, w, 2100 + s, 1.0 + 0.1 * (s % 5), 0.5 + 0.1 * (s % 3)) for s in range(m)]).astype(np.float32)
+cfg = L.make_config((1, h, w), base_cr=25.0, error=0.05, residual_type=L.MAX_ERROR)
+ctx = None
+for attempt in range(4):                                     # (the failing allocation may be one of the context's own)
+    try:
+        ctx = L.Context(cap, h, w)
+        break
+    except AssertionError:
+        print("NO CONTEXT", flush=True)
+for attempt in range(3):
+    try:
+        got = ctx.encode_shard(frames, cfg)
+    except AssertionError:                                   # (the frames' own device buffer was the allocation that failed)
+        got = None
+    print("RETURNED", "-" if got is None else hashlib.sha256(b"".join(got)).hexdigest(), flush=True)
+ctx.close()
+"""
+
+
+def test_shard_entry_point_survives_failed_allocations():
+    """EBCC_HIP_FAIL_ALLOC in a child: when the second engine set (or a slice engine of either set) cannot be made the shard
+    runs on what there is, or the call fails cleanly; the process always recovers and gives the same streams."""
+    import os
+    import subprocess
+    import sys
+    base = {k: v for k, v in os.environ.items() if not k.startswith("EBCC_HIP_")}
+    ok = subprocess.run([sys.executable, "-c", _SHARD.format(root=L.ROOT)], capture_output=True, text=True, env=base, timeout=600)
+    want = [l for l in ok.stdout.splitlines() if l.startswith("RETURNED")]
+    assert ok.returncode == 0 and len(want) == 3 and len(set(want)) == 1 and want[0] != "RETURNED -", (ok.stdout, ok.stderr[-400:])
+    for nth in (2, 40, 70, 100, 130, 160, 190):
+        r = subprocess.run([sys.executable, "-c", _SHARD.format(root=L.ROOT)], capture_output=True, text=True, env=dict(base, EBCC_HIP_FAIL_ALLOC=str(nth)),
+                           timeout=600)
+        got = [l for l in r.stdout.splitlines() if l.startswith("RETURNED")]
+        assert r.returncode == 0 and len(got) == 3, (nth, r.returncode, r.stdout, r.stderr[-600:])
+        assert got[2] == want[0], (nth, got)
+        assert all(g == want[0] or g == "RETURNED -" for g in got), (nth, got)
 
 
 _BIG = r"""

@@ -2095,6 +2095,26 @@ int ebcc_hip_prefault(void *h_dst, size_t bytes)
     EBCC_API_CATCH(1)
 }
 
+// The engines the reference-compatible entry points keep between calls (one per device and frame geometry, with their slice
+// engines and second set: tens of GB of device memory for 256 frames of 721 x 1440) are destroyed; the next call makes them
+// again.  Contexts made with ebcc_hip_create are the caller's and are not touched.
+void ebcc_hip_release_engines(void)
+{
+    EBCC_API_TRY
+    std::vector<std::pair<int, ebcc_hip_ctx *>> victims;
+    {
+        std::lock_guard<std::mutex> lock(g_map_mutex);
+        for (auto &kv : g_ctx) victims.emplace_back(std::get<0>(kv.first), kv.second);
+        g_ctx.clear();
+    }
+    for (auto &v : victims) {
+        std::lock_guard<std::mutex> lock(device_mutex(v.first));       // (a call that is using the engine finishes first)
+        DeviceScope scope(v.first);
+        ebcc_hip_destroy(v.second);
+    }
+    EBCC_API_CATCH_VOID
+}
+
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
 {
     EBCC_API_TRY

@@ -95,6 +95,11 @@ int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t 
  * slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
  * n_frames (part of setting a context up, like ebcc_hip_create).  Returns 0. */
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
+/* ebcc_encode / ebcc_decode / the chunking entry points and the HDF5 filter (/root/reference/src/ebcc_codec.h:41-49) keep
+ * their engines between calls, one per device and frame geometry - tens of GB of device memory for batches of 256 frames of
+ * 721 x 1440.  This gives that memory back; the next call makes the engines again.  Contexts of ebcc_hip_create are not
+ * touched. */
+void ebcc_hip_release_engines(void);
 /* Pageable host memory <-> device memory through the engine's pinned bounce buffers with several copying host threads
  * (what the chunking entry points use for their own arrays): ~3x hipMemcpy on a fresh pageable array.  0 = ok. */
 int ebcc_hip_upload(ebcc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

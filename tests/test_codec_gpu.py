@@ -444,6 +444,22 @@ def test_device_selection_and_multi_device_chunking():
         assert r.stdout == runs["dev0"]
 
 
+def test_released_engines_are_made_again():
+    """ebcc_hip_release_engines drops what the reference-compatible entry points cache; the next call works and gives the
+    same bytes."""
+    lib = L.product()
+    lib.ebcc_hip_release_engines.restype = None
+    frame = L.era5_like(64, 96, 31, 1.2, 0.8)
+    cfg = L.make_config((1, 64, 96), base_cr=20.0, error=0.05, residual_type=L.MAX_ERROR)
+    a = api_encode(frame, cfg)
+    lib.ebcc_hip_release_engines()
+    lib.ebcc_hip_release_engines()                                   # (nothing left: a no-op)
+    assert api_encode(frame, cfg) == a
+    d = api_decode(a)
+    lib.ebcc_hip_release_engines()
+    assert np.array_equal(api_decode(a), d)
+
+
 def test_chunking_in_several_batches_gives_the_same_container():
     """EBCC_HIP_MAX_BATCH below the number of chunks: ebcc_encode_chunking uploads and codes batch after batch on two
     alternating engine sets (encode_batches_alternating), ebcc_decode_chunking decodes batch after batch - same container,

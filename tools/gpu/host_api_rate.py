@@ -28,7 +28,7 @@ for rep in range(3):
     t2 = time.perf_counter()
     assert m == x.size
     if rep == 2:
-        d = np.frombuffer(ctypes.string_at(dec.value, 4 * m), np.float32).reshape(x.shape)
+        d = np.ctypeslib.as_array(ctypes.cast(dec, ctypes.POINTER(ctypes.c_float)), shape=x.shape)
         print("max abs error", float(np.abs(d - x).max()), "ratio", x.nbytes / nb)
     lib.free_buffer(out)
     lib.free_buffer(dec)

@@ -1812,6 +1812,39 @@ int encode_batches_alternating(ebcc_hip_ctx *ctx, size_t n_frames, const codec_c
     return worst.load();
 }
 
+// The decode counterpart: batches of `cap` frames alternately on the two engine sets, both free-running - one batch's
+// download (or, for long residual streams, its one-wave-per-frame SPIHT chains, which leave most of the chip idle) beside
+// the other's kernels.  each(set, first frame, count) decodes one batch and puts its output where it belongs.
+template <class Each>
+int decode_batches_alternating(ebcc_hip_ctx *ctx, size_t n_frames, size_t cap, Each each)
+{
+    const size_t batches = (n_frames + cap - 1) / cap;
+    if (batches == 1) return each(ctx, (size_t) 0, n_frames);
+    if (!ctx->twin) ctx->twin = ebcc_hip_create(ctx->device, ctx->max_frames, (size_t) ctx->height, (size_t) ctx->width);
+    ebcc_hip_ctx *const set[2] = {ctx, ctx->twin};
+    std::atomic<int> worst{0};
+    std::string err[2];
+    auto work = [&](int t) {
+        try {
+            EBCC_HIP_CHECK(hipSetDevice(ctx->device));
+            for (size_t b = (size_t) t; b < batches && !worst.load(); b += set[1] ? 2 : 1) {
+                const size_t lo = b * cap;
+                const int r = each(set[t], lo, std::min(cap, n_frames - lo));
+                if (r) { err[t] = ebcc_hip_last_error(); int e = 0; worst.compare_exchange_strong(e, r); }
+            }
+        } catch (const std::exception &e) { err[t] = e.what(); int z = 0; worst.compare_exchange_strong(z, 1); }
+    };
+    if (set[1]) {
+        std::thread second(work, 1);
+        work(0);
+        second.join();
+    } else {
+        work(0);
+    }
+    if (worst.load()) set_error("%s", (err[0].empty() ? err[1] : err[0]).c_str());
+    return worst.load();
+}
+
 // host-pointer convenience used by the reference-compatible entry points
 // n chunks of `tiles` frames of H x W each, contiguous in host memory, on device `device`.  Returns 0 ok, 1 error (logged),
 // 2 NaN / Inf in the data (the caller exits as the reference does, /root/reference/src/ebcc_codec.c:598-605).
@@ -2185,6 +2218,23 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
     EBCC_API_CATCH(1)
 }
 
+// Any number of streams decoded to consecutive frames on the device, in batches of the context's capacity on the two
+// engine sets side by side (decode_batches_alternating).  Same frames as ebcc_hip_decode_frames batch by batch.
+int ebcc_hip_decode_shard(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
+                          float *d_frames_out)
+{
+    EBCC_API_TRY
+    if (!ctx || !streams || !sizes || !d_frames_out || n_frames < 1) { set_error("ebcc_hip_decode_shard: bad arguments"); return 1; }
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+    const size_t n_pix = ctx->n_pix;
+    return decode_batches_alternating(ctx, n_frames, ctx->max_frames, [&](ebcc_hip_ctx *set, size_t lo, size_t k) {
+        return run_decode_slices(set, streams + lo, sizes + lo, k, d_frames_out + lo * n_pix);
+    });
+    EBCC_API_CATCH(1)
+}
+
 size_t ebcc_encode(float *data, codec_config_t *config, uint8_t **out_buffer)
 {
     log_set_level_from_env();
@@ -2415,21 +2465,27 @@ size_t ebcc_decode_chunking(uint8_t *data, size_t data_size, float **out_buffer)
             ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
             if (!chunk_engines(device, H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
             if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-            PhaseTimer pt;
-            float *d = io_buffer(ctx, cap * csize * sizeof(float));
-            pt.mark("decode_chunking: engine, device image");
-            for (size_t done = first; done < first + count;) {
-                const size_t k = std::min(cap, first + count - done);
-                // (one download per batch: copies issued from inside the slices slowed them down)
-                const int r = tiles > 1 ? decode_tiled(ctx, rc, ptrs.data() + done, lens.data() + done, k, tiles, d)
-                                        : run_decode_slices(ctx, ptrs.data() + done, lens.data() + done, k, d);
+            // (one download per batch: copies issued from inside the slices slowed them down)
+            auto one_batch = [&](ebcc_hip_ctx *set, size_t lo, size_t k) {
+                PhaseTimer pt;
+                float *d = io_buffer(set, cap * csize * sizeof(float));
+                pt.mark("decode_chunking: engine, device image");
+                const size_t done = first + lo;
+                const int r = tiles > 1 ? decode_tiled(set, rc, ptrs.data() + done, lens.data() + done, k, tiles, d)
+                                        : run_decode_slices(set, ptrs.data() + done, lens.data() + done, k, d);
                 if (r) return r;
                 pt.mark("decode_chunking: decode");
                 prefault.join();
                 pt.mark("decode_chunking: output pages");
-                copy_pageable(ctx, h_chunks + done * csize, d, k * csize * sizeof(float), true);
+                copy_pageable(set, h_chunks + done * csize, d, k * csize * sizeof(float), true);
                 pt.mark("decode_chunking: download");
-                done += k;
+                return 0;
+            };
+            // one-frame chunks in several batches: on two alternating engine sets, a batch's download beside the next one's kernels
+            if (tiles == 1 && ctx->max_frames == cap) return decode_batches_alternating(ctx, count, cap, one_batch);
+            for (size_t lo = 0; lo < count; lo += cap) {
+                const int r = one_batch(ctx, lo, std::min(cap, count - lo));
+                if (r) return r;
             }
             return 0;
         } catch (const std::exception &e) {

@@ -123,6 +123,12 @@ int ebcc_hip_decode_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, con
  * Streams are identical to those of ebcc_hip_encode_frames.  0 = ok; on error every stream made so far has been freed. */
 int ebcc_hip_encode_shard(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_frames, const codec_config_t *config,
                           uint8_t **out_streams, size_t *out_sizes);
+/* The decode counterpart: any number of streams to consecutive frames on the device, batches on the two engine sets side
+ * by side (a batch of long residual streams is one wave per frame and leaves most of the chip idle; for host arrays,
+ * ebcc_decode_chunking - /root/reference/src/ebcc_codec.c:1322-1449 - downloads one batch beside the next one's kernels the
+ * same way).  Same frames as ebcc_hip_decode_frames batch by batch.  0 = ok. */
+int ebcc_hip_decode_shard(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
+                          float *d_frames_out);
 
 /* Worker threads of the process-wide host pool that runs the entropy stage (level-22 zstd of the residual prefixes) of
  * every slice of every call: EBCC_HOST_THREADS, else the CPUs the process may really use - its affinity mask cut down to

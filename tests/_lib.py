@@ -191,6 +191,7 @@ def product():
         if hasattr(lib, "ebcc_hip_encode_shard"):
             lib.ebcc_hip_encode_shard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.POINTER(CodecConfig), c_void_pp, c_size_p]
+            lib.ebcc_hip_decode_shard.argtypes = [ctypes.c_void_p, c_void_pp, c_size_p, ctypes.c_size_t, ctypes.c_void_p]
         for name in ("ebcc_encode", "ebcc_encode_chunking", "ebcc_encode_chunking_compat"):
             if hasattr(lib, name):
                 f = getattr(lib, name)
@@ -383,13 +384,13 @@ class Context:
             self.lib.free_buffer(outs[f])
         return res
 
-    def decode_frames(self, streams):
+    def decode_frames(self, streams, shard=False):
         n = len(streams)
         bufs = [ctypes.create_string_buffer(bytes(s), len(s)) for s in streams]
         ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(b, ctypes.c_void_p).value for b in bufs])
         sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
         out = DeviceArray(nbytes=n * self.h * self.w * 4)
-        rc = self.lib.ebcc_hip_decode_frames(self.ptr, ptrs, sizes, n, out.ptr)
+        rc = (self.lib.ebcc_hip_decode_shard if shard else self.lib.ebcc_hip_decode_frames)(self.ptr, ptrs, sizes, n, out.ptr)
         assert rc == 0, self.lib.ebcc_hip_last_error()
         res = out.get(np.float32, (n, self.h, self.w))
         out.free()

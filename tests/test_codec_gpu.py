@@ -560,6 +560,8 @@ def test_shard_entry_point_alternates_engine_sets_and_gives_the_same_streams(mon
             assert ctx.encode_shard(frames, cfg) == want
             assert ctx.encode_shard(frames, cfg) == want                # (both engine sets warm)
             assert ctx.encode_shard(frames[:5], cfg) == want[:5]        # one batch: no second set involved
+            dec = np.concatenate([ctx.decode_frames(want[lo:lo + cap]) for lo in range(0, m, cap)])
+            assert np.array_equal(ctx.decode_frames(want, shard=True), dec)    # decode: both sets side by side
 
 
 _SHARD = r"""

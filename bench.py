@@ -280,12 +280,12 @@ def main():
         env.pop("PYTHONPATH", None)
         try:
             with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
-                r = subprocess.run([conda, os.path.join(ROOT, "tools", "gpu", "h5_rate.py"), tmp, str(frames_), "--json"], env=env,
+                r = subprocess.run([conda, os.path.join(ROOT, "tools", "gpu", "h5_rate.py"), tmp, str(frames_), "--json", "--big"], env=env,
                                    capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 return {"error": (r.stderr or r.stdout)[-400:]}
             out_ = json.loads(r.stdout.strip().splitlines()[-1])
-            out_["workload"] = f"{frames_} one-frame chunks 721x1440 (error bound 0.5) through h5py {conda}: filter callback (16 frames) and direct-chunk device batches; file in memory-backed /dev/shm"
+            out_["workload"] = f"{frames_} one-frame chunks 721x1440 (error bound 0.5) through h5py {conda}: filter callback (16 frames), direct-chunk device batches, and a dataset of four such batches (on two alternating engine sets); files in memory-backed /dev/shm"
             return out_
         except Exception as e:                                      # (a report, never a gate)
             return {"error": repr(e)}
@@ -372,6 +372,7 @@ def main():
         # ---- BASELINE configs[4]'s path: EBCC-filtered HDF5 datasets of one frame per chunk, written and read (i) through the
         #      plain filter-308 callback (one chunk per call) and (ii) as device batches of pre-filtered chunks
         #      (ebcc_amd/h5_batch.py: H5Dwrite_chunk / H5Dread_chunk), with the image's conda h5py in a child process
+        torch.cuda.empty_cache()                                                  # (the child makes its own engines: 125 GB for two sets)
         ex["h5_path"] = h5_path_rates(n)
         # ---- the reference's host-pointer API: pageable host array in, EBCK container in host memory out (PCIe inclusive)
         host = frames.cpu().numpy()

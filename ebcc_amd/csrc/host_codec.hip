@@ -2128,6 +2128,58 @@ int ebcc_hip_prefault(void *h_dst, size_t bytes)
     EBCC_API_CATCH(1)
 }
 
+// Frames in pageable host memory <-> streams through a caller's context, for callers that keep the chunks themselves
+// (ebcc_amd/h5_batch.py: HDF5 direct chunk writes / reads): what ebcc_encode_chunking / ebcc_decode_chunking do between the
+// array and the EBCK container - uploads / downloads through the pinned bounce buffers, batches of the context's capacity
+// on the two alternating engine sets, the output's pages mapped while the GPU decodes.  Any number of frames.  0 = ok;
+// on error every stream made so far has been freed.
+int ebcc_hip_encode_host_frames(ebcc_hip_ctx *ctx, const float *h_frames, size_t n_frames, const codec_config_t *config,
+                                uint8_t **out_streams, size_t *out_sizes)
+{
+    EBCC_API_TRY
+    if (!ctx || !h_frames || !config || !out_streams || !out_sizes || n_frames < 1) { set_error("ebcc_hip_encode_host_frames: bad arguments"); return 1; }
+    if (config->dims[0] != 1 || (int) config->dims[1] != ctx->height || (int) config->dims[2] != ctx->width) {
+        set_error("ebcc_hip_encode_host_frames: config dims must be (1, %d, %d)", ctx->height, ctx->width);
+        return 1;
+    }
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    log_set_level_from_env();
+    if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+    for (size_t f = 0; f < n_frames; f++) { out_streams[f] = nullptr; out_sizes[f] = 0; }
+    const size_t n_pix = ctx->n_pix, cap = ctx->max_frames;
+    const int rc = encode_batches_alternating(ctx, n_frames, config, out_streams, out_sizes, [&](ebcc_hip_ctx *set, size_t lo, size_t cnt) {
+        float *d = io_buffer(set, cap * n_pix * sizeof(float));
+        copy_pageable(set, const_cast<float *>(h_frames + lo * n_pix), d, cnt * n_pix * sizeof(float), false);
+        return (const float *) d;
+    });
+    if (rc) {
+        if (rc == 2) set_error("ebcc_hip_encode_host_frames: NaN or Inf in the data");
+        for (size_t f = 0; f < n_frames; f++) { free(out_streams[f]); out_streams[f] = nullptr; out_sizes[f] = 0; }
+    }
+    return rc;
+    EBCC_API_CATCH(1)
+}
+int ebcc_hip_decode_host_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames, float *h_frames_out)
+{
+    EBCC_API_TRY
+    if (!ctx || !streams || !sizes || !h_frames_out || n_frames < 1) { set_error("ebcc_hip_decode_host_frames: bad arguments"); return 1; }
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+    const size_t n_pix = ctx->n_pix, cap = ctx->max_frames;
+    Prefault prefault(h_frames_out, n_frames * n_pix * sizeof(float));
+    return decode_batches_alternating(ctx, n_frames, cap, [&](ebcc_hip_ctx *set, size_t lo, size_t k) {
+        float *d = io_buffer(set, cap * n_pix * sizeof(float));
+        const int r = run_decode_slices(set, streams + lo, sizes + lo, k, d);
+        if (r) return r;
+        prefault.join();
+        copy_pageable(set, h_frames_out + lo * n_pix, d, k * n_pix * sizeof(float), true);
+        return 0;
+    });
+    EBCC_API_CATCH(1)
+}
+
 // The engines the reference-compatible entry points keep between calls (one per device and frame geometry, with their slice
 // engines and second set: tens of GB of device memory for 256 frames of 721 x 1440) are destroyed; the next call makes them
 // again.  Contexts made with ebcc_hip_create are the caller's and are not touched.

@@ -59,21 +59,19 @@ class BatchCodec:
                                                ctypes.c_size_t, ctypes.c_void_p]
         lib.ebcc_hip_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         lib.ebcc_hip_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-        lib.ebcc_hip_prefault.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-        lib.ebcc_hip_prefault.restype = ctypes.c_int
+        lib.ebcc_hip_encode_host_frames.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CodecConfig),
+                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        lib.ebcc_hip_decode_host_frames.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                                    ctypes.c_size_t, ctypes.c_void_p]
         lib.ebcc_hip_last_error.restype = ctypes.c_char_p
         lib.free_buffer.argtypes = [ctypes.c_void_p]
         self.h, self.w, self.max_frames = int(height), int(width), int(max_frames)
         self.ctx = lib.ebcc_hip_create(device, self.max_frames, self.h, self.w)
         if not self.ctx:
             raise RuntimeError("EBCC MI355X engine: " + (lib.ebcc_hip_last_error() or b"?").decode())
-        self.d_buf = lib.ebcc_hip_malloc(self.max_frames * self.h * self.w * 4)
-        if not self.d_buf:
-            raise MemoryError("device frame buffer")
 
     def close(self):
         if self.ctx:
-            self.lib.ebcc_hip_free(self.d_buf)
             self.lib.ebcc_hip_destroy(self.ctx)
             self.ctx = None
 
@@ -84,19 +82,16 @@ class BatchCodec:
         self.close()
 
     def encode(self, frames, cfg):
-        """frames: (n, H, W) float32, n <= max_frames -> list of EBCC frame streams (bytes)."""
+        """frames: (n, H, W) float32 in host memory, any n -> list of EBCC frame streams (bytes).  More frames than the
+        engine holds are coded in batches on two alternating engine sets (the host part of one batch beside the upload and
+        the kernels of the next)."""
         frames = np.ascontiguousarray(frames, np.float32)
         n = frames.shape[0]
-        assert frames.shape[1:] == (self.h, self.w) and 1 <= n <= self.max_frames
-        if self.lib.ebcc_hip_upload(self.ctx, self.d_buf, frames.ctypes.data, frames.nbytes):
-            raise RuntimeError("ebcc_hip_upload: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+        assert frames.shape[1:] == (self.h, self.w) and n >= 1
         outs = (ctypes.c_void_p * n)()
         sizes = (ctypes.c_size_t * n)()
-        if self.lib.ebcc_hip_encode_frames(self.ctx, self.d_buf, n, ctypes.byref(cfg), outs, sizes):
-            for i in range(n):                                   # (streams finished before the failure are still ours to free)
-                if outs[i]:
-                    self.lib.free_buffer(outs[i])
-            raise RuntimeError("ebcc_hip_encode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+        if self.lib.ebcc_hip_encode_host_frames(self.ctx, frames.ctypes.data, n, ctypes.byref(cfg), outs, sizes):
+            raise RuntimeError("ebcc_hip_encode_host_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
         res = []
         for i in range(n):
             res.append(ctypes.string_at(outs[i], sizes[i]))
@@ -104,10 +99,11 @@ class BatchCodec:
         return res
 
     def decode(self, streams, out=None):
-        """list of EBCC frame streams (bytes) -> (n, H, W) float32; `out`: a C-contiguous float32 array to decode into
-        (the frames then cross PCIe straight into it - no intermediate array)."""
+        """list of EBCC frame streams (bytes), any number -> (n, H, W) float32; `out`: a C-contiguous float32 array to decode
+        into (the frames cross PCIe straight into it; its pages are mapped while the GPU decodes, one batch is downloaded
+        beside the kernels of the next)."""
         n = len(streams)
-        assert 1 <= n <= self.max_frames
+        assert n >= 1
         streams = [s if isinstance(s, bytes) else bytes(s) for s in streams]
         # (pointers into the bytes objects themselves: they stay alive in `streams` for the duration of the call)
         ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(s), ctypes.c_void_p).value for s in streams])
@@ -115,31 +111,15 @@ class BatchCodec:
         if out is None:
             out = np.empty((n, self.h, self.w), np.float32)
         assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == n * self.h * self.w
-        # the destination's pages are mapped on a second thread while the GPU decodes (ctypes releases the GIL)
-        timing = os.environ.get("EBCC_H5_TIMING")
         t0 = time.perf_counter()
-        tp = [t0]
-
-        def prefault():
-            self.lib.ebcc_hip_prefault(ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.nbytes))
-            tp[0] = time.perf_counter()
-
-        pre = threading.Thread(target=prefault)
-        pre.start()
-        try:
-            if self.lib.ebcc_hip_decode_frames(self.ctx, ptrs, sizes, n, self.d_buf):
-                raise RuntimeError("ebcc_hip_decode_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
-            t1 = time.perf_counter()
-        finally:
-            pre.join()
-        t2 = time.perf_counter()
-        if self.lib.ebcc_hip_download(self.ctx, out.ctypes.data, self.d_buf, out.nbytes):
-            raise RuntimeError("ebcc_hip_download: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
-        if timing:
-            print(f"h5_batch.decode: {n} frames, decode {1e3 * (t1 - t0):.1f} ms, pages mapped after {1e3 * (tp[0] - t0):.1f} ms, "
-                  f"download {1e3 * (time.perf_counter() - t2):.1f} ms", file=sys.stderr, flush=True)
+        if self.lib.ebcc_hip_decode_host_frames(self.ctx, ptrs, sizes, n, out.ctypes.data):
+            raise RuntimeError("ebcc_hip_decode_host_frames: " + (self.lib.ebcc_hip_last_error() or b"?").decode())
+        if os.environ.get("EBCC_H5_TIMING"):
+            print(f"h5_batch.decode: {n} frames decoded and downloaded in {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr, flush=True)
         return out
 
+
+_SUPER = 16         # batches handed to the engine per call by write_frames / read_frames (filling and draining the two sets costs ~half a batch)
 
 # Engines are expensive to make (tens of GB of device workspace for 256 frames of 721 x 1440) and cheap to keep: the
 # helpers below share one per (height, width, capacity, device) for the life of the process (close_cached() lets go).
@@ -182,28 +162,30 @@ def write_frames(dset, data, base_cr, residual_opt=("none", None), batch=256, co
     lead = data.shape[:-2]
     cfg = frame_config(h, w, base_cr, residual_opt)
     codec = codec or cached_codec(h, w, min(batch, len(flat)))
-    for lo in range(0, len(flat), codec.max_frames):
-        streams = codec.encode(flat[lo:lo + codec.max_frames], cfg)
+    step = _SUPER * codec.max_frames                            # (several batches per call: they alternate between two engine sets)
+    for lo in range(0, len(flat), step):
+        streams = codec.encode(flat[lo:lo + step], cfg)
         for i, s in enumerate(streams):
             idx = np.unravel_index(lo + i, lead) if lead else ()
             dset.id.write_direct_chunk(tuple(int(v) for v in idx) + (0, 0), s, filter_mask=0)
 
 
 def read_frames(dset, batch=256, codec=None):
-    """Read an EBCC-filtered one-frame-per-chunk dataset by decoding its raw chunks in device batches.  The raw chunks of
-    batch k + 1 are fetched from the file (h5py, one call per chunk) on a helper thread while batch k is decoded and
-    downloaded - straight into its place in the result."""
-    import threading
+    """Read an EBCC-filtered one-frame-per-chunk dataset by decoding its raw chunks in device batches, several batches per
+    call (they alternate between two engine sets: one is downloaded while the next decodes).  The raw chunks of the next
+    call are fetched from the file (h5py, one call per chunk) on a helper thread meanwhile; the frames land straight in
+    their place in the result."""
     h, w = dset.shape[-2:]
     lead = dset.shape[:-2]
     n = int(np.prod(lead)) if lead else 1
     out = np.empty((n, h, w), np.float32)
     codec = codec or cached_codec(h, w, min(batch, n))
+    step = _SUPER * codec.max_frames
 
     def fetch(lo, box):
         try:
             raw = []
-            for i in range(lo, min(n, lo + codec.max_frames)):
+            for i in range(lo, min(n, lo + step)):
                 idx = np.unravel_index(i, lead) if lead else ()
                 mask, chunk = dset.id.read_direct_chunk(tuple(int(v) for v in idx) + (0, 0))
                 if mask:
@@ -217,14 +199,14 @@ def read_frames(dset, batch=256, codec=None):
     t0 = time.perf_counter()
     fetch(0, box)
     if os.environ.get("EBCC_H5_TIMING"):
-        print(f"h5_batch.read_frames: first batch of chunks fetched in {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr, flush=True)
-    for lo in range(0, n, codec.max_frames):
+        print(f"h5_batch.read_frames: first {min(n, step)} chunks fetched in {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr, flush=True)
+    for lo in range(0, n, step):
         raw = box[0]
         if isinstance(raw, BaseException):
             raise raw
         box, t = [], None
-        if lo + codec.max_frames < n:
-            t = threading.Thread(target=fetch, args=(lo + codec.max_frames, box))
+        if lo + step < n:
+            t = threading.Thread(target=fetch, args=(lo + step, box))
             t.start()
         try:
             codec.decode(raw, out=out[lo:lo + len(raw)])

@@ -104,6 +104,15 @@ void ebcc_hip_release_engines(void);
  * (what the chunking entry points use for their own arrays): ~3x hipMemcpy on a fresh pageable array.  0 = ok. */
 int ebcc_hip_upload(ebcc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ebcc_hip_download(ebcc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* Frames in pageable host memory <-> streams, any number of frames: what ebcc_encode_chunking / ebcc_decode_chunking
+ * (/root/reference/src/ebcc_codec.c:1007-1046, :1322-1449) do between the array and the EBCK container, for callers that
+ * keep the chunks themselves (HDF5 direct chunk writes / reads, ebcc_amd/h5_batch.py): staged uploads / downloads, batches
+ * of the context's capacity on the two alternating engine sets, the output's pages mapped while the GPU decodes.
+ * 0 = ok; on an encode error every stream made so far has been freed. */
+int ebcc_hip_encode_host_frames(ebcc_hip_ctx *ctx, const float *h_frames, size_t n_frames, const codec_config_t *config,
+                                uint8_t **out_streams, size_t *out_sizes);
+int ebcc_hip_decode_host_frames(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
+                                float *h_frames_out);
 /* Maps the pages of a host array that is about to receive a download (a fresh allocation of hundreds of MB is unmapped:
  * the download would fault it in page by page): asks for huge pages and touches every page from several threads, returns
  * when done.  DESTINATION arrays only - a zero is written to every page.  Meant to run on a second thread of the caller

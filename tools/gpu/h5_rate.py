@@ -50,6 +50,25 @@ for rep in range(2):
                                  "max_abs_error": round(float(np.abs(back - data).max()), 5), "file_MB": round(os.path.getsize(os.path.join(out, "dc.h5")) / 1e6, 2)}
     print(f"direct-chunk batch ({N} frames), rep {rep}: write {gb / (t1 - t0):.3f} GB/s, read {gb / (t2 - t1):.3f} GB/s, "
           f"max error {float(np.abs(back - data).max()):.4f}, file {os.path.getsize(os.path.join(out, 'dc.h5')) / 1e6:.1f} MB", flush=True, file=sys.stderr if as_json else sys.stdout)
+# a dataset of several device batches: the batches alternate between two engine sets (host part of one beside the kernels of
+# the next; one batch downloaded while the next decodes), the next call's chunks are fetched meanwhile
+M = 4 * N
+if "--big" in sys.argv:
+    big = np.concatenate([data + np.float32(0.11 * r) for r in range(M // N)])
+    for rep in range(2):
+        back = None
+        t0 = time.perf_counter()
+        with h5py.File(os.path.join(out, "big.h5"), "w") as f:
+            d = h5_batch.create_dataset(f, "t", big.shape, base_cr=30, residual_opt=opt)
+            h5_batch.write_frames(d, big, 30, opt)
+        t1 = time.perf_counter()
+        with h5py.File(os.path.join(out, "big.h5"), "r") as f:
+            back = h5_batch.read_frames(f["t"])
+        t2 = time.perf_counter()
+        res["direct_chunk_batches_x4"] = {"frames": M, "write_GBps": round(big.nbytes / 1e9 / (t1 - t0), 4), "read_GBps": round(big.nbytes / 1e9 / (t2 - t1), 4),
+                                          "max_abs_error": round(float(np.abs(back[::5] - big[::5]).max()), 5)}
+        print(f"direct-chunk batches ({M} frames), rep {rep}: write {big.nbytes / 1e9 / (t1 - t0):.3f} GB/s, read {big.nbytes / 1e9 / (t2 - t1):.3f} GB/s",
+              flush=True, file=sys.stderr if as_json else sys.stdout)
 if as_json:
     import json
     print(json.dumps(res), flush=True)

@@ -564,6 +564,32 @@ def test_shard_entry_point_alternates_engine_sets_and_gives_the_same_streams(mon
             assert np.array_equal(ctx.decode_frames(want, shard=True), dec)    # decode: both sets side by side
 
 
+def test_host_frame_entry_points_take_any_number_of_frames():
+    """ebcc_hip_encode_host_frames / ebcc_hip_decode_host_frames (through ebcc_amd.h5_batch.BatchCodec): frames in host memory,
+    more than the engine holds - same streams and frames as batch by batch through the device-pointer API."""
+    from ebcc_amd import h5_batch
+    h, w, cap, m = 64, 96, 8, 27
+    frames = np.stack([L.era5_like(h, w, 2300 + s, 1.0 + 0.1 * (s % 5), 0.5 + 0.1 * (s % 3)) for s in range(m)]).astype(np.float32)
+    cfg = L.make_config((1, h, w), base_cr=25.0, error=0.05, residual_type=L.MAX_ERROR)
+    with L.Context(cap, h, w) as ctx:
+        want = []
+        for lo in range(0, m, cap):
+            want += ctx.encode_frames(frames[lo:lo + cap], cfg)
+        dec = np.concatenate([ctx.decode_frames(want[lo:lo + cap]) for lo in range(0, m, cap)])
+    with h5_batch.BatchCodec(h, w, cap) as codec:
+        bcfg = h5_batch.frame_config(h, w, 25.0, ("max_error_target", 0.05))
+        assert codec.encode(frames, bcfg) == want
+        assert codec.encode(frames[:3], bcfg) == want[:3]
+        out = np.full((m, h, w), -1.0, np.float32)
+        assert codec.decode(want, out=out) is out and np.array_equal(out, dec)
+        assert np.array_equal(codec.decode(want[:5]), dec[:5])
+        bad = frames.copy()
+        bad[11, 3, 4] = np.nan
+        with pytest.raises(RuntimeError):
+            codec.encode(bad, bcfg)
+        assert codec.encode(frames[:9], bcfg) == want[:9]            # (and the codec goes on working)
+
+
 _SHARD = r"""
 import ctypes, hashlib, sys
 import numpy as np

@@ -1094,6 +1094,20 @@ struct LdsTable {
 // ================================================================================================
 // true decode: tier-1 MQ decoding, one code-block per lane, values scattered into V (half units)
 // ================================================================================================
+// context tables of the serial passes (t1_device.hpp: LdsCtx): in device memory once per device, copied to LDS by every workgroup
+__device__ __attribute__((aligned(16))) uint8_t g_ctx_tables[LdsCtx::kBytes];
+void ensure_ctx_tables()
+{
+    static std::once_flag once[64];
+    int dev = 0;
+    EBCC_HIP_CHECK(hipGetDevice(&dev));
+    std::call_once(once[dev & 63], [] {
+        uint8_t t[LdsCtx::kBytes];
+        make_ctx_tables(t);
+        EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ctx_tables), t, sizeof t));
+    });
+}
+
 struct DecStore {
     unsigned char *st; // group base of the state words (uniform: a wave stays inside one group of 64 code-blocks)
     uint32_t lane8;    // lane * 8
@@ -1233,7 +1247,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                                                        const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total, int lpw, int n_big, int lpw_small)
 {
     extern __shared__ unsigned long long dec_state[];                  // [kDecStateRows][lanes of this wave]
+    __shared__ __attribute__((aligned(16))) uint8_t ctx_store[LdsCtx::kBytes];
+    copy_ctx_tables(ctx_store, g_ctx_tables, (int) threadIdx.x, 64);   // (EBCC_LDS_MQ_TABLE synchronises)
     EBCC_LDS_MQ_TABLE(tab);
+    const LdsCtx ctxp{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) ctx_store, 0u};
     // the first n_big code-blocks of the order (the long chains) go `lpw` to a wave, the rest `lpw_small` to a wave: the
     // kernel is bound by vector issue slots, diverged lanes share most of their instructions (4 lanes: 1.8x fewer wave
     // instructions than 2), but a wave lasts as long as its lanes together - affordable only for short code-blocks
@@ -1257,7 +1274,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lanes * 8u,
                    V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
     for (int r = 0; r < kDecStateRows; r++) st.at(r) = 0ull;
-    t1::decode_block(st, DecSrcAhead(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab);
+    t1::decode_block(st, DecSrcAhead(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab, ctxp);
 }
 
 
@@ -1396,26 +1413,33 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
                                                    const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs,
                                                    const int *active, int total, int lpw)
 {
+    extern __shared__ unsigned long long dec_state[];                  // [kDecStateRows][lpw]: the state row masks of this wave's code-blocks
+    __shared__ __attribute__((aligned(16))) uint8_t ctx_store[LdsCtx::kBytes];
     EBCC_LDS_MQ_TABLE(tab);
-    if ((int) threadIdx.x >= lpw) return;                              // see t1_lanes_per_wave()
     const int gid0 = blockIdx.x * lpw;                                 // lpw divides 64: the wave stays inside one group
     const int gid = gid0 + threadIdx.x;
-    if (gid >= total) return;
     const int nb = geom->stride;
-    const int frame = gid / nb, bi = gid - frame * nb;
-    if ((active && !active[frame]) || fs[frame].const_field) return;
+    int plan = -1, frame = 0, bi = 0;
+    if ((int) threadIdx.x < lpw && gid < total) {                       // see t1_lanes_per_wave()
+        frame = gid / nb; bi = gid - frame * nb;
+        if (!((active && !active[frame]) || fs[frame].const_field)) plan = rpass[gid];
+    }
+    // most code-blocks keep their passes from one probe to the next: a workgroup (one wave) without a changed one leaves here
+    if (!__any(plan >= 0)) return;
+    copy_ctx_tables(ctx_store, g_ctx_tables, (int) threadIdx.x, 64);
+    __syncthreads();
+    if (plan < 0) return;
+    const LdsCtx ctxp{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) ctx_store, 0u};
     blocks = j2k_frame_blocks(geom, blocks, frame);
     geom = &j2k_frame_geom(geom, frame);
-    const int plan = rpass[gid];
-    if (plan < 0) return;
     const int r = plan & 0xFF, stripe = plan >> 8;
     const int np = npass[gid], P = numbps[gid];
     const int len = rates[(size_t) gid * kJ2kMaxPasses + np - 1];
     const J2kBlock blk = blocks[bi];
     const size_t grp = (size_t) (gid0 >> 6);
     const int gl = (gid0 & 63) + threadIdx.x;
-    DecStore st{(unsigned char *) (T1S + grp * kT1StateWords * 64), (uint32_t) gl * 8u,
-                V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
+    DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lpw * 8u,
+                   V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
     // Decoder state when pass r reaches the restart stripe: rows above it are as at the start of pass r + 1,
     // the rest as at the start of pass r.  Only the rows the remaining stripes can
     // see are needed when no further pass follows, but all 64 are cheap next to the decode.
@@ -1447,7 +1471,7 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     const t1::Contexts cxp = t1::Contexts::from_bytes(cxb);
     const t1::MqCheckpoint ck{r0.x & 0xFFFFu, r1.w, (int) (r0.x >> 16), (int) r0.y, cxp.w0, cxp.w1, cxp.w2};
     t1::decode_resume(st, DecSrc{cblk_bytes + (size_t) gid * kJ2kCblkBytes, len}, blk.w, blk.h, geom->bands[blk.band].orient, P,
-                      np, r, stripe, ck, tab);
+                      np, r, stripe, ck, tab, ctxp);
 }
 
 // LDS carve-up of the rate / write kernels for the largest tile position of the context
@@ -1544,7 +1568,8 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
                        jb.d_geom, jb.d_blocks, jb.fs, d_active);
     timing_begin("t1_probe_decode", s);
     const int lpw = t1_lanes_per_wave(T1_RESUME);
-    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) ceil_div(total, lpw)), dim3(64), 0, s, jb.T1S, jb.BP, jb.SUF, jb.SGN, jb.SPS,
+    ensure_ctx_tables();
+    hipLaunchKernelGGL(k_t1_resume, dim3((unsigned) ceil_div(total, lpw)), dim3(64), (size_t) kDecStateRows * lpw * 8, s, jb.T1S, jb.BP, jb.SUF, jb.SGN, jb.SPS,
                        jb.VISP, jb.cblk_bytes, jb.numbps, jb.npass, jb.rates, jb.qplane, ck, jb.V, jb.d_geom, jb.d_blocks, jb.fs,
                        d_active, total, lpw);
     timing_end("t1_probe_decode", s);
@@ -1616,6 +1641,7 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
         if (lpw_small < lpw) lpw_small = lpw;
         const int n_big = lpw_small == lpw ? total : std::min(total, ceil_div(ceil_div(total, den), lpw) * lpw);
         const unsigned waves = (unsigned) (ceil_div(n_big, lpw) + ceil_div(total - n_big, lpw_small));
+        ensure_ctx_tables();
         hipLaunchKernelGGL(k_t1_decode_lds, dim3(waves), dim3(64), (size_t) kDecStateRows * std::max(lpw, lpw_small) * 8, s, jb.stream,
                            jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw, n_big, lpw_small);
     }

@@ -388,6 +388,31 @@ T1_HD int ctx_sc(uint32_t sup, uint32_t smid, uint32_t sdn, uint32_t nup, uint32
     return CTX_SC0 + n;
 }
 
+// The serial passes form a column's contexts from WINDOWS: the 3-bit windows {x-1, x, x+1} of the six significance rows
+// around the stripe in one word, row r in bits 3r .. 3r+2 (Passes::windows).  The zero-coding context of stripe row R is a
+// function of the nine bits from 3R on - rows R (above), R+1 (own), R+2 (below) - and the sign context of eight bits
+// picked from the significance and the sign windows:
+//   bit 0 above significant, 1 above negative, 2 left significant, 3 left negative, 4 right significant, 5 right negative,
+//   6 below significant, 7 below negative.
+// A context policy turns the index into the context: DirectCtx evaluates tables D-1 .. D-3 (host builds), the device
+// kernels read a 512-byte table per orientation and a 256-byte sign table from LDS (t1_device.hpp: LdsCtx) - what was
+// ~25 + ~30 vector instructions per decision.
+T1_HD uint32_t sc_index(uint32_t si, uint32_t ni)                        // si / ni: nine window bits of significance / sign
+{
+    return (((si >> 1) & 0x41u) | (((ni >> 1) & 0x41u) << 1)) | ((((si >> 3) & 5u) | (((ni >> 3) & 5u) << 1)) << 2);
+}
+struct DirectCtx {
+    int orient = 0;
+    T1_HD void bind(int o) { orient = o; }
+    T1_HD int zc(uint32_t idx) const { return ctx_zc(idx & 7u, (idx >> 3) & 7u, (idx >> 6) & 7u, orient); }
+    T1_HD int sc(uint32_t idx, int &xb) const
+    {
+        const uint32_t sup = (idx & 1u) << 1, nup = ((idx >> 1) & 1u) << 1, sdn = ((idx >> 6) & 1u) << 1, ndn = ((idx >> 7) & 1u) << 1;
+        const uint32_t smid = ((idx >> 2) & 1u) | (((idx >> 4) & 1u) << 2), nmid = ((idx >> 3) & 1u) | (((idx >> 5) & 1u) << 2);
+        return ctx_sc(sup, smid, sdn, nup, nmid, ndn, xb);
+    }
+};
+
 // renormalisation shift count of the interval register: a in [1, 0x7FFF] -> shifts until bit 15 is set
 T1_HD int renorm_shifts(uint32_t a)
 {
@@ -433,14 +458,25 @@ struct Stripe {
     u64 sps[4];      // encoder: became significant in a propagation pass (accumulated, stored with the stripe)
 };
 
-template <bool ENC, class Store, class Coder, class Obs = NoObserver>
+template <bool ENC, class Store, class Coder, class Obs = NoObserver, class CtxP = DirectCtx>
 struct Passes {
     Store &st;
     Coder &mq;
     int w, h, orient;
     Obs *obs;
+    CtxP cp;
 
-    T1_HD Passes(Store &s, Coder &c, int w_, int h_, int o, Obs *ob = nullptr) : st(s), mq(c), w(w_), h(h_), orient(o), obs(ob) {}
+    T1_HD Passes(Store &s, Coder &c, int w_, int h_, int o, Obs *ob = nullptr, CtxP cp_ = CtxP()) : st(s), mq(c), w(w_), h(h_), orient(o), obs(ob), cp(cp_) { cp.bind(o); }
+    // the windows of six row masks at column x (see DirectCtx)
+    T1_HD static uint32_t windows(const u64 *m, int x)
+    {
+        // (one 64-bit shift per row by x - 1; column 0 has no left neighbour: every field moves up by one bit instead)
+        const int sh = x > 0 ? x - 1 : 0;
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) v |= ((uint32_t) (m[r] >> sh) & 7u) << (3 * r);
+        return x > 0 ? v : (v << 1) & 0x36DB6u;
+    }
     T1_HD void stripe_hook(int y0)
     {
         if constexpr (!std::is_same<Obs, NoObserver>::value) obs->stripe_start(y0, mq);   // (may write to the coder: stream markers)
@@ -474,12 +510,14 @@ struct Passes {
     }
 
     // sign coding of (x, row r) and state update; returns nothing.  R is a compile-time row.
+    // sw / nw: the column's significance / sign windows (nw is taken from the masks when the first sign of the column is
+    // coded: have_n); both are kept up to date for the rows below
     template <int R>
-    T1_HD void code_sign(Stripe &sp, int x, int y0, int plane, bool from_sigprop)
+    T1_HD void code_sign(Stripe &sp, uint32_t &sw, uint32_t &nw, bool &have_n, int x, int y0, int plane, bool from_sigprop)
     {
+        if (!have_n) { nw = windows(sp.neg, x); have_n = true; }
         int xb;
-        int cx = ctx_sc(tri(sp.s[R], x), tri(sp.s[R + 1], x), tri(sp.s[R + 2], x), tri(sp.neg[R], x), tri(sp.neg[R + 1], x),
-                        tri(sp.neg[R + 2], x), xb);
+        int cx = cp.sc(sc_index((sw >> (3 * R)) & 0x1FFu, (nw >> (3 * R)) & 0x1FFu), xb);
         int neg;
         if constexpr (ENC) {
             neg = (int) ((sp.sgn[R] >> x) & 1);
@@ -488,25 +526,24 @@ struct Passes {
             neg = mq.decode_sc(cx) ^ xb;
         }
         sp.s[R + 1] |= 1ull << x;
-        if (neg) sp.neg[R + 1] |= 1ull << x;
+        sw |= 0x10u << (3 * R);
+        if (neg) { sp.neg[R + 1] |= 1ull << x; nw |= 0x10u << (3 * R); }
         if constexpr (ENC) { if (from_sigprop) sp.sps[R] |= 1ull << x; }
         else st.set_sig(x, y0 + R, neg, plane);
     }
 
     // ---------------- significance propagation pass over one stripe
     template <int R>
-    T1_HD bool sigprop_cell(Stripe &sp, int x, int y0, int plane, u64 bp)
+    T1_HD bool sigprop_cell(Stripe &sp, uint32_t &sw, uint32_t &nw, bool &have_n, int x, int y0, int plane, u64 bp)
     {
-        const u64 bit = 1ull << x;
-        if (R >= sp.nrows || (sp.s[R + 1] & bit)) return false;      // (x comes from a width-masked column set)
-        uint32_t up = tri(sp.s[R], x), mid = tri(sp.s[R + 1], x), dn = tri(sp.s[R + 2], x);
-        if ((up | (mid & 5u) | dn) == 0) return false;
-        int cx = ctx_zc(up, mid, dn, orient);
+        const uint32_t idx = (sw >> (3 * R)) & 0x1FFu;                // (x comes from a width-masked column set)
+        if (R >= sp.nrows || (idx & 0x10u) || !(idx & 0x1EFu)) return false;   // outside, significant, or no significant neighbour
+        int cx = cp.zc(idx);
         int v;
         if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_zc(cx, v); }
         else v = mq.decode_zc(cx);
-        sp.vis[R] |= bit;
-        if (v) { code_sign<R>(sp, x, y0, plane, true); return true; }
+        sp.vis[R] |= 1ull << x;
+        if (v) { code_sign<R>(sp, sw, nw, have_n, x, y0, plane, true); return true; }
         return false;
     }
 
@@ -528,11 +565,12 @@ struct Passes {
                 T1_STAT(0);
                 int x = ctz64(pending);
                 pending &= pending - 1;
-                bool grew = false;
-                grew |= sigprop_cell<0>(sp, x, y0, plane, b0);
-                grew |= sigprop_cell<1>(sp, x, y0, plane, b1);
-                grew |= sigprop_cell<2>(sp, x, y0, plane, b2);
-                grew |= sigprop_cell<3>(sp, x, y0, plane, b3);
+                uint32_t sw = windows(sp.s, x), nw = 0;
+                bool have_n = false, grew = false;
+                grew |= sigprop_cell<0>(sp, sw, nw, have_n, x, y0, plane, b0);
+                grew |= sigprop_cell<1>(sp, sw, nw, have_n, x, y0, plane, b1);
+                grew |= sigprop_cell<2>(sp, sw, nw, have_n, x, y0, plane, b2);
+                grew |= sigprop_cell<3>(sp, sw, nw, have_n, x, y0, plane, b3);
                 if (grew && x + 1 < w) pending |= 1ull << (x + 1);       // a new neighbour to the right
             }
             store(sp, y0);
@@ -587,19 +625,20 @@ struct Passes {
 
     // ---------------- cleanup pass
     template <int R>
-    T1_HD void cleanup_cell(Stripe &sp, int x, int y0, int plane, u64 bp, bool skip_zc)
+    T1_HD void cleanup_cell(Stripe &sp, uint32_t &sw, uint32_t &nw, bool &have_n, int x, int y0, int plane, u64 bp, bool skip_zc)
     {
         const u64 bit = 1ull << x;
+        const uint32_t idx = (sw >> (3 * R)) & 0x1FFu;
         if (!skip_zc) {
-            if (R >= sp.nrows || (sp.s[R + 1] & bit) || (sp.vis[R] & bit)) return;
+            if (R >= sp.nrows || (idx & 0x10u) || (sp.vis[R] & bit)) return;
         }
         int v = 1;
         if (!skip_zc) {
-            int cx = ctx_zc(tri(sp.s[R], x), tri(sp.s[R + 1], x), tri(sp.s[R + 2], x), orient);
+            int cx = cp.zc(idx);
             if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_zc(cx, v); }
             else v = mq.decode_zc(cx);
         }
-        if (v) code_sign<R>(sp, x, y0, plane, false);
+        if (v) code_sign<R>(sp, sw, nw, have_n, x, y0, plane, false);
     }
 
     T1_HD void cleanup(int plane, int ystart = 0)
@@ -631,14 +670,10 @@ struct Passes {
                 int x = ctz64(pending);
                 pending &= pending - 1;
                 const u64 bit = 1ull << x;
+                uint32_t sw = windows(sp.s, x), nw = 0;
+                bool have_n = false;
                 // run-length mode: the whole column is insignificant, unvisited and has an all-zero neighbourhood
-                bool agg = false;
-                if (full && !((sp.vis[0] | sp.vis[1] | sp.vis[2] | sp.vis[3]) & bit)) {
-                    uint32_t any = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; r++) any |= tri(sp.s[r], x);
-                    agg = any == 0;
-                }
+                const bool agg = full && !((sp.vis[0] | sp.vis[1] | sp.vis[2] | sp.vis[3]) & bit) && sw == 0;
                 int start = 0;
                 if (agg) {
                     if constexpr (ENC) {
@@ -661,10 +696,10 @@ struct Passes {
                         start = (start << 1) | mq.decode_uni();
                     }
                 }
-                if (start <= 0) cleanup_cell<0>(sp, x, y0, plane, b0, agg && start == 0);
-                if (start <= 1) cleanup_cell<1>(sp, x, y0, plane, b1, agg && start == 1);
-                if (start <= 2) cleanup_cell<2>(sp, x, y0, plane, b2, agg && start == 2);
-                if (start <= 3) cleanup_cell<3>(sp, x, y0, plane, b3, agg && start == 3);
+                if (start <= 0) cleanup_cell<0>(sp, sw, nw, have_n, x, y0, plane, b0, agg && start == 0);
+                if (start <= 1) cleanup_cell<1>(sp, sw, nw, have_n, x, y0, plane, b1, agg && start == 1);
+                if (start <= 2) cleanup_cell<2>(sp, sw, nw, have_n, x, y0, plane, b2, agg && start == 2);
+                if (start <= 3) cleanup_cell<3>(sp, sw, nw, have_n, x, y0, plane, b3, agg && start == 3);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) sp.vis[r] = 0;                   // the visited flags die with the plane
@@ -1651,13 +1686,13 @@ T1_HD int first_pass_of_plane(int P, int bp) { return bp == P - 1 ? 0 : 3 * (P -
 T1_HD int plane_of_pass(int P, int i) { return i == 0 ? P - 1 : P - 2 - (i - 1) / 3; }
 T1_HD int type_of_pass(int i) { return i == 0 ? 2 : (i - 1) % 3; }          // 0 propagation, 1 refinement, 2 cleanup
 
-template <class Store, class Source, class Observer, class Table = ConstTable>
+template <class Store, class Source, class Observer, class Table = ConstTable, class CtxP = DirectCtx>
 T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Observer &obs,
-                                 Table tab = Table())
+                                 Table tab = Table(), CtxP cp = CtxP())
 {
     MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
     mq.init();
-    Passes<false, Store, MqDecoder<Source, Table>, Observer> ps(st, mq, w, h, orient, &obs);
+    Passes<false, Store, MqDecoder<Source, Table>, Observer, CtxP> ps(st, mq, w, h, orient, &obs, cp);
     int passtype = 2, bp = numbps - 1;
     for (int p = 0; p < npasses && bp >= 0; p++) {
         obs.pass_start(p, mq);
@@ -1668,25 +1703,25 @@ T1_HD void decode_block_observed(Store &st, Source src, int w, int h, int orient
     }
 }
 
-template <class Store, class Source, class Table = ConstTable>
-T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Table tab = Table())
+template <class Store, class Source, class Table = ConstTable, class CtxP = DirectCtx>
+T1_HD void decode_block(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, Table tab = Table(), CtxP cp = CtxP())
 {
     NoObserver obs;
-    decode_block_observed(st, src, w, h, orient, numbps, npasses, obs, tab);
+    decode_block_observed(st, src, w, h, orient, numbps, npasses, obs, tab, cp);
 }
 
 // Decode passes [r, npasses) only.  The caller has put the store into the state the decoder has at the start
 // of pass r (S/NEG/VIS/REF masks and the values of everything already significant); `ck` holds the MQ
 // registers there (ignored for r == 0, where decoding starts afresh).  Valid whenever the checkpoint was taken
 // with no byte at or beyond the (truncated) segment length consumed: ck.pos + 1 < length of src.
-template <class Store, class Source, class Table = ConstTable>
+template <class Store, class Source, class Table = ConstTable, class CtxP = DirectCtx>
 T1_HD void decode_resume(Store &st, Source src, int w, int h, int orient, int numbps, int npasses, int r, int stripe,
-                         const MqCheckpoint &ck, Table tab = Table())
+                         const MqCheckpoint &ck, Table tab = Table(), CtxP cp = CtxP())
 {
     MqDecoder<Source, Table> mq{0, 0, 0, 0, {0, 0, 0}, src, tab};
     if (r == 0 && stripe == 0) mq.init();
     else { mq.a = ck.a; mq.c = ck.c; mq.ct = ck.ct; mq.pos = ck.pos; mq.cx.w0 = ck.w0; mq.cx.w1 = ck.w1; mq.cx.w2 = ck.w2; }
-    Passes<false, Store, MqDecoder<Source, Table>> ps(st, mq, w, h, orient);
+    Passes<false, Store, MqDecoder<Source, Table>, NoObserver, CtxP> ps(st, mq, w, h, orient, nullptr, cp);
     int bp = plane_of_pass(numbps, r), passtype = type_of_pass(r);
     int ystart = 4 * stripe;                                             // only the first pass starts mid-way
     for (int p = r; p < npasses && bp >= 0; p++) {

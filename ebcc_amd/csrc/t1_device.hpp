@@ -39,4 +39,40 @@ __device__ inline void fill_mq_table_next(uint2 *tab_store)
     for (int i = (int) threadIdx.x; i < 128; i += (int) blockDim.x) { uint32_t nxt, nqes; t1::mq_entry_next(t1::mq_code((uint32_t) i), nxt, nqes); tab_store[i] = make_uint2(nxt, nqes); }
 }
 
+// Context tables of the serial tier-1 passes in LDS (t1_core.hpp: DirectCtx): 512 bytes per orientation class (orientation 0
+// and 2 share one) indexed by the nine window bits, 256 bytes of sign contexts (context | xor bit << 7) indexed by sc_index.
+struct LdsCtx {
+    static constexpr int kBytes = 3 * 512 + 256;
+    uint32_t base = 0, zc_tab = 0;                 // LDS byte addresses
+    __device__ void bind(int orient) { zc_tab = base + 512u * (orient == 1 ? 1u : (orient == 3 ? 2u : 0u)); }
+    __device__ int zc(uint32_t idx) const { return (int) *(const __attribute__((address_space(3))) uint8_t *) (uintptr_t) (zc_tab + idx); }
+    __device__ int sc(uint32_t idx, int &xb) const
+    {
+        const uint32_t v = *(const __attribute__((address_space(3))) uint8_t *) (uintptr_t) (base + 1536u + idx);
+        xb = (int) (v >> 7);
+        return (int) (v & 0x7Fu);
+    }
+};
+// the tables, by evaluating DirectCtx (one definition of the contexts): worked out on the host once per device and kept in
+// device memory; a workgroup copies them to LDS with a few 16-byte loads
+inline void make_ctx_tables(uint8_t *store)
+{
+    for (int i = 0; i < 1536; i++) {
+        t1::DirectCtx d;
+        d.bind(i < 512 ? 0 : (i < 1024 ? 1 : 3));
+        store[i] = (uint8_t) d.zc((uint32_t) i & 511u);
+    }
+    for (int i = 0; i < 256; i++) {
+        t1::DirectCtx d;
+        int xb = 0;
+        const int c = d.sc((uint32_t) i, xb);
+        store[1536 + i] = (uint8_t) (c | (xb << 7));
+    }
+}
+__device__ inline void copy_ctx_tables(uint8_t *lds, const uint8_t *global, int tid, int nthreads)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < LdsCtx::kBytes / 16; i += nthreads) ((u32x4 *) lds)[i] = ((const u32x4 *) global)[i];
+}
+
 }  // namespace ebcc

@@ -362,8 +362,14 @@ static int has_sig_neighbour(const t1_t *t, int x, int y)
 /* ---------------------------------------------------------------- T1 decoder (D.3), OpenJPEG value convention:
  * data carries one fractional bit; a coefficient found significant in plane p becomes 1.5*2^p and each
  * refinement moves it by +-2^(p-1) (mid-point reconstruction). */
+/* study hook (tools/t1_decode_stats.cpp): every code-block segment the decoder is handed, before it is decoded */
+static void (*g_dec_sink)(const uint8_t *data, int len, int numbps, int npasses, int w, int h, int orient, void *user) = NULL;
+static void *g_dec_sink_user = NULL;
+void orc_j2k_set_decode_sink(void (*fn)(const uint8_t *, int, int, int, int, int, int, void *), void *user) { g_dec_sink = fn; g_dec_sink_user = user; }
+
 static void t1_decode_cblk(t1_t *t, const cblk_t *cb, int orient)
 {
+    if (g_dec_sink) g_dec_sink(cb->data, cb->len, cb->numbps, cb->npasses, t->w, t->h, orient, g_dec_sink_user);
     mq_t mq;
     mqd_init(&mq, cb->data, cb->len);
     int bp = cb->numbps - 1, passtype = 2;

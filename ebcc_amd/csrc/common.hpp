@@ -111,6 +111,21 @@ __device__ inline float lane_above(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in eight DPP additions (row_shr 1/2/3, row_shr:4 / :8 on the upper banks,
+// row_bcast:15 / :31 into the rows above - GFX9 family) - no trip through the LDS crossbar, which a wave pays with ~100
+// cycles per shuffle and more when other waves keep the LDS busy.  Every lane must be active.
+__device__ inline uint32_t wave_prefix_sum(uint32_t x)
+{
+    const int xi = (int) x;
+    int v = xi + __builtin_amdgcn_update_dpp(0, xi, 0x111, 0xF, 0xF, false) + __builtin_amdgcn_update_dpp(0, xi, 0x112, 0xF, 0xF, false) +
+            __builtin_amdgcn_update_dpp(0, xi, 0x113, 0xF, 0xF, false);                    // lanes i-3 .. i of the row of 16
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xE, false);                         // + the four before (banks 1-3)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xC, false);                         // + the eight before (banks 2, 3)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);                         // rows 1, 3: + the row below's total
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);                         // rows 2, 3: + the total of rows 0, 1
+    return (uint32_t) v;
+}
+
 // Monotone key for float ordering with -0 == +0 (reference compares with < and >, so the two
 // zeros tie; ties are then broken by index to reproduce "first occurrence wins").
 __host__ __device__ inline uint32_t float_order_key(float f)

@@ -656,12 +656,13 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 const unsigned long long X = stream64(kHeaderBits + cnt);                // first bit in bit 63
                 // what a type-A entry starting at bit `lane` would take (every lane works its own position out: 1 bit, or the
                 // set bit and four children of 1 or 2 bits); the scalar walk then only adds lengths up
+                const uint32_t Wl = (uint32_t) ((X << lane) >> 32);                // the 32 stream bits from this lane's position on, first in bit 31
                 int len_a = 1;
-                if (lane < 55 && ((X >> (63 - lane)) & 1ull)) {
-                    int q = lane + 1;
+                if (lane < 55 && (Wl >> 31)) {
+                    int q = 1;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) q += 1 + (int) ((X >> (63 - q)) & 1ull);
-                    len_a = q - lane;
+                    for (int k = 0; k < 4; k++) q += 1 + (int) ((Wl >> (31 - q)) & 1u);
+                    len_a = q;
                 }
                 unsigned long long starts = 0, types = typemask;
                 int rel = 0, n_ent = 0;
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 const int isB = (int) (e & 1u);
                 const unsigned long long later = lane < 63 ? starts >> (lane + 1) : 0ull;
                 const int mylen = valid ? (later ? __builtin_ctzll(later) + 1 : rel - lane) : 0;
-                const unsigned int mybits = mylen ? (unsigned int) ((X << lane) >> (64 - mylen)) : 0u;   // MSB-first, mylen <= 9
+                const unsigned int mybits = mylen ? Wl >> (32 - mylen) : 0u;           // MSB-first, mylen <= 9
                 const unsigned long long k = cnt + (unsigned long long) lane;          // bits consumed before this entry
                 bool setbit = valid && mylen > 0 && ((mybits >> (mylen - 1)) & 1u);
                 bool act = valid && (k + 1 <= B);                                      // :358 / :394
@@ -725,26 +726,16 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                         else surv = 1;
                     }
                 }
-                // wave exclusive scans of the four counters
-                unsigned int pk = (unsigned int) n_lsp | ((unsigned int) n_lip << 8) | ((unsigned int) n_app << 16) |
-                                  ((unsigned int) surv << 24);
-                // counters per lane <= 4, wave totals <= 256: use 64-bit packing to avoid carries
-                unsigned long long pack = (unsigned long long) n_lsp | ((unsigned long long) n_lip << 16) |
-                                          ((unsigned long long) n_app << 32) | ((unsigned long long) surv << 48);
-                (void) pk;
-                unsigned long long x = pack;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    unsigned long long yv = shfl_up_u64(x, d);
-                    if (lane >= d) x += yv;
-                }
-                unsigned long long tot = ((unsigned long long) __shfl((unsigned int) (x >> 32), 63) << 32) |
-                                         __shfl((unsigned int) x, 63);
-                unsigned long long ex = x - pack;
-                unsigned int r_lsp = nlsp + (unsigned int) (ex & 0xFFFF);
-                unsigned int r_lip = nlip + (unsigned int) ((ex >> 16) & 0xFFFF);
-                unsigned int r_app = ncur + (unsigned int) ((ex >> 32) & 0xFFFF);
-                unsigned int r_surv = nnext + (unsigned int) ((ex >> 48) & 0xFFFF);
+                // wave exclusive scans of the four counters: three of them (at most 4 per lane, 256 per wave) packed into one word
+                // and summed by DPP, the survivors (0 / 1) by a ballot
+                const uint32_t pack = (uint32_t) n_lsp | ((uint32_t) n_lip << 10) | ((uint32_t) n_app << 20);
+                const uint32_t inc = wave_prefix_sum(pack), ex = inc - pack;
+                const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+                const unsigned long long msurv = __ballot(surv != 0);
+                unsigned int r_lsp = nlsp + (ex & 0x3FFu);
+                unsigned int r_lip = nlip + ((ex >> 10) & 0x3FFu);
+                unsigned int r_app = ncur + ((ex >> 20) & 0x3FFu);
+                unsigned int r_surv = nnext + (unsigned int) __popcll(msurv & lanemask_lt);
                 if (act) {
                     if (!isB && ch >= 0) {
                         for (int c = 0; c < 4; c++) {
@@ -766,10 +757,10 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                     }
                     if (surv) nxt[r_surv] = e;
                 }
-                nlsp += (unsigned int) (tot & 0xFFFF);
-                nlip += (unsigned int) ((tot >> 16) & 0xFFFF);
-                ncur += (unsigned int) ((tot >> 32) & 0xFFFF);
-                nnext += (unsigned int) ((tot >> 48) & 0xFFFF);
+                nlsp += tot & 0x3FFu;
+                nlip += (tot >> 10) & 0x3FFu;
+                ncur += (tot >> 20) & 0x3FFu;
+                nnext += (unsigned int) __popcll(msurv);
                 cnt += (unsigned long long) rel;
                 base += (unsigned int) n_ent;
                 lw.advance(base, lane);

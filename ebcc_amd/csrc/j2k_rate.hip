@@ -1211,6 +1211,7 @@ struct DecSrcAhead {
 // length classes, k_dec_hist / k_dec_offsets / k_dec_place) and the waves take them in that order: the long chains start
 // at once, the short ones fill in behind them, and the lanes of a wave hold blocks of similar length.
 constexpr int kDecClasses = 64;
+constexpr int kDecTierDen0 = 0, kDecTierDen1 = 32, kDecTierDen2 = 1;     // tiers of k_t1_decode_lds (launch_j2k_decode): the longest 1/32 at 2 lanes, the rest at 4
 __device__ inline int dec_class(const int *e) { return e[3] <= 0 || e[2] <= 0 ? 0 : min(kDecClasses - 1, 1 + (e[1] >> 6)); }
 __global__ __launch_bounds__(256) void k_dec_hist(const int *dec_table, int *counters, int total)
 {
@@ -1243,23 +1244,32 @@ __global__ __launch_bounds__(256) void k_dec_place(const int *dec_table, int *co
     if (gid < total) order[base[cls] + rank] = gid;
 }
 
+// Lanes per wave by rank in the order: the first n[0] code-blocks (the longest chains) go lanes[0] to a wave, the next n[1]
+// lanes[1] to a wave, the next n[2] lanes[2], the rest lanes[3] (every n[i] a multiple of lanes[i]).
+struct DecTiers { int n[3]; int lanes[4]; };
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_t1_decode_lds(const uint8_t *bytes, size_t stream_cap, const int *dec_table, const int *order, int32_t *V,
-                                                       const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total, int lpw, int n_big, int lpw_small)
+                                                       const J2kGeom *geom, const J2kBlock *blocks, const FrameState *fs, int total, DecTiers tiers)
 {
     extern __shared__ unsigned long long dec_state[];                  // [kDecStateRows][lanes of this wave]
     __shared__ __attribute__((aligned(16))) uint8_t ctx_store[LdsCtx::kBytes];
     copy_ctx_tables(ctx_store, g_ctx_tables, (int) threadIdx.x, 64);   // (EBCC_LDS_MQ_TABLE synchronises)
     EBCC_LDS_MQ_TABLE(tab);
     const LdsCtx ctxp{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) ctx_store, 0u};
-    // the first n_big code-blocks of the order (the long chains) go `lpw` to a wave, the rest `lpw_small` to a wave: the
-    // kernel is bound by vector issue slots, diverged lanes share most of their instructions (4 lanes: 1.8x fewer wave
-    // instructions than 2), but a wave lasts as long as its lanes together - affordable only for short code-blocks
-    const int big_waves = (n_big + lpw - 1) / lpw;
-    const bool small = (int) blockIdx.x >= big_waves;
-    const int lanes = small ? lpw_small : lpw;
+    // the kernel is bound by vector issue slots, diverged lanes share most of their instructions (4 lanes: 1.8x fewer wave
+    // instructions than 2), but a wave lasts as long as its lanes together: the longer a code-block's segment, the fewer
+    // lanes its wave has (tiers by rank in the longest-first order), so that every wave carries about the same work
+    int w = (int) blockIdx.x, slot0 = 0, lanes = tiers.lanes[3], end = total;
+    {
+        int t = 0;
+        for (; t < 3; t++) {
+            const int waves = tiers.n[t] / tiers.lanes[t];
+            if (w < waves) { lanes = tiers.lanes[t]; end = slot0 + tiers.n[t]; break; }
+            w -= waves; slot0 += tiers.n[t];
+        }
+    }
     if ((int) threadIdx.x >= lanes) return;                            // see t1_lanes_per_wave()
-    const int slot = small ? n_big + ((int) blockIdx.x - big_waves) * lpw_small + (int) threadIdx.x : (int) blockIdx.x * lpw + (int) threadIdx.x;
-    if (slot >= total || (!small && slot >= n_big)) return;
+    const int slot = slot0 + w * lanes + (int) threadIdx.x;
+    if (slot >= end || slot >= total) return;
     const int gid = order[slot];
     const int nb = geom->stride;
     const int frame = gid / nb, bi = gid - frame * nb;
@@ -1634,16 +1644,38 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
         hipLaunchKernelGGL(k_dec_hist, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, total);
         hipLaunchKernelGGL(k_dec_offsets, dim3(1), dim3(kDecClasses), 0, s, counters);
         hipLaunchKernelGGL(k_dec_place, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.dec_table, counters, jb.dec_order, total);
-        // the longest 1/32 of the code-blocks at `lpw` lanes per wave, the rest at 4 (256 frames: 27.3 ms all at 2 lanes,
-        // 23.5 ms with this mix, 34 ms with 1/16 and 8 lanes - measured in round 2)
-        const int den = 32;
-        int lpw_small = few_blocks ? 1 : 4;
-        if (lpw_small < lpw) lpw_small = lpw;
-        const int n_big = lpw_small == lpw ? total : std::min(total, ceil_div(ceil_div(total, den), lpw) * lpw);
-        const unsigned waves = (unsigned) (ceil_div(n_big, lpw) + ceil_div(total - n_big, lpw_small));
+        // Tiers by rank (EBCC_T1_DEC_TIERS = "d0,d1,d2[,L]": the first total/d0 code-blocks of the order at 1 lane per wave, up
+        // to total/d1 at 2, up to total/d2 at 4, the rest at L = 4, 8 or 16; EBCC_T1_LPW = one number of lanes for all).
+        // Measured on 256 frames of configs[1] (round 3): 1/32 at 2 lanes and the rest at 4: 18.5 ms; all at 4: 18.5; a tier
+        // of single lanes for the longest 1/256 or 1/512: 18.5 (the launch is bound by vector issue, not by its longest
+        // chain); an 8-lane tier for the shortest 2/3: 31.6 - and 29.7 with no wave using it: what costs is the LDS a
+        // workgroup reserves (the state rows of its widest tier: 16.5 KB instead of 8), i.e. how many waves a CU holds.
+        DecTiers tiers{{0, 0, 0}, {1, 2, 4, 4}};
+        if (few_blocks) { tiers.lanes[3] = 1; }
+        else if (getenv("EBCC_T1_LPW")) { tiers.lanes[3] = lpw; }
+        else {
+            int den[3] = {kDecTierDen0, kDecTierDen1, kDecTierDen2};
+            if (const char *e = getenv("EBCC_T1_DEC_TIERS")) {
+                int v[4];
+                const int got = sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+                if (got >= 3) for (int i = 0; i < 3; i++) den[i] = v[i];
+                if (got == 4 && (v[3] == 4 || v[3] == 8 || v[3] == 16)) tiers.lanes[3] = v[3];      // (lanes of the last tier)
+            }
+            int before = 0;
+            for (int t = 0; t < 3; t++) {
+                const int upto = den[t] > 0 ? total / den[t] : 0;                  // (den 0: no such tier)
+                const int n = std::max(0, upto - before) / tiers.lanes[t] * tiers.lanes[t];
+                tiers.n[t] = n; before += n;
+            }
+        }
+        unsigned waves = 0;
+        int rest = total;
+        for (int t = 0; t < 3; t++) { waves += (unsigned) (tiers.n[t] / tiers.lanes[t]); rest -= tiers.n[t]; }
+        waves += (unsigned) ceil_div(rest, tiers.lanes[3]);
+        const int max_lanes = std::max(std::max(tiers.n[0] ? tiers.lanes[0] : 1, tiers.n[1] ? tiers.lanes[1] : 1), std::max(tiers.n[2] ? tiers.lanes[2] : 1, rest > 0 ? tiers.lanes[3] : 1));
         ensure_ctx_tables();
-        hipLaunchKernelGGL(k_t1_decode_lds, dim3(waves), dim3(64), (size_t) kDecStateRows * std::max(lpw, lpw_small) * 8, s, jb.stream,
-                           jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, lpw, n_big, lpw_small);
+        hipLaunchKernelGGL(k_t1_decode_lds, dim3(waves), dim3(64), (size_t) kDecStateRows * max_lanes * 8, s, jb.stream,
+                           jb.stream_cap, jb.dec_table, jb.dec_order, jb.V, jb.d_geom, jb.d_blocks, jb.fs, total, tiers);
     }
     timing_end("t1_decode", s);
     decode_tail(nullptr, jb, n_frames, nullptr, false, s);

@@ -66,6 +66,28 @@ __device__ inline int first_child_of(const Grid &g, int p)
     return first_child(g, x, y);
 }
 
+// The decoder keeps grid positions in its lists as packed coordinates, x | y << 12 (the extents are 12-bit header fields):
+// the first child of a position and the four children's positions are a few integer operations, where the linear index
+// p = x + y * nx costs a division by the run-time nx for every significant set.
+constexpr int kPkShift = 12;
+constexpr uint32_t kPkMask = (1u << kPkShift) - 1u;
+__device__ inline uint32_t pk_of(int x, int y) { return (uint32_t) x | ((uint32_t) y << kPkShift); }
+__device__ inline uint32_t pk_index(uint32_t pk, int nx) { return (pk >> kPkShift) * (uint32_t) nx + (pk & kPkMask); }
+__device__ inline uint32_t first_child_pk(const Grid &g, uint32_t pk)      // ~0u: no children (first_child)
+{
+    const int x = (int) (pk & kPkMask), y = (int) (pk >> kPkShift);
+    int cx, cy;
+    if (x < g.lx && y < g.ly) {
+        cx = (x & 1) ? x + g.lx - 1 : x;
+        cy = (y & 1) ? y + g.ly - 1 : y;
+        if (cx == x && cy == y) return ~0u;
+    } else {
+        cx = 2 * x; cy = 2 * y;
+        if (cx >= g.nx || cy >= g.ny) return ~0u;
+    }
+    return pk_of(cx, cy);
+}
+
 __device__ inline unsigned long long shfl_up_u64(unsigned long long v, int d)
 {
     unsigned int lo = __shfl_up((unsigned int) v, d), hi = __shfl_up((unsigned int) (v >> 32), d);
@@ -477,7 +499,7 @@ __device__ inline unsigned int read_bits_uniform(const uint8_t *s, unsigned long
 }
 
 // EBCC_HIP_SPIHT_PROF=1: cycles and list entries of the three passes, summed over the frames of a launch
-__device__ unsigned long long g_spiht_prof[10];
+__device__ unsigned long long g_spiht_prof[12];
 
 __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restrict__ streams, size_t stream_stride,
                                                         const unsigned long long *sizes,
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
             int i = base + lane;
             bool valid = i < nll;
             int y = valid ? i / g.lx : 0, x = valid ? i - y * g.lx : 0;
-            unsigned int p = (unsigned int) (x + y * g.nx);
+            unsigned int p = pk_of(x, y);
             bool isset = valid && ((x & 1) || (y & 1));
             unsigned long long m = __ballot(isset);
             if (valid) lip[i] = p;
@@ -554,18 +576,20 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
         const unsigned long long hi = ((unsigned long long) w0 << 32) | w1, lo = (unsigned long long) w2 << 32;
         return sh ? (hi << sh) | (lo >> (64 - sh)) : hi;
     };
-    // A list is read through two registers per lane holding 128 consecutive entries (entry wb + l in w0 of lane l, entry
-    // wb + 64 + l in w1); the second is requested a chunk before it is needed.  `limit`: entries below it were visible
-    // when the registers were loaded.
+    // A list is read through three registers per lane holding 192 consecutive entries (entry wb + l in w0 of lane l, entry
+    // wb + 64 + l in w1, wb + 128 + l in w2); a chunk reads from the first two, the third is requested when the window moves on
+    // and used after the NEXT move, about two chunks later (with two registers the load asked for at the end of one chunk was
+    // wanted at the start of the next).  `limit`: entries below it were visible when the registers were loaded.
     struct ListWindow {
         const uint32_t *list;
         unsigned int wb, limit;
-        uint32_t w0, w1;
+        uint32_t w0, w1, w2;
         __device__ void reset(const uint32_t *l, unsigned int base, unsigned int n, int lane)
         {
             list = l; wb = base; limit = n;
             w0 = wb + lane < n ? list[wb + lane] : 0u;
             w1 = wb + kWave + lane < n ? list[wb + kWave + lane] : 0u;
+            w2 = wb + 2 * kWave + lane < n ? list[wb + 2 * kWave + lane] : 0u;
         }
         // entry base + i for the lane that asks for i (0 <= i < 64, base - wb <= 64); every lane takes part
         __device__ uint32_t get(unsigned int base, int i) const
@@ -574,11 +598,18 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
             const uint32_t a = __shfl(w0, idx & 63), b = __shfl(w1, idx & 63);
             return idx < kWave ? a : b;
         }
+        // bit 0 of the entries base .. base + 63 (the LIS entries' types; zero past the list's end), in scalar registers
+        __device__ unsigned long long types(unsigned int base) const
+        {
+            const unsigned long long t0 = __ballot(w0 & 1u), t1 = __ballot(w1 & 1u);
+            const int off = __builtin_amdgcn_readfirstlane((int) (base - wb));
+            return off == 0 ? t0 : (off >= kWave ? t1 : (t0 >> off) | (t1 << (kWave - off)));
+        }
         __device__ void advance(unsigned int base, int lane)
         {
             if (base - wb >= (unsigned int) kWave) {
-                w0 = w1; wb += kWave;
-                w1 = wb + kWave + lane < limit ? list[wb + kWave + lane] : 0u;
+                w0 = w1; w1 = w2; wb += kWave;
+                w2 = wb + 2 * kWave + lane < limit ? list[wb + 2 * kWave + lane] : 0u;
             }
         }
     };
@@ -621,7 +652,7 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 const unsigned long long msig = __ballot(act && sig), mkeep = __ballot(valid && !(act && sig));
                 if (act && sig) {
                     lsp[nlsp + __popcll(msig & lanemask_lt)] = p;
-                    C[p] = neg ? -one : one;                                                       // :338
+                    C[pk_index(p, g.nx)] = neg ? -one : one;                                       // :338
                 } else if (valid) {
                     lip[wr + __popcll(mkeep & lanemask_lt)] = p;                                   // (at or below the entry's own slot)
                 }
@@ -651,79 +682,123 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
             while (base < ncur && !stop) {
                 const int m = (int) min((unsigned int) kWave, ncur - base);
                 if (base + (unsigned int) m > lw.limit) { __threadfence_block(); lw.reset(cur, base, ncur, lane); }
-                const unsigned int el = lw.get(base, lane);                              // list entry base + lane
-                const unsigned long long typemask = __ballot(lane < m && (el & 1u));
+                if (prof && lane == 0) atomicAdd(&g_spiht_prof[10], 1ull);
+                const unsigned long long typemask = lw.types(base);                      // types of the entries base .. base + 63
                 const unsigned long long X = stream64(kHeaderBits + cnt);                // first bit in bit 63
                 // what a type-A entry starting at bit `lane` would take (every lane works its own position out: 1 bit, or the
-                // set bit and four children of 1 or 2 bits); the scalar walk then only adds lengths up
+                // set bit and four children of 1 or 2 bits); the scalar walk then only adds lengths up.  The same steps give the
+                // children's significance and sign flags, used when the position turns out to be such an entry.
                 const uint32_t Wl = (uint32_t) ((X << lane) >> 32);                // the 32 stream bits from this lane's position on, first in bit 31
                 int len_a = 1;
+                unsigned int wsig = 0, wneg = 0;
                 if (lane < 55 && (Wl >> 31)) {
                     int q = 1;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) q += 1 + (int) ((Wl >> (31 - q)) & 1u);
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned int sb = (Wl >> (31 - q)) & 1u;
+                        wsig |= sb << k;
+                        wneg |= (sb & (Wl >> (30 - q))) << k;
+                        q += 1 + (int) sb;
+                    }
                     len_a = q;
                 }
-                unsigned long long starts = 0, types = typemask;
-                int rel = 0, n_ent = 0;
-                const int m_s = __builtin_amdgcn_readfirstlane(m);                  // (uniform anyway; this way the loop is scalar code)
-                while (n_ent < m_s && rel < 55) {
-                    starts |= 1ull << rel;
-                    const int la = __builtin_amdgcn_readlane(len_a, rel);
-                    rel += (types & 1ull) ? 1 : la;
-                    types >>= 1;
-                    n_ent++;
+                // The walk steps from set bit to set bit: an entry whose first bit is 0 takes that one bit whatever its type, so
+                // a run of z zero bits is z entries at once, and only an entry that starts on a set bit needs its type (the number
+                // of starts up to it is its place in the list) and the length its lane worked out: ~6 steps of ~20 scalar
+                // instructions per chunk where a step per entry took ~35 steps.  A set bit stands guard at position 55, where
+                // lanes hold length 1, so the loop needs no test for "no set bit left"; the list's end is cut afterwards.
+                constexpr unsigned long long kLow55 = (1ull << 55) - 1ull;
+                const unsigned long long Xr = (__builtin_bitreverse64(X) & kLow55) | (1ull << 55);   // bit x = stream bit cnt + x
+                unsigned long long starts = 0;
+                int rel = 0;
+                do {
+                    const int z = __builtin_ctzll(Xr >> rel);
+                    starts |= ((2ull << z) - 1ull) << rel;                          // z zero bits and the set bit after them
+                    const int pos = rel + z;
+                    const int la = __builtin_amdgcn_readlane(len_a, pos);
+                    rel = pos + (((typemask >> (__popcll(starts) - 1)) & 1ull) ? 1 : la);
+                } while (rel < 55);
+                rel -= (int) ((starts >> 55) & 1ull);                               // the guard is not an entry: 55 bits taken
+                starts &= kLow55;
+                int n_ent = __popcll(starts);
+                if (n_ent > m) {                                                    // the list ends inside the chunk
+                    const unsigned long long past = __ballot(((starts >> lane) & 1ull) && __popcll(starts & lanemask_lt) == m);
+                    rel = __builtin_ctzll(past);
+                    starts &= (1ull << rel) - 1ull;
+                    n_ent = m;
                 }
                 const bool valid = (starts >> lane) & 1ull;
                 const int idx = __popcll(starts & lanemask_lt);
                 const unsigned int e = lw.get(base, valid ? idx : 0);
-                const unsigned int p = e >> 1;
+                const unsigned int p = e >> 1;                                         // packed coordinates
                 const int isB = (int) (e & 1u);
-                const unsigned long long later = lane < 63 ? starts >> (lane + 1) : 0ull;
-                const int mylen = valid ? (later ? __builtin_ctzll(later) + 1 : rel - lane) : 0;
-                const unsigned int mybits = mylen ? Wl >> (32 - mylen) : 0u;           // MSB-first, mylen <= 9
                 const unsigned long long k = cnt + (unsigned long long) lane;          // bits consumed before this entry
-                bool setbit = valid && mylen > 0 && ((mybits >> (mylen - 1)) & 1u);
-                bool act = valid && (k + 1 <= B);                                      // :358 / :394
-                bool overrun = valid && !act;
                 int n_lsp = 0, n_lip = 0, n_app = 0, surv = 0;
-                int ch = -1;
+                uint32_t ch = ~0u;
                 unsigned int csig = 0, cneg = 0, cact = 0;                             // per-child flags
-                if (act) {
-                    if (!isB) {
-                        if (setbit) {
-                            ch = first_child_of(g, (int) p);
-                            int rem = mylen - 1;
-                            unsigned long long kk = k + 1;                              // bits consumed so far
-                            bool alive = true;
-                            for (int c = 0; c < 4; c++) {
-                                unsigned int sb = (mybits >> (rem - 1)) & 1u;
-                                kk += 1;
-                                if (alive && kk > B) { alive = false; overrun = true; }   // :367
-                                if (alive) {
-                                    cact |= 1u << c;
-                                    if (sb) {
-                                        csig |= 1u << c;
-                                        if ((mybits >> (rem - 2)) & 1u) cneg |= 1u << c;
-                                        n_lsp++;
-                                    } else {
-                                        n_lip++;
-                                    }
-                                }
-                                rem -= 1;
-                                if (sb) {
-                                    kk += 1;
-                                    rem -= 1;
-                                    if (alive && kk > B) { alive = false; overrun = true; } // :371 (value already assigned)
-                                }
+                bool act, overrun;
+                if (cnt + 64ull <= B) {
+                    // every bit of the chunk lies inside the budget (all chunks of a stream but its last one or two): none of the
+                    // budget tests of :358-:394 can fire, and what an entry on a set bit says is what its lane read ahead
+                    act = valid; overrun = false;
+                    if (valid) {
+                        if (Wl >> 31) {
+                            ch = first_child_pk(g, p);
+                            if (!isB) {
+                                csig = wsig; cneg = wneg; cact = 0xFu;
+                                n_lsp = __popc(csig); n_lip = 4 - n_lsp;
+                                // (a child of a set has children of its own iff its doubled coordinates are inside the grid: :273-278)
+                                n_app = (2 * (int) (ch & kPkMask) < g.nx && 2 * (int) (ch >> kPkShift) < g.ny) ? 1 : 0;
+                            } else {
+                                n_app = 4;
                             }
-                            if (alive && first_child_of(g, ch) >= 0) n_app = 1;
                         } else {
                             surv = 1;
                         }
-                    } else {
-                        if (setbit) { ch = first_child_of(g, (int) p); n_app = 4; }
-                        else surv = 1;
+                    }
+                } else {
+                    const unsigned long long later = lane < 63 ? starts >> (lane + 1) : 0ull;
+                    const int mylen = valid ? (later ? __builtin_ctzll(later) + 1 : rel - lane) : 0;
+                    const unsigned int mybits = mylen ? Wl >> (32 - mylen) : 0u;       // MSB-first, mylen <= 9
+                    const bool setbit = valid && mylen > 0 && ((mybits >> (mylen - 1)) & 1u);
+                    act = valid && (k + 1 <= B);                                       // :358 / :394
+                    overrun = valid && !act;
+                    if (act) {
+                        if (!isB) {
+                            if (setbit) {
+                                ch = first_child_pk(g, p);
+                                int rem = mylen - 1;
+                                unsigned long long kk = k + 1;                          // bits consumed so far
+                                bool alive = true;
+                                for (int c = 0; c < 4; c++) {
+                                    unsigned int sb = (mybits >> (rem - 1)) & 1u;
+                                    kk += 1;
+                                    if (alive && kk > B) { alive = false; overrun = true; }   // :367
+                                    if (alive) {
+                                        cact |= 1u << c;
+                                        if (sb) {
+                                            csig |= 1u << c;
+                                            if ((mybits >> (rem - 2)) & 1u) cneg |= 1u << c;
+                                            n_lsp++;
+                                        } else {
+                                            n_lip++;
+                                        }
+                                    }
+                                    rem -= 1;
+                                    if (sb) {
+                                        kk += 1;
+                                        rem -= 1;
+                                        if (alive && kk > B) { alive = false; overrun = true; } // :371 (value already assigned)
+                                    }
+                                }
+                                if (alive && ch != ~0u && first_child_pk(g, ch) != ~0u) n_app = 1;
+                            } else {
+                                surv = 1;
+                            }
+                        } else {
+                            if (setbit) { ch = first_child_pk(g, p); n_app = 4; }
+                            else surv = 1;
+                        }
                     }
                 }
                 // wave exclusive scans of the four counters: three of them (at most 4 per lane, 256 per wave) packed into one word
@@ -737,23 +812,24 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 unsigned int r_app = ncur + ((ex >> 20) & 0x3FFu);
                 unsigned int r_surv = nnext + (unsigned int) __popcll(msurv & lanemask_lt);
                 if (act) {
-                    if (!isB && ch >= 0) {
+                    if (!isB && ch != ~0u) {
+#pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            if (!((cact >> c) & 1u)) break;
-                            unsigned int q = (unsigned int) (ch + (c & 1) + (c >> 1) * g.nx);
-                            if ((csig >> c) & 1u) {
-                                lsp[r_lsp++] = q;
-                                C[q] = ((cneg >> c) & 1u) ? -one : one;                // :370
-                            } else {
-                                lip[r_lip++] = q;
+                            if ((cact >> c) & 1u) {                                    // (the flags of the children a budget cut off are clear)
+                                const unsigned int q = ch + (unsigned int) (c & 1) + ((unsigned int) (c >> 1) << kPkShift);
+                                const unsigned int sg = (csig >> c) & 1u;
+                                uint32_t *dst = sg ? lsp + r_lsp : lip + r_lip;        // (one store, not a branch per child)
+                                *dst = q;
+                                r_lsp += sg; r_lip += 1u - sg;
+                                if (sg) C[pk_index(q, g.nx)] = ((cneg >> c) & 1u) ? -one : one;   // :370
                             }
                         }
                         if (n_app) cur[r_app] = (p << 1) | 1u;
-                    } else if (isB && ch >= 0) {
-                        cur[r_app + 0] = (unsigned int) ch << 1;
-                        cur[r_app + 1] = (unsigned int) (ch + 1) << 1;
-                        cur[r_app + 2] = (unsigned int) (ch + g.nx) << 1;
-                        cur[r_app + 3] = (unsigned int) (ch + g.nx + 1) << 1;
+                    } else if (isB && ch != ~0u) {
+                        cur[r_app + 0] = ch << 1;
+                        cur[r_app + 1] = (ch + 1u) << 1;
+                        cur[r_app + 2] = (ch + (1u << kPkShift)) << 1;
+                        cur[r_app + 3] = (ch + (1u << kPkShift) + 1u) << 1;
                     }
                     if (surv) nxt[r_surv] = e;
                 }
@@ -790,7 +866,7 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
                 const unsigned long long k = cnt + i + 1;                              // ordinal of this bit
                 const unsigned int bit = win_bits_lane(wreg, o0 + (int) i, 1);        // (a cross-lane read: every lane takes part)
                 on[j] = i < m && k <= B + 1 && bit;                                    // applied, then checked (:418-426)
-                pj[j] = on[j] ? lsp[base + i] : 0u;
+                pj[j] = on[j] ? pk_index(lsp[base + i], g.nx) : 0u;
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) cj[j] = on[j] ? C[pj[j]] : 0;
@@ -867,20 +943,23 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
                          const unsigned long long *d_num_bits, const ResidualBuffers &rb, int n_frames,
                          const int *d_active, hipStream_t s)
 {
+    // (the decoder's lists hold packed 12-bit coordinates: the extents the stream header can carry, spiht_re.c:448-464)
+    if (rb.g.nx > (1 << kPkShift) || rb.g.ny > (1 << kPkShift)) throw HipFailure("ebcc-mi355x: residual grid wider than the SPIHT header's 12-bit extents");
     // spiht_decode_init clears the coefficient grid, spiht_re.c:101 (of the frames that are decoded)
     hipLaunchKernelGGL(k_zero_active, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.np, d_active);
     static const bool prof = getenv("EBCC_HIP_SPIHT_PROF") != nullptr;
-    if (prof) { unsigned long long z[10] = {}; EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_spiht_prof), z, sizeof z)); }
+    if (prof) { unsigned long long z[12] = {}; EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_spiht_prof), z, sizeof z)); }
     timing_begin("spiht_decode", s);
     hipLaunchKernelGGL(k_spiht_decode, dim3(n_frames), dim3(kWave), 0, s, d_streams, stream_stride, d_sizes, d_num_bits,
                        rb.C, rb.lip, rb.lsp, rb.lis0, rb.lis1, rb.g, rb.np, rb.fs, d_active, prof ? 1 : 0);
     timing_end("spiht_decode", s);
     if (prof) {
-        unsigned long long v[10];
+        unsigned long long v[12];
         wait_stream(s);
         EBCC_HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_spiht_prof), sizeof v));
         fprintf(stderr, "spiht_decode profile (%d frames): LIP %.1f Mcycles %llu entries | LIS %.1f Mcycles %llu entries | refinement %.1f Mcycles %llu bits | %llu stream bits, longest %llu | slowest frame: %llu cycle-counter ticks in %.1f us (100 MHz clock)\n",
                 n_frames, v[0] / 1e6, v[1], v[2] / 1e6, v[3], v[4] / 1e6, v[5], v[6], v[7], v[8], v[9] / 100.0);
+        fprintf(stderr, "spiht_decode profile: %llu chunks in the LIS passes\n", v[10]);
     }
     hipLaunchKernelGGL(k_int_to_float, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.A, rb.np, d_active);
     EBCC_HIP_LAUNCH_CHECK();

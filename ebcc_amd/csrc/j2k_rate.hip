@@ -1649,7 +1649,10 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
         // Measured on 256 frames of configs[1] (round 3): 1/32 at 2 lanes and the rest at 4: 18.5 ms; all at 4: 18.5; a tier
         // of single lanes for the longest 1/256 or 1/512: 18.5 (the launch is bound by vector issue, not by its longest
         // chain); an 8-lane tier for the shortest 2/3: 31.6 - and 29.7 with no wave using it: what costs is the LDS a
-        // workgroup reserves (the state rows of its widest tier: 16.5 KB instead of 8), i.e. how many waves a CU holds.
+        // workgroup reserves (the state rows of its widest tier: 16.5 KB instead of 8), i.e. how many waves a CU holds.  With
+        // the NEG and REF rows in device memory instead (half the LDS per code-block, so that 8 lanes reserve what 4 do now;
+        // bit-exact, since removed): 18.9 ms at 4 lanes, 20.5 - 27.6 ms with 8-lane tiers - lanes of a wave take turns, a
+        // wave of 8 lasts twice as long; and 96 VGPRs for a fifth wave per SIMD spill 62 registers: 20.1 - 20.8 ms.
         DecTiers tiers{{0, 0, 0}, {1, 2, 4, 4}};
         if (few_blocks) { tiers.lanes[3] = 1; }
         else if (getenv("EBCC_T1_LPW")) { tiers.lanes[3] = lpw; }

@@ -180,8 +180,9 @@ def test_full_size_batch_is_configuration_independent(monkeypatch):
     cfg = L.make_config((1, 721, 1440), base_cr=30.0, error=0.5, residual_type=L.MAX_ERROR)
     digests = {}
     for name, env in (("default", {}), ("one slice", {"EBCC_HIP_SLICES": "1"}),
-                      ("single-kernel tier-1, 16 lanes", {"EBCC_T1_TWO_PHASE": "0", "EBCC_T1_LPW": "16"})):
-        for k in ("EBCC_HIP_SLICES", "EBCC_T1_TWO_PHASE", "EBCC_T1_LPW"):
+                      ("single-kernel tier-1, 16 lanes", {"EBCC_T1_TWO_PHASE": "0", "EBCC_T1_LPW": "16"}),
+                      ("decoder tiers of 1 / 2 / 4 / 8 lanes", {"EBCC_T1_DEC_TIERS": "128,16,3,8"})):
+        for k in ("EBCC_HIP_SLICES", "EBCC_T1_TWO_PHASE", "EBCC_T1_LPW", "EBCC_T1_DEC_TIERS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -191,6 +192,7 @@ def test_full_size_batch_is_configuration_independent(monkeypatch):
         assert np.abs(dec - frames).max() <= 0.5 * 1.01 + 1e-3, name
         digests[name] = (sha(b"".join(sha(s).encode() for s in got)), sha(dec.tobytes()), got[0], got[47])
     assert digests["default"][:2] == digests["one slice"][:2] == digests["single-kernel tier-1, 16 lanes"][:2]
+    assert digests["default"][:2] == digests["decoder tiers of 1 / 2 / 4 / 8 lanes"][:2]
     L.oracle().orc_set_j2k_backend(0)
     assert digests["default"][2] == L.orc_encode(frames[0], cfg)
     assert digests["default"][3] == L.orc_encode(frames[47], cfg)

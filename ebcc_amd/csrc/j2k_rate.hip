@@ -1206,6 +1206,50 @@ struct DecSrcAhead {
     }
 };
 
+// The same source for a decoder that walks the segment from its first byte (the true decode): BYTEIN looks at the byte it
+// stands on and the one after it - both come out of two dword registers with one v_alignbyte - and steps forward by at most
+// one; every fourth step the next dword of the 16-byte chunk registers moves in (bytes past the segment's end read as 0xFF).
+// get() cost ~40 vector instructions per byte and BYTEIN asked twice: a third of the decoder's instructions.
+struct DecSrcSeq {
+    static constexpr bool kSequential = true;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint8_t *base;           // 16-byte aligned address at or before the segment's first byte
+    int end;                       // offset from `base` one past the segment's last byte
+    int o;                         // offset of the byte the decoder stands on
+    uint32_t lo, hi;               // the dword that holds byte o, and the one after it
+    u32x4 cur, nxt;                // the chunk that holds `hi`'s dword (or the one before), and the one after it
+    __device__ u32x4 chunk(int c) const
+    {
+        if (c * 16 >= end) return u32x4{0, 0, 0, 0};
+        return *(const __attribute__((address_space(1))) u32x4 *) (uintptr_t) (base + (size_t) c * 16);
+    }
+    __device__ uint32_t dword(int off)                                   // off: a multiple of 4, asked for in rising order
+    {
+        if ((off & 15) == 0 && off > 0) { cur = nxt; nxt = chunk((off >> 4) + 1); }
+        const int j = (off >> 2) & 3;
+        uint32_t w = j & 2 ? (j & 1 ? cur.w : cur.z) : (j & 1 ? cur.y : cur.x);
+        const int rem = end - off;
+        if (rem < 4) w |= rem <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * rem);
+        return w;
+    }
+    __device__ DecSrcSeq(const uint8_t *p, int len)
+        : base((const uint8_t *) ((uintptr_t) p & ~(uintptr_t) 15)), end((int) ((uintptr_t) p & 15) + len), o((int) ((uintptr_t) p & 15))
+    {
+        cur = chunk(0); nxt = chunk(1);
+        lo = dword(o & ~3);
+        hi = dword((o & ~3) + 4);
+    }
+    __device__ uint32_t pair() const { return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t) o & 3u); }   // bytes o, o + 1, .. from bit 0 up
+    __device__ uint32_t at0() const { return pair() & 0xFFu; }
+    __device__ uint32_t at1() const { return (pair() >> 8) & 0xFFu; }
+    __device__ void step()
+    {
+        o++;
+        if ((o & 3) == 0) { lo = hi; hi = dword(o + 4); }
+    }
+    __device__ uint32_t get(int) const { return 0xFFu; }                  // (not used by a sequential decoder)
+};
+
 // Longest first: a code-block is one serial chain (a large one ~10 ms of dependent instructions), so the launch ends
 // when the last large block does.  The blocks are put in order of falling segment length (a counting sort over 64
 // length classes, k_dec_hist / k_dec_offsets / k_dec_place) and the waves take them in that order: the long chains start
@@ -1284,7 +1328,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lanes * 8u,
                    V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
     for (int r = 0; r < kDecStateRows; r++) st.at(r) = 0ull;
-    t1::decode_block(st, DecSrcAhead(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab, ctxp);
+    t1::decode_block(st, DecSrcSeq(src, len), blk.w, blk.h, geom->bands[blk.band].orient, P, np, tab, ctxp);
 }
 
 

@@ -248,6 +248,11 @@ T1_HD uint32_t div_u16(uint32_t x, uint32_t q)
 #endif
 }
 
+template <class Source, class = void>
+struct source_is_sequential : std::false_type {};
+template <class Source>
+struct source_is_sequential<Source, std::enable_if_t<Source::kSequential>> : std::true_type {};
+
 template <class Source, class Table = ConstTable>
 struct MqDecoder {
     uint32_t a, c;
@@ -256,21 +261,31 @@ struct MqDecoder {
     Source src;
     Table tab;
 
+    // BYTEIN looks at the byte the decoder stands on and the one after it, and steps forward by at most one: a source that
+    // keeps those two at hand (Source::kSequential: at(0), at(1), step()) saves the two random accesses of get()
     T1_HD void bytein()
     {
-        uint32_t cur = src.get(pos), nxt = src.get(pos + 1);
+        uint32_t cur, nxt;
+        if constexpr (source_is_sequential<Source>::value) { cur = src.at0(); nxt = src.at1(); }
+        else { cur = src.get(pos); nxt = src.get(pos + 1); }
         if (cur == 0xFF) {
             if (nxt > 0x8F) { c += 0xFF00; ct = 8; }
-            else { pos++; c += nxt << 9; ct = 7; }
+            else { step(); c += nxt << 9; ct = 7; }
         } else {
-            pos++; c += nxt << 8; ct = 8;
+            step(); c += nxt << 8; ct = 8;
         }
+    }
+    T1_HD void step()
+    {
+        pos++;
+        if constexpr (source_is_sequential<Source>::value) src.step();
     }
     T1_HD void init()
     {
         cx.reset();
         pos = 0;
-        c = src.get(0) << 16;
+        if constexpr (source_is_sequential<Source>::value) c = src.at0() << 16;
+        else c = src.get(0) << 16;
         bytein();
         c <<= 7; ct -= 7; a = 0x8000;
     }

@@ -54,7 +54,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
         const char *e = getenv("EBCC_T1_TWO_PHASE");
         jb->sym_rows = kJ2kSymRows;
         if (const char *r = getenv("EBCC_HIP_SYM_ROWS")) jb->sym_rows = std::max(1, std::min(kJ2kSymRows, atoi(r)));
-        if (!e || atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * (size_t) jb->sym_rows * 1024 + 256)) != nullptr;
+        if (!e || atoi(e)) ok &= (jb->SYM = ctx_alloc<uint8_t>(ctx, groups * (size_t) ((jb->sym_rows + 1) & ~1) * 1024 + 256)) != nullptr;
     }
     ok &= (jb->seglen = ctx_alloc<uint16_t>(ctx, groups * (size_t) kJ2kSegCount * 64)) != nullptr;
     ok &= (jb->lanerows = ctx_alloc<uint32_t>(ctx, groups * 64)) != nullptr;

@@ -124,7 +124,7 @@ struct J2kBuffers {
     unsigned long long *SPS;      // [groups][64][64] "became significant in a propagation pass" row masks (encoder)
     unsigned long long *VISP;     // [groups][planes][64][64] visited masks at the end of each plane's propagation pass
     void *ckpt;                   // [frames*nblocks][passes * 16 stripes][8 words] MQ-decoder checkpoints at every stripe start of every coding pass (J2kCkptView)
-    uint8_t *SYM;                 // [groups][sym_rows][64 lanes][16] decision rows of the segmented two-phase encoder (t1_core.hpp: row format); null: single-kernel encoder
+    uint8_t *SYM;                 // [groups][sym_rows / 2][64 lanes][2 rows][16] decision rows (rows in pairs: j2k_analysis.hip sym_row_offset) of the segmented two-phase encoder (t1_core.hpp: row format); null: single-kernel encoder
     int sym_rows;                 // 1-KB rows of SYM per group (kJ2kSymRows; EBCC_HIP_SYM_ROWS overrides, for tests of the retry)
     std::uint16_t *seglen;        // [groups][kJ2kSegCount][64] decisions of every segment of every code-block, then its first row in the block's stream
     std::uint32_t *lanerows;      // [frames*nblocks] rows in the block's stream

@@ -1222,9 +1222,14 @@ __global__ __launch_bounds__(64) void k_t1_rowoffs(std::uint16_t *seglen, uint32
 // ---- decisions: one wave per (group of 64 code-blocks, bit-plane), a code-block per lane; the decisions of a segment
 // go through a per-lane byte ring in LDS and leave as the 16-byte rows of the block's stream: row r of lane l of a
 // group at ((r * 64) + l) * 16, so that the MQ pass reads one contiguous KB per step
+// Rows are stored in PAIRS: rows 2j and 2j + 1 of lane l at (j * 64 + l) * 32 (+ 16 for the odd row), so that the two rows a
+// lane writes one after the other fill one 32-byte sector (16-byte pieces at 1 KB stride were partial-sector writes: the emit
+// wrote 23.9 MB per frame for 11 MB of rows) and the MQ pass, which takes two rows per step, reads 32 contiguous bytes per lane.
+__device__ inline size_t sym_row_offset(uint32_t row) { return (size_t) (row >> 1) * 2048 + (size_t) (row & 1u) * 16; }   // + lane * 32
+__host__ __device__ inline size_t sym_group_bytes(uint32_t sym_rows) { return (size_t) ((sym_rows + 1u) & ~1u) * 1024; }
 struct SegEmDev {
     unsigned char *ring;           // LDS: this lane's 64 bytes (lane stride 68 bytes = 17 banks: lanes at the same offset never conflict)
-    uint8_t *sym;                  // the group's rows + lane * 16
+    uint8_t *sym;                  // the group's rows + lane * 32
     const std::uint16_t *rowoff;   // this lane's column of the segments' first rows
     uint32_t cap;                  // rows the lane may write
     uint32_t cnt = 0, fl = 0;      // decisions of the segment so far, rows written
@@ -1248,7 +1253,7 @@ struct SegEmDev {
             }
         }
         if (fl == 0) w[0] |= t1::kRowStart;
-        if (row0 + fl < cap) *(uint4 *) (sym + (size_t) (row0 + fl) * 1024) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (row0 + fl < cap) *(uint4 *) (sym + sym_row_offset(row0 + fl)) = make_uint4(w[0], w[1], w[2], w[3]);
         fl++;
     }
     __device__ void column_end() { if ((cnt >> 4) != fl) piece(16u); }  // (a column adds at most 11 decisions)
@@ -1273,7 +1278,7 @@ __global__ __launch_bounds__(64) void k_t1_emit(const unsigned long long *BP, co
     const uint32_t lane8 = threadIdx.x * 8u;
     DevMasks M{(const unsigned char *) (BP + grp * kJ2kMaxPlanes * 64 * 64), (const unsigned char *) (SUF + grp * (kJ2kMaxPlanes + 2) * 64 * 64),
                (const unsigned char *) (SGN + grp * 64 * 64), (unsigned char *) (VISP + grp * kJ2kMaxPlanes * 64 * 64), lane8};
-    SegEmDev em{(unsigned char *) ring + threadIdx.x * 68u, SYM + grp * (size_t) sym_rows * 1024 + threadIdx.x * 16u,
+    SegEmDev em{(unsigned char *) ring + threadIdx.x * 68u, SYM + grp * sym_group_bytes(sym_rows) + threadIdx.x * 32u,
                 seglen + grp * kJ2kSegCount * 64 + threadIdx.x, sym_rows};
     const int nstr = (l.h + 3) >> 2;
     for (int s = 0; s < nstr; s++) t1::emit_stripe_segments(M, em, l.P, p, s, l.w, l.h, l.orient);
@@ -1373,7 +1378,7 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
         return;
     }
     // ---- wave 1: loader + code chain.  Barrier k hands chunk k of the rows to wave 0 and chunk k - 1 of the hand-over words to this wave.
-    const uint8_t *sym = SYM + grp * (size_t) sym_rows * 1024 + (size_t) lane * 16u;
+    const uint8_t *sym = SYM + grp * sym_group_bytes(sym_rows) + (size_t) lane * 32u;
     uint8_t *out = cblk_bytes + (size_t) (on ? gid : 0) * kJ2kCblkBytes;
     int *myrates = rates + (size_t) (on ? gid : 0) * kJ2kMaxPasses;
     MqSinkLds sink{(unsigned char *) bring + lane * 68, out, &jf[l.frame].overflow};
@@ -1382,7 +1387,7 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
 #pragma unroll
         for (int i = 0; i < kRowChunk; i++) {
             const uint32_t row = q * kRowChunk + (uint32_t) i;
-            v[i] = row < wrows ? *(const uint4 *) (sym + (size_t) row * 1024) : make_uint4(0, 0, 0, 0);
+            v[i] = row < wrows ? *(const uint4 *) (sym + sym_row_offset(row)) : make_uint4(0, 0, 0, 0);
         }
     };
     auto put_chunk = [&](uint32_t q, const uint4 v[kRowChunk]) {

@@ -1217,7 +1217,8 @@ struct DecSrcSeq {
     int end;                       // offset from `base` one past the segment's last byte
     int o;                         // offset of the byte the decoder stands on
     uint32_t lo, hi;               // the dword that holds byte o, and the one after it
-    u32x4 cur, nxt;                // the chunk that holds `hi`'s dword (or the one before), and the one after it
+    u32x4 cur;                     // the chunk that holds `hi`'s dword (no chunk is requested ahead: the launch is bound by
+                                   // vector issue, other waves cover the load, and four registers fewer end the spills)
     __device__ u32x4 chunk(int c) const
     {
         if (c * 16 >= end) return u32x4{0, 0, 0, 0};
@@ -1225,7 +1226,7 @@ struct DecSrcSeq {
     }
     __device__ uint32_t dword(int off)                                   // off: a multiple of 4, asked for in rising order
     {
-        if ((off & 15) == 0 && off > 0) { cur = nxt; nxt = chunk((off >> 4) + 1); }
+        if ((off & 15) == 0 && off > 0) cur = chunk(off >> 4);
         const int j = (off >> 2) & 3;
         uint32_t w = j & 2 ? (j & 1 ? cur.w : cur.z) : (j & 1 ? cur.y : cur.x);
         const int rem = end - off;
@@ -1235,7 +1236,7 @@ struct DecSrcSeq {
     __device__ DecSrcSeq(const uint8_t *p, int len)
         : base((const uint8_t *) ((uintptr_t) p & ~(uintptr_t) 15)), end((int) ((uintptr_t) p & 15) + len), o((int) ((uintptr_t) p & 15))
     {
-        cur = chunk(0); nxt = chunk(1);
+        cur = chunk(0);
         lo = dword(o & ~3);
         hi = dword((o & ~3) + 4);
     }

@@ -1501,23 +1501,45 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     const unsigned long long *sg = SGN + grp * 64 * 64 + gl;
     const unsigned long long *sps = SPS + grp * 64 * 64 + gl;
     st.S(-1) = 0; st.S(64) = 0;                                         // (the guard rows: nothing else writes them on this path)
-    for (int y = 0; y < 64; y++) {
-        unsigned long long S = 0, R = 0, Vv = 0;
-        const int q = r + (y < 4 * stripe ? 1 : 0);
-        if (y < blk.h && q > 0) {
-            const int p = t1::plane_of_pass(P, q), t = t1::type_of_pass(q);
-            const unsigned long long s1 = SUF[((grp * (kJ2kMaxPlanes + 2) + p + 1) * 64 + y) * 64 + gl];
-            S = s1;
-            if (t >= 1) {
-                S |= sps[(size_t) y * 64] & BP[((grp * kJ2kMaxPlanes + p) * 64 + y) * 64 + gl] & ~s1;
-                Vv = VISP[((grp * kJ2kMaxPlanes + p) * 64 + y) * 64 + gl];
+    // When no further pass follows (the usual case: the restart point lies in the last pass the layer keeps) the decoder only
+    // looks at the rows from the one above the restart stripe on.  Four rows are requested together: taken one at a time every
+    // row waited for its own loads (64 round trips to L2 ahead of a decode of one or two stripes).
+    const int y_first = r == np - 1 ? max(0, 4 * stripe - 1) & ~3 : 0;
+    for (int y0 = y_first; y0 < 64; y0 += 4) {
+        unsigned long long s1[4], s2[4], bpv[4], spv[4], vv[4], sgv[4];
+        int tt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = y0 + k;
+            const int q = r + (y < 4 * stripe ? 1 : 0);
+            tt[k] = -1; s1[k] = s2[k] = bpv[k] = spv[k] = vv[k] = sgv[k] = 0ull;
+            if (y < blk.h && q > 0) {
+                const int p = t1::plane_of_pass(P, q), t = t1::type_of_pass(q);
+                tt[k] = t;
+                s1[k] = SUF[((grp * (kJ2kMaxPlanes + 2) + p + 1) * 64 + y) * 64 + gl];
+                if (t >= 1) {
+                    spv[k] = sps[(size_t) y * 64];
+                    bpv[k] = BP[((grp * kJ2kMaxPlanes + p) * 64 + y) * 64 + gl];
+                    vv[k] = VISP[((grp * kJ2kMaxPlanes + p) * 64 + y) * 64 + gl];
+                }
+                if (t != 2) s2[k] = SUF[((grp * (kJ2kMaxPlanes + 2) + p + 2) * 64 + y) * 64 + gl];
+                sgv[k] = sg[(size_t) y * 64];
             }
-            R = t == 2 ? s1 : SUF[((grp * (kJ2kMaxPlanes + 2) + p + 2) * 64 + y) * 64 + gl];
         }
-        st.S(y) = S;
-        st.NEG(y) = S ? (sg[(size_t) y * 64] & S) : 0ull;
-        st.REF(y) = R;
-        st.VIS(y) = Vv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = y0 + k;
+            unsigned long long S = 0, R = 0, Vv = 0;
+            if (tt[k] >= 0) {
+                S = s1[k];
+                if (tt[k] >= 1) { S |= spv[k] & bpv[k] & ~s1[k]; Vv = vv[k]; }
+                R = tt[k] == 2 ? s1[k] : s2[k];
+            }
+            st.S(y) = S;
+            st.NEG(y) = sgv[k] & S;
+            st.REF(y) = R;
+            st.VIS(y) = Vv;
+        }
     }
     const J2kCkptView cv = J2kCkptView::of(ckpt, (size_t) gid);
     const uint4 *rec = (const uint4 *) cv.slot((uint32_t) (r * 16 + stripe));

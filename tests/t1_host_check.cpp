@@ -125,6 +125,16 @@ struct CtxSlots { uint32_t *b; uint32_t handle(uint32_t c) const { return c; } u
     void words(uint32_t x[5]) const { for (int j = 0; j < 5; j++) { uint32_t v = 0; for (int k = 0; k < 4; k++) if (4 * j + k < NCTX) v |= mq_code_state(b[4 * j + k] >> 16) << (8 * k); x[j] = v; } } };
 struct VecSink3 { std::vector<uint8_t> *v; void put(int i, uint32_t b) { if (i < 0) return; if ((int) v->size() <= i) v->resize(i + 1); (*v)[i] = (uint8_t) b; } void row_end(int) {} void finish(int n) { v->resize((size_t) n); } };
 struct BufSrc { const uint8_t *p; int n; uint32_t get(int i) const { return i < n ? p[i] : 0xFFu; } };
+// a source of the sequential kind (t1_core.hpp: source_is_sequential; the device's is DecSrcSeq of j2k_rate.hip): the
+// decoder only asks for the byte it stands on, the one after it, and a step forward
+struct SeqSrc {
+    static constexpr bool kSequential = true;
+    const uint8_t *p; int n; int o = 0;
+    uint32_t at0() const { return o < n ? p[o] : 0xFFu; }
+    uint32_t at1() const { return o + 1 < n ? p[o + 1] : 0xFFu; }
+    void step() { o++; }
+    uint32_t get(int) const { return 0u; }            // (must not be used: a wrong byte would show in the decode)
+};
 struct HostEnv { BufSrc src; bool any(bool b) const { return b; } BufSrc &bytes() { return src; } bool starved(int) const { return false; } void refill_point(int) {} void pass_point(int) {} };
 
 int main(int argc, char **argv)
@@ -318,6 +328,13 @@ int main(int argc, char **argv)
             ds.out = d2.data(); ds.w = w;
             decode_block(ds, BufSrc{bytes.data(), len}, w, h, orient, numbps, np);
             if (d1 != d2) { printf("trial %d DECODE mismatch np %d/%d\n", t, np, opasses); bad++; break; }
+            {
+                std::vector<int32_t> d3((size_t) w * h, 0);
+                HostStore ss;
+                ss.out = d3.data(); ss.w = w;
+                decode_block(ss, SeqSrc{bytes.data(), len}, w, h, orient, numbps, np);
+                if (d1 != d3) { printf("trial %d DECODE (sequential source) mismatch np %d/%d\n", t, np, opasses); bad++; break; }
+            }
             // ---- resume at the last coded plane from a checkpoint of the FULL-segment decode
             static Obs obs;
             obs.nstr = nstr;

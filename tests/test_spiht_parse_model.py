@@ -6,7 +6,9 @@ pinned on the CPU as well as by the GPU parity tests:
 * LIP pass: an entry is one bit, or two when the first is set.  The bits that are second bits ("signs") of the next 64
   stream bits have a closed form (the odd / even run-of-ones carry argument of simdjson's backslash scanner);
 * LIS pass: a chunk is the entries that start in the first 55 of the next 64 stream bits; what a type-A entry would take
-  is worked out per bit position, a walk adds the lengths up.
+  is worked out per bit position (together with its children's significance / sign flags), a walk from set bit to set
+  bit adds the lengths up (a run of zero bits is that many one-bit entries whatever their types; a guard bit at position
+  55 ends the walk), and the list's end is cut afterwards.
 """
 import random
 
@@ -111,35 +113,88 @@ def lis_sequential(bits, types):
     return out, pos
 
 
+def ctz(x):
+    return (x & -x).bit_length() - 1
+
+
 def lis_chunked(bits, types):
-    out, base, cnt, n = [], 0, 0, len(types)
+    """the kernel's LIS loop: entry starts, bits consumed, and for every type-A entry on a set bit the children's
+    (significant, negative) flags its lane read ahead (wsig / wneg)"""
+    out, flags, base, cnt, n = [], [], 0, 0, len(types)
+    low55 = (1 << 55) - 1
     while base < n:
         m = min(64, n - base)
         x = stream64(bits, cnt)
-        len_a = []
+        typemask = sum(1 << i for i in range(m) if types[base + i])
+        len_a, wsig, wneg = [], [], []
         for lane in range(64):                             # every lane: what a type-A entry at its bit would take
-            la = 1
-            if lane < 55 and (x >> (63 - lane)) & 1:
-                q = lane + 1
-                for _ in range(4):
-                    q += 1 + ((x >> (63 - q)) & 1)
-                la = q - lane
-            len_a.append(la)
-        rel = n_ent = 0
-        while n_ent < m and rel < 55:                      # the scalar walk
-            out.append(cnt + rel)
-            rel += 1 if types[base + n_ent] else len_a[rel]
-            n_ent += 1
-        assert rel <= 64
+            wl = ((x << lane) & M) >> 32                   # the 32 stream bits from this lane's position on, first in bit 31
+            la, sg, ng = 1, 0, 0
+            if lane < 55 and wl >> 31:
+                q = 1
+                for k in range(4):
+                    sb = (wl >> (31 - q)) & 1
+                    sg |= sb << k
+                    ng |= (sb & (wl >> (30 - q))) << k
+                    q += 1 + sb
+                la = q
+            len_a.append(la); wsig.append(sg); wneg.append(ng)
+        # the walk from set bit to set bit, a guard bit at position 55
+        xr = (brev64(x) & low55) | (1 << 55)
+        starts, rel = 0, 0
+        while True:
+            z = ctz(xr >> rel)
+            starts |= ((2 << z) - 1) << rel
+            pos = rel + z
+            rel = pos + (1 if (typemask >> (bin(starts).count("1") - 1)) & 1 else len_a[pos])
+            if rel >= 55:
+                break
+        rel -= (starts >> 55) & 1
+        starts &= low55
+        n_ent = bin(starts).count("1")
+        if n_ent > m:                                      # the list ends inside the chunk
+            lanes = [lane for lane in range(64) if (starts >> lane) & 1]
+            rel = lanes[m]
+            starts &= (1 << rel) - 1
+            n_ent = m
+        assert 0 < rel <= 64
+        i = 0
+        for lane in range(64):
+            if (starts >> lane) & 1:
+                out.append(cnt + lane)
+                if not types[base + i] and (x >> (63 - lane)) & 1:
+                    flags.append((cnt + lane, wsig[lane], wneg[lane]))
+                i += 1
         cnt += rel
         base += n_ent
-    return out, cnt
+    return out, cnt, flags
+
+
+def lis_sequential_flags(bits, types):
+    out, pos = [], 0
+    for is_b in types:
+        start = pos
+        sb = bits[pos]
+        pos += 1
+        if not is_b and sb:
+            sg = ng = 0
+            for k in range(4):
+                s_ = bits[pos]
+                pos += 1
+                if s_:
+                    sg |= 1 << k
+                    ng |= bits[pos] << k
+                    pos += 1
+            out.append((start, sg, ng))
+    return out
 
 
 def test_lis_chunks_match_sequential_parse():
     rng = random.Random(7)
-    for _ in range(1500):
-        density = rng.random()
+    for t in range(1500):
+        density = rng.random() if t % 4 else rng.choice([0.0, 0.02, 0.98, 1.0])
         bits = [1 if rng.random() < density else 0 for _ in range(3000)]
-        types = [rng.random() < 0.5 for _ in range(rng.randint(1, 200))]
-        assert lis_sequential(bits, types) == lis_chunked(bits, types)
+        types = [rng.random() < (0.5 if t % 3 else rng.choice([0.0, 1.0])) for _ in range(rng.randint(1, 200))]
+        starts, used, flags = lis_chunked(bits, types)
+        assert (starts, used) == lis_sequential(bits, types)
+        assert flags == lis_sequential_flags(bits, types)

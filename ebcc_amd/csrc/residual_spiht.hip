@@ -94,18 +94,21 @@ __device__ inline unsigned long long shfl_up_u64(unsigned long long v, int d)
     return ((unsigned long long) hi << 32) | lo;
 }
 
-// exclusive scan of a packed counter word across the workgroup; returns the block total in `total`
+// exclusive scan of a packed counter word across the workgroup; returns the block total in `total`.  `wave_tot` holds two
+// sets of wave totals used alternately (`turn`): the readers of one scan never meet the writers of the next, so a scan costs
+// ONE barrier - and that barrier also stands between the window flush of the step before and this step's puts.
 template <int NWAVES>
-__device__ inline unsigned long long block_scan(unsigned long long v, unsigned long long *wave_tot,
+__device__ inline unsigned long long block_scan(unsigned long long v, unsigned long long *wave_tot_both, unsigned int &turn,
                                                 unsigned long long &total)
 {
+    unsigned long long *wave_tot = wave_tot_both + (turn & 1u) * NWAVES;
+    turn++;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned long long y = shfl_up_u64(x, d);
-        if (lane >= d) x += y;
-    }
+    // the wave's inclusive sums from three 32-bit DPP scans (the two halves of the low word cannot overflow on their own; no
+    // trip through the LDS crossbar: the twelve shuffles of a 64-bit scan were ~0.3 us of every sweep step)
+    const uint32_t lo = (uint32_t) v;
+    const uint32_t s0 = wave_prefix_sum(lo & 0xFFFFu), s1 = wave_prefix_sum(lo >> 16), s2 = wave_prefix_sum((uint32_t) (v >> 32));
+    unsigned long long x = (unsigned long long) s0 + ((unsigned long long) s1 << 16) + ((unsigned long long) s2 << 32);
     if (NWAVES == 1) {
         unsigned int lo = __shfl((unsigned int) x, 63), hi = __shfl((unsigned int) (x >> 32), 63);
         total = ((unsigned long long) hi << 32) | lo;
@@ -120,7 +123,6 @@ __device__ inline unsigned long long block_scan(unsigned long long v, unsigned l
         if (i < w) base += t;
         tot += t;
     }
-    __syncthreads();
     total = tot;
     return base + x - v;
 }
@@ -150,24 +152,27 @@ __device__ inline void window_put(const BitWindow &bw, unsigned int val, int nb,
     if (lo) atomicOr(&bw.w[j + 1], lo);
 }
 
-// zero the window for a chunk whose first bit has SPIHT index `first`
+// the window of a chunk whose first bit has SPIHT index `first` (the words are zero: the flush before left them so)
 __device__ inline void window_open(BitWindow &bw, unsigned long long first)
 {
-    for (int i = threadIdx.x; i < kWindowWords; i += blockDim.x) bw.w[i] = 0;
     bw.base = ((kHeaderBits + first) >> 5) << 5;
-    __syncthreads();
 }
 
-// OR the window into the big-endian byte stream
-__device__ inline void window_flush(const BitWindow &bw, unsigned int *stream, size_t stream_words)
+// OR the window into the big-endian byte stream and leave it zeroed.  A barrier stands before the reads (every put of the
+// step is in); the one behind them is the caller's next block_scan - a sweep without a scan (the refinement pass) asks for it
+// here (`fence_after`).
+__device__ inline void window_flush(const BitWindow &bw, unsigned int *stream, size_t stream_words, bool fence_after = false)
 {
     __syncthreads();
     size_t w0 = (size_t) (bw.base >> 5);
     for (int i = threadIdx.x; i < kWindowWords; i += blockDim.x) {
         unsigned int v = bw.w[i];
-        if (v && w0 + i < stream_words) atomicOr(&stream[w0 + i], __builtin_bswap32(v));
+        if (v) {
+            bw.w[i] = 0;
+            if (w0 + i < stream_words) atomicOr(&stream[w0 + i], __builtin_bswap32(v));
+        }
     }
-    __syncthreads();
+    if (fence_after) __syncthreads();
 }
 
 // ================================================================================================
@@ -178,8 +183,10 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
     uint32_t *lspb, uint32_t *lis0b, uint32_t *lis1b, uint32_t *sigordb, uint32_t *lspidxb, uint32_t *streamb,
     size_t stream_words, Grid g, size_t np, FrameState *fsb, const unsigned long long *bits0, const int *active)
 {
-    __shared__ unsigned long long wave_tot[kEncWaves];
+    __shared__ unsigned long long wave_tot[2 * kEncWaves];
     __shared__ unsigned int window[kWindowWords];
+    unsigned int turn = 0;
+    for (int i = threadIdx.x; i < kWindowWords; i += blockDim.x) window[i] = 0;   // (the first scan's barrier comes before the first put)
 
     const int frame = blockIdx.x;
     if (active && !active[frame]) return;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
             unsigned int p = (unsigned int) (x + y * g.nx);
             bool isset = valid && ((x & 1) || (y & 1));
             unsigned long long tot;
-            unsigned long long ex = block_scan<kEncWaves>(isset ? 1ull : 0ull, wave_tot, tot);
+            unsigned long long ex = block_scan<kEncWaves>(isset ? 1ull : 0ull, wave_tot, turn, tot);
             if (valid) lip[i] = p;
             if (isset) cur[nlis + (unsigned int) ex] = p << 1;           // bit0 = 0: type A
             nlis += (unsigned int) tot;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
                 unsigned long long pack = (unsigned long long) nb | ((unsigned long long) (sig ? 1 : 0) << 16) |
                                           ((unsigned long long) ((valid && !sig) ? 1 : 0) << 32);
                 unsigned long long tot;
-                unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, tot);
+                unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, turn, tot);
                 unsigned long long off = nbits + (ex & 0xFFFF);
                 window_open(bw, nbits);
                 window_put(bw, val, nb, off, limit);
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
                                           ((unsigned long long) n_lip << kShLip) | ((unsigned long long) n_app << kShApp) |
                                           ((unsigned long long) surv << kShSurv);
                 unsigned long long tot;
-                unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, tot);
+                unsigned long long ex = block_scan<kEncWaves>(pack, wave_tot, turn, tot);
                 unsigned long long off = nbits + (ex & fld_mask(kFldBits));
                 window_open(bw, nbits);
                 window_put(bw, val, nb, off, limit);
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
             fs.refine_count[s] = n_old;
             fs.step_reached[s] = 1;
         }
+        __syncthreads();                                                 // (the LIS pass's last flush is still zeroing the window; this sweep has no scan)
         for (unsigned int base = 0; base < n_old && !stop; base += kEncThreads) {
             unsigned int i = base + tid;
             bool valid = i < n_old;
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
             }
             window_open(bw, nbits);
             window_put(bw, bit, valid ? 1 : 0, nbits + tid, limit);
-            window_flush(bw, stream, stream_words);
+            window_flush(bw, stream, stream_words, true);
             nbits += min((unsigned int) kEncThreads, n_old - base);
             if (nbits > budget) stop = true;
         }

@@ -1379,7 +1379,8 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 for (size_t f : with_prefix) {
                     const Job &j = jobs[f];
                     const long long x = (long long) j.last[1].stream_bytes - (long long) j.len1;
-                    fprintf(stderr, "zstd-trace c %zu floor %zu X %lld z %zu state %d need_pure %d\n", j.coeffs_size, zfloor[f], x, j.zbytes.size(), (int) zstate[f].load(), (int) j.need_pure);
+                    fprintf(stderr, "zstd-trace c %zu floor %zu X %lld z %zu state %d need_pure %d nbad1 %llu len1 %zu orig %zu\n", j.coeffs_size, zfloor[f], x, j.zbytes.size(), (int) zstate[f].load(), (int) j.need_pure,
+                            (unsigned long long) j.last[0].nbad, j.len1, j.coeffs_orig);
                 }
             bool any_pure = false;
             for (size_t f = 0; f < n; f++) {

@@ -632,6 +632,78 @@ __global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// A COARSER level of the probes whole, the same way: the level's four bands are floats of the grid (LL from `ll`, the
+// three detail bands from `det` - the coarse reconstruction; the two differ from the second level on, whose LL is the
+// level before's result), the ny x nx synthesised samples go to `dst` as the next level's LL.  Replaces the
+// LDS-staged column pass + row pass of the level (two launches and a trip of the level through memory between them; at
+// these sizes - 360 x 182 and 720 x 364 of a 1440 x 728 grid - the passes were bound by workgroup latency, not by bytes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_level_inv_fused(const float *__restrict__ ll, const float *__restrict__ det, float *__restrict__ dst,
+                                                         int stride, size_t np, int nx, int ny, const int *active, int strips, int n_frames, int pieces)
+{
+    const int strip = (int) blockIdx.x, frame = (int) blockIdx.y % n_frames, piece = (int) blockIdx.y / n_frames;
+    if (active && !active[frame]) return;
+    const int lane = (int) threadIdx.x;
+    const int half = ny >> 1, hx = nx >> 1;
+    const int k = strip * kFusePairs + lane - 2;                          // this lane's pair of output columns (2k, 2k + 1)
+    const bool owner = lane >= 2 && lane < 2 + kFusePairs && k >= 0 && k < hx;
+    const int kc = min(max(k, 0), hx - 1);
+    const float *a = ll + (size_t) frame * np, *b = det + (size_t) frame * np;
+    float *out = dst + (size_t) frame * np;
+    const int per = (half + pieces - 1) / pieces, ka = piece * per, kb = min(half, ka + per);
+    if (ka >= kb) return;
+    const int jstart = max(ka - 2, 0);
+    struct Raw { float ll, lh, hl, hh; };
+    auto fetch = [&](int j, Raw &r) {
+        const int jj = min(j, half - 1);
+        const size_t top = (size_t) jj * stride, bot = (size_t) (half + jj) * stride;
+        r.ll = a[top + kc];
+        r.lh = b[bot + kc];
+        r.hl = b[top + hx + kc];
+        r.hh = b[bot + hx + kc];
+    };
+    const bool first = !(k > 0), last = !(k + 1 < hx);
+    auto hsynth = [&](float e_raw, float o_raw, float &even, float &odd) {   // (k_finest_inv_use: lift_inverse_tile's expressions and boundary forms)
+        const float E0 = div_xi(e_raw), O0 = o_raw * kXi;
+        const float Ol = lane_below(O0), Or = lane_above(O0);
+        const float e1 = E0 - kDelta * (O0 + (first ? Or : Ol));
+        const float e1l = lane_below(e1), e1r = lane_above(e1);
+        const float o1 = O0 - kGamma * (e1 + (last ? e1l : e1r));
+        const float o1l = lane_below(o1), o1r = lane_above(o1);
+        const float e2 = e1 - kBeta * (o1 + (first ? o1r : o1l));
+        const float e2r = lane_above(e2);
+        even = e2;
+        odd = last ? o1 - (2 * kAlpha) * e2 : o1 - kAlpha * (e2 + e2r);
+    };
+    RPipe pl, ph;
+    Raw cur;
+    fetch(jstart, cur);
+    for (int j = jstart; j < kb + 4; j++) {
+        Raw nxt;
+        fetch(j + 1, nxt);
+        const int kk = j - 4;
+        float le, lo, he, ho;
+        if (j >= 4 && j < half) {
+            pl.interior(cur.ll, cur.lh, le, lo);
+            ph.interior(cur.hl, cur.hh, he, ho);
+        } else {
+            pl.step(j, half, cur.ll, cur.lh, le, lo);
+            ph.step(j, half, cur.hl, cur.hh, he, ho);
+        }
+        if (kk >= ka) {                                                  // (uniform: the warm-up steps of a piece put nothing out)
+            float s00, s01, s10, s11;
+            hsynth(le, he, s00, s01);
+            hsynth(lo, ho, s10, s11);
+            if (owner && kk < kb) {
+                *reinterpret_cast<float2 *>(out + (size_t) (2 * kk) * stride + 2 * k) = make_float2(s00, s01);
+                *reinterpret_cast<float2 *>(out + (size_t) (2 * kk + 1) * stride + 2 * k) = make_float2(s10, s11);
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // residual min/max with "first occurrence wins" tie-break (reference findMinMaxf, ebcc_codec.c:515-533)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_minmax_init(FrameState *fs, int n_frames)
@@ -1095,10 +1167,31 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     }
     hipLaunchKernelGGL(k_probe_init, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, n_frames, d_active);
     launch_reconstruct_coarse(rb, n_frames, d_trunc_bits, d_active, s);
-    for (int lv = g.stages - 1; lv >= 1; lv--) {
-        int nx = g.nx >> lv, ny = g.ny >> lv;
-        cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
-        rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
+    // the coarser levels, each whole in one launch (k_level_inv_fused): the detail bands stay where the reconstruction put
+    // them (rb.A), a level's result - the next level's LL - alternates between rb.T and the descendant-maxima grid, which
+    // nothing reads between the SPIHT encoder and the next batch's analysis (A/B against the LDS-staged column + row passes,
+    // three alternating runs each: the residual layer + truncation phase of a slice 18.2 - 18.7 ms against 18.4 - 19.2)
+    const float *fine_ll = rb.A;
+    const bool finest_fused = ceil_div(g.nx >> 1, kFusePairs) * 8 <= kPartials && (g.nx >> 1) >= 2;   // (the stream form of the finest level reads rb.A and writes rb.T)
+    if (finest_fused && (long long) n_frames * 8 <= 65535) {
+        float *scratch[2] = {rb.T, reinterpret_cast<float *>(rb.D)};
+        const float *ll = rb.A;
+        int turn = 0;
+        for (int lv = g.stages - 1; lv >= 1; lv--) {
+            const int nx = g.nx >> lv, ny = g.ny >> lv;
+            const int lstrips = ceil_div(nx >> 1, kFusePairs), lpieces = std::max(1, std::min(8, (ny >> 1) / 16));
+            hipLaunchKernelGGL(k_level_inv_fused, dim3((unsigned) lstrips, (unsigned) (n_frames * lpieces)), dim3(64), 0, s, ll, rb.A, scratch[turn], g.nx, rb.np,
+                               nx, ny, d_active, lstrips, n_frames, lpieces);
+            ll = scratch[turn];
+            turn ^= 1;
+        }
+        fine_ll = ll;
+    } else {
+        for (int lv = g.stages - 1; lv >= 1; lv--) {
+            int nx = g.nx >> lv, ny = g.ny >> lv;
+            cols_pass<false>(rb.A, rb.T, rb, ny, nx, n_frames, d_active, s);
+            rows_inv(rb.T, rb.A, rb, nx, ny, n_frames, d_active, s);
+        }
     }
     int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
     while (pieces > 1 && (long long) n_frames * pieces > 65535) pieces--;                // (grid y)
@@ -1112,7 +1205,7 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
         //  probe round with 1, 571 with 4, 788 with 6, 898 with all 12, tools/gpu/kstat.sh)
         const int wave_cap = 1;
         const int wg = std::min(strips, wave_cap);
-        hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, rb.A, g, rb.np, rb.C, rb.sigord, rb.lspidx,
+        hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, fine_ll, g, rb.np, rb.C, rb.sigord, rb.lspidx,
                            d_trunc_bits, d_active, u, strips, n_frames, pieces);
         partials = strips * pieces;
     } else {

@@ -110,6 +110,15 @@ struct Contexts {
     T1_HD u64 &word() { if constexpr (W == 0) return w0; else if constexpr (W == 1) return w1; else return w2; }
     template <int W>
     T1_HD uint32_t get_in(int k) { return (uint32_t) (word<W>() >> (7 * k)) & 0x7Fu; }
+    // the same with the field's bit position (7 k) given: a context table can hold the position itself
+    template <int W>
+    T1_HD uint32_t get_at(int sh) { return (uint32_t) (word<W>() >> sh) & 0x7Fu; }
+    template <int W>
+    T1_HD void set_at(int sh, uint32_t v)
+    {
+        u64 &w = word<W>();
+        w = (w & ~(0x7Full << sh)) | ((u64) (v & 0x7Fu) << sh);
+    }
     template <int W>
     T1_HD void set_in(int k, uint32_t v)
     {
@@ -300,23 +309,26 @@ struct MqDecoder {
         } while (n);
     }
     template <int W>
-    T1_HD int decode_in(int k)
+    T1_HD int decode_in(int k) { return decode_at<W>(7 * k); }
+    // sh: bit position of the context's field in its word (7 x index inside the word)
+    template <int W>
+    T1_HD int decode_at(int sh)
     {
-        uint32_t st = cx.template get_in<W>(k);
+        uint32_t st = cx.template get_at<W>(sh);
         uint32_t e = tab((int) (st & 0x3F));
         uint32_t qe = e & 0xFFFF;
         int mps = st >> 6, d;
         a -= qe;
         if ((c >> 16) < qe) {
-            if (a < qe) { d = mps; cx.template set_in<W>(k, ((e >> 16) & 0x3F) | (mps << 6)); }
-            else { d = 1 - mps; if (e >> 28) mps ^= 1; cx.template set_in<W>(k, ((e >> 22) & 0x3F) | (mps << 6)); }
+            if (a < qe) { d = mps; cx.template set_at<W>(sh, ((e >> 16) & 0x3F) | (mps << 6)); }
+            else { d = 1 - mps; if (e >> 28) mps ^= 1; cx.template set_at<W>(sh, ((e >> 22) & 0x3F) | (mps << 6)); }
             a = qe;
             renorm();
         } else {
             c -= qe << 16;
             if ((a & 0x8000) == 0) {
-                if (a < qe) { d = 1 - mps; if (e >> 28) mps ^= 1; cx.template set_in<W>(k, ((e >> 22) & 0x3F) | (mps << 6)); }
-                else { d = mps; cx.template set_in<W>(k, ((e >> 16) & 0x3F) | (mps << 6)); }
+                if (a < qe) { d = 1 - mps; if (e >> 28) mps ^= 1; cx.template set_at<W>(sh, ((e >> 22) & 0x3F) | (mps << 6)); }
+                else { d = mps; cx.template set_at<W>(sh, ((e >> 16) & 0x3F) | (mps << 6)); }
                 renorm();
             } else {
                 d = mps;
@@ -347,6 +359,8 @@ struct MqDecoder {
     }
     T1_HD int decode_zc(int ctx) { return decode_in<0>(ctx - CTX_ZC0); }
     T1_HD int decode_sc(int ctx) { return decode_in<1>(ctx - 9); }
+    T1_HD int decode_zc_at(int sh) { return decode_at<0>(sh); }           // (a context policy with kFieldPositions hands these out)
+    T1_HD int decode_sc_at(int sh) { return decode_at<1>(sh); }
     T1_HD int decode_mag(int ctx) { return decode_in<1>(ctx - 9); }
     T1_HD int decode_agg() { return decode_in<1>(CTX_AGG - 9); }
     T1_HD int decode_uni() { return decode_in<2>(0); }
@@ -417,6 +431,7 @@ T1_HD uint32_t sc_index(uint32_t si, uint32_t ni)                        // si /
     return (((si >> 1) & 0x41u) | (((ni >> 1) & 0x41u) << 1)) | ((((si >> 3) & 5u) | (((ni >> 3) & 5u) << 1)) << 2);
 }
 struct DirectCtx {
+    static constexpr bool kFieldPositions = false;   // zc() / sc() return context numbers (a table policy may return 7 x (index in the word) instead)
     int orient = 0;
     T1_HD void bind(int o) { orient = o; }
     T1_HD int zc(uint32_t idx) const { return ctx_zc(idx & 7u, (idx >> 3) & 7u, (idx >> 6) & 7u, orient); }
@@ -537,6 +552,8 @@ struct Passes {
         if constexpr (ENC) {
             neg = (int) ((sp.sgn[R] >> x) & 1);
             mq.encode_sc(cx, neg ^ xb);
+        } else if constexpr (CtxP::kFieldPositions) {
+            neg = mq.decode_sc_at(cx) ^ xb;
         } else {
             neg = mq.decode_sc(cx) ^ xb;
         }
@@ -556,6 +573,7 @@ struct Passes {
         int cx = cp.zc(idx);
         int v;
         if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_zc(cx, v); }
+        else if constexpr (CtxP::kFieldPositions) v = mq.decode_zc_at(cx);
         else v = mq.decode_zc(cx);
         sp.vis[R] |= 1ull << x;
         if (v) { code_sign<R>(sp, sw, nw, have_n, x, y0, plane, true); return true; }
@@ -651,6 +669,7 @@ struct Passes {
         if (!skip_zc) {
             int cx = cp.zc(idx);
             if constexpr (ENC) { v = (int) ((bp >> x) & 1); mq.encode_zc(cx, v); }
+            else if constexpr (CtxP::kFieldPositions) v = mq.decode_zc_at(cx);
             else v = mq.decode_zc(cx);
         }
         if (v) code_sign<R>(sp, sw, nw, have_n, x, y0, plane, false);

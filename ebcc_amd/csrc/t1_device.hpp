@@ -43,6 +43,7 @@ __device__ inline void fill_mq_table_next(uint2 *tab_store)
 // and 2 share one) indexed by the nine window bits, 256 bytes of sign contexts (context | xor bit << 7) indexed by sc_index.
 struct LdsCtx {
     static constexpr int kBytes = 3 * 512 + 256;
+    static constexpr bool kFieldPositions = true;  // the tables hold 7 x (context's index in its word of t1::Contexts): no multiply per decision
     uint32_t base = 0, zc_tab = 0;                 // LDS byte addresses
     __device__ void bind(int orient) { zc_tab = base + 512u * (orient == 1 ? 1u : (orient == 3 ? 2u : 0u)); }
     __device__ int zc(uint32_t idx) const { return (int) *(const __attribute__((address_space(3))) uint8_t *) (uintptr_t) (zc_tab + idx); }
@@ -60,13 +61,13 @@ inline void make_ctx_tables(uint8_t *store)
     for (int i = 0; i < 1536; i++) {
         t1::DirectCtx d;
         d.bind(i < 512 ? 0 : (i < 1024 ? 1 : 3));
-        store[i] = (uint8_t) d.zc((uint32_t) i & 511u);
+        store[i] = (uint8_t) (7 * (d.zc((uint32_t) i & 511u) - t1::CTX_ZC0));
     }
     for (int i = 0; i < 256; i++) {
         t1::DirectCtx d;
         int xb = 0;
         const int c = d.sc((uint32_t) i, xb);
-        store[1536 + i] = (uint8_t) (c | (xb << 7));
+        store[1536 + i] = (uint8_t) ((7 * (c - 9)) | (xb << 7));
     }
 }
 __device__ inline void copy_ctx_tables(uint8_t *lds, const uint8_t *global, int tid, int nthreads)

@@ -126,6 +126,20 @@ __device__ inline uint32_t wave_prefix_sum(uint32_t x)
     return (uint32_t) v;
 }
 
+// Maximum over the 64 lanes of a wave (non-negative values) by DPP, the result in every lane's copy of lane 63's value: the
+// same ladder as the prefix sum - no trip through the LDS crossbar.  Every lane must be active.
+__device__ inline int wave_max_nonneg(int x)
+{
+    int v = x;
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false));                  // row_shr:1 (0 where no lane is)
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false));                  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false));                  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false));                  // row_shr:8: lane 15 of a row holds the row's maximum
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));                  // rows 1, 3: the row below's lane 15
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));                  // rows 2, 3: lane 31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Monotone key for float ordering with -0 == +0 (reference compares with < and >, so the two
 // zeros tie; ties are then broken by index to reproduce "first occurrence wins").
 __host__ __device__ inline uint32_t float_order_key(float f)

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
                                                    unsigned long long *__restrict__ SUF, int *__restrict__ blkmax, const J2kGeom *geom, const J2kBlock *blocks,
                                                    const FrameState *fs, int total)
 {
-    __shared__ unsigned long long m[kQuantMasks][64];                   // [mask][code-block of the group]
+    __shared__ __attribute__((aligned(16))) unsigned long long m[kQuantMasks][64];   // [mask][code-block of the group]
     __shared__ int smax[64];
     // the 64 code-blocks of the group: element offset of (0, 0) in B / Q6 (-1: none), extent, row pitch, step size
     __shared__ long long s_base[64];
@@ -952,12 +952,11 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
                 Q6[s_base[k] + (long long) row * s_pitch[k] + lane] = q6;
             }
             const int a6 = q6 < 0 ? -q6 : q6;
-            int mx = a6;
-            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+            const int mx = wave_max_nonneg(a6);                          // (DPP: six shuffles through the LDS crossbar before)
             const unsigned long long sgn = __ballot(q6 < 0);
             const int a = a6 >> 6;
             // planes above the row's top magnitude bit are empty: no ballots for them
-            const int top = __builtin_amdgcn_readfirstlane(mx) >> 6, p_top = top ? 32 - __builtin_clz(top) : 0;
+            const int top = mx >> 6, p_top = top ? 32 - __builtin_clz(top) : 0;
             if (lane < kJ2kMaxPlanes && lane >= p_top) { m[lane][k] = 0; m[kJ2kMaxPlanes + 1 + lane][k] = 0; }
             unsigned long long suf = 0;                                  // OR of the planes >= p: "some bit at or above p"
             if (lane == 0) {
@@ -973,12 +972,14 @@ __global__ __launch_bounds__(256) void k_quantize(const float *__restrict__ B, i
             }
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < kQuantMasks * 64; t += 256) {
-            const int i = t >> 6, k = t & 63;
-            const unsigned long long v = m[i][k];
-            if (i < kJ2kMaxPlanes) bp[((size_t) i * 64 + row) * 64 + k] = v;
-            else if (i == kJ2kMaxPlanes) sg[(size_t) row * 64 + k] = v;
-            else su[((size_t) (i - kJ2kMaxPlanes - 1) * 64 + row) * 64 + k] = v;
+        // the 55 lines of this row index leave as 16-byte pieces: 32 lanes per line of 512 bytes
+        for (int t = threadIdx.x; t < kQuantMasks * 32; t += 256) {
+            const int i = t >> 5, k2 = (t & 31) * 2;
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(&m[i][k2]);
+            unsigned long long *line = i < kJ2kMaxPlanes ? bp + ((size_t) i * 64 + row) * 64
+                                     : (i == kJ2kMaxPlanes ? sg + (size_t) row * 64 : su + ((size_t) (i - kJ2kMaxPlanes - 1) * 64 + row) * 64);
+            *reinterpret_cast<u64x2 *>(line + k2) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -1479,20 +1480,27 @@ __global__ __launch_bounds__(256) void k_distortion(const int32_t *__restrict__ 
         nms[threadIdx.x * kCopies] = sum;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // every pass's weighted distortion on its own thread (the same double expressions), then one thread adds them up in pass
+    // order - the running sum's roundings are the reference's - and all threads store: the tail used to be one thread's
+    // loop of ~40 passes with three dependent double operations and a store each
+    __shared__ double wms[kJ2kMaxPasses];
+    if ((int) threadIdx.x < np) {
+        const int p = (int) threadIdx.x;
         const J2kBand &bd = geom->bands[blk.band];
         const int log2_gain = bd.orient == 0 ? 0 : (bd.orient == 3 ? 2 : 1);
         const double st = (double) bd.step_enc / (double) (1 << log2_gain);   // opj_t1_getwmsedec: step without the gain
-        double cum = 0;
-        int bp = P - 1, passtype = 2;
-        for (int p = 0; p < np; p++) {
-            double wm = ((1.0 * bd.norm) * st) * (double) (1 << bp);
-            wm = wm * ((wm * (double) nms[p * kCopies]) / 8192.0);
-            cum += wm;
-            disto[(size_t) gid * kJ2kMaxPasses + p] = cum;
-            if (++passtype == 3) { passtype = 0; bp--; }
-        }
+        const int bp = t1::plane_of_pass(P, p);
+        double wm = ((1.0 * bd.norm) * st) * (double) (1 << bp);
+        wm = wm * ((wm * (double) nms[p * kCopies]) / 8192.0);
+        wms[p] = wm;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double cum = 0;
+        for (int p = 0; p < np; p++) { cum += wms[p]; wms[p] = cum; }
+    }
+    __syncthreads();
+    if ((int) threadIdx.x < np) disto[(size_t) gid * kJ2kMaxPasses + threadIdx.x] = wms[threadIdx.x];
 }
 
 

@@ -134,6 +134,58 @@ void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const 
     wait_stream(s);
 }
 
+void stage_area_free(StageArea &a)
+{
+    if (a.h) hipHostFree(a.h);
+    if (a.d) hipFree(a.d);
+    if (a.h_pack) hipHostFree(a.h_pack);
+    if (a.d_pack) hipFree(a.d_pack);
+    a = StageArea{};
+}
+
+void stage_download_async(ebcc_hip_ctx *ctx, StageArea &a, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s, bool copy_now)
+{
+    a.packed = 0;
+    if (a.pack_cap < 2 * n) {
+        if (a.h_pack) hipHostFree(a.h_pack);
+        if (a.d_pack) hipFree(a.d_pack);
+        a.h_pack = nullptr; a.d_pack = nullptr; a.pack_cap = 0;
+        const size_t cap = 2 * std::max(n, ctx->max_frames);
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &a.h_pack, cap * sizeof(unsigned long long)));
+        EBCC_HIP_CHECK(device_malloc((void **) &a.d_pack, cap * sizeof(unsigned long long)));
+        a.pack_cap = cap;
+    }
+    size_t total = 0;
+    for (size_t f = 0; f < n; f++) {
+        off[f] = total;
+        a.h_pack[2 * f] = total; a.h_pack[2 * f + 1] = len[f];
+        total += (len[f] + 15) & ~(size_t) 15;
+    }
+    if (!total) return;
+    if (total > a.cap) {
+        if (a.h) hipHostFree(a.h);
+        if (a.d) hipFree(a.d);
+        a.h = nullptr; a.d = nullptr; a.cap = 0;
+        const size_t cap = total + total / 2 + 4096;
+        uint8_t *h_new = nullptr, *d_new = nullptr;
+        EBCC_HIP_CHECK(hipHostMalloc((void **) &h_new, cap));
+        const hipError_t e = device_malloc((void **) &d_new, cap);
+        if (e != hipSuccess) { hipHostFree(h_new); EBCC_HIP_CHECK(e); }
+        a.h = h_new; a.d = d_new; a.cap = cap;
+    }
+    a.packed = total;
+    EBCC_HIP_CHECK(hipMemcpyAsync(a.d_pack, a.h_pack, 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_stage, dim3((unsigned) n, 4), dim3(256), 0, s, const_cast<uint8_t *>(src), stride, a.d_pack, a.d, 1);
+    if (copy_now) EBCC_HIP_CHECK(hipMemcpyAsync(a.h, a.d, total, hipMemcpyDeviceToHost, s));
+}
+
+void stage_area_fetch(StageArea &a, hipStream_t s)
+{
+    if (!a.packed) return;
+    EBCC_HIP_CHECK(hipMemcpyAsync(a.h, a.d, a.packed, hipMemcpyDeviceToHost, s));
+    wait_stream(s);
+}
+
 void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m) { stage_layout(ctx, len, off, m); }
 
 void stage_send(ebcc_hip_ctx *ctx, size_t m, hipStream_t s)
@@ -294,6 +346,7 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, 2 * max_frames)) != nullptr;      // (second half: the overlapped search's mask)
     ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 4 * max_frames)) != nullptr;
+    ok &= (ctx->d_active3 = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_search = ctx_alloc<uint8_t>(ctx, 2 * sizeof(DevChunk) * max_frames)) != nullptr;   // (second half: the overlapped search)
     ok &= (ctx->d_counter = (int *) ctx_alloc<uint32_t>(ctx, 8)) != nullptr;
     if (ok) {
@@ -304,7 +357,7 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 4 * max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_act, 2 * max_frames * sizeof(int)));
-        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, 2 * sizeof(DevChunk) * max_frames));
+        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, 4 * sizeof(DevChunk) * max_frames));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_counter, 8 * sizeof(int)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
@@ -348,10 +401,15 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_table) hipHostFree(ctx->h_table);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->d_stage) hipFree(ctx->d_stage);
+    for (StageArea &a : ctx->aux_stage) ebcc::stage_area_free(a);
     if (ctx->d_io) hipFree(ctx->d_io);
     if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
+    if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
+    if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
+    if (ctx->stream3) hipStreamDestroy(ctx->stream3);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     EBCC_API_CATCH_VOID

@@ -836,8 +836,12 @@ int search_rounds()
     return 16;
 }
 constexpr int kSearchAll = 0, kSearchStart = 1, kSearchFinish = 2;
+// snap_dst / snap_event (kSearchStart only): after a few rounds the states are copied to snap_dst (pinned) and the event is
+// recorded behind the copy - a look at the search in mid-flight for whoever wants to guess where it is heading.
+constexpr int kSnapshotAfterRounds = 5;
 template <class Jobs>
-void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices, int lane = 0, int part = kSearchAll)
+void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices, int lane = 0, int part = kSearchAll,
+                        DevChunk *snap_dst = nullptr, hipEvent_t snap_event = nullptr)
 {
     // lane 1: the search runs on the engine's second stream with its own state, counters and active mask, beside whatever
     // the first stream does (search #2 beside the residual layer).  part: enqueue the first batch of rounds only
@@ -913,7 +917,15 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
         EBCC_HIP_CHECK(hipMemsetAsync(jb.have_rate, 0, sizeof(int) * b.nt, s));
     }
     advance();
-    enqueue_rounds(search_rounds());
+    if (snap_dst && part == kSearchStart) {
+        const int before = std::min(kSnapshotAfterRounds, search_rounds());
+        enqueue_rounds(before);
+        EBCC_HIP_CHECK(hipMemcpyAsync(snap_dst, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
+        EBCC_HIP_CHECK(hipEventRecord(snap_event, s));
+        enqueue_rounds(search_rounds() - before);
+    } else {
+        enqueue_rounds(search_rounds());
+    }
     }
     if (part == kSearchStart) return;
     if (speculate && !s2) s2 = second_stream(ctx);
@@ -1078,7 +1090,12 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
         }
         pt.mark("rate search 1");
-        b.collect_tails(jobs);                                                                // base layer of search #1
+        if (!ctx->ev_d) EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
+        if (!ctx->ev_e) EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming | hipEventBlockingSync));
+        // base layer of search #1.  (Sending the codestreams off without waiting for them - written and packed on the second
+        // search's stream, fetched at the assembly - was measured: the slice's next stages are queued 2 ms earlier and the step
+        // gets 1 - 5 ms LONGER, three alternating runs on two boxes; the wait stays.)
+        b.collect_tails(jobs);
         auto start_search2 = [&]() {
             for (size_t f = 0; f < n; f++) {
                 if (jobs[f].const_field) continue;
@@ -1097,11 +1114,19 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             ebcc_hip_ctx *c; bool armed;
             ~DrainSecond() { if (armed && c->stream2) hipStreamSynchronize(c->stream2); }
         } drain2{ctx, false};
+        DevChunk *snap2 = nullptr;
         if (overlap2) {
             start_search2();
-            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart);
+            if (!getenv("EBCC_HIP_NO_SNAPSHOT")) snap2 = static_cast<DevChunk *>(ctx->h_search) + 3 * ctx->max_frames;
+            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart, snap2, ctx->ev_e);
             drain2.armed = true;
         }
+        // the second search a few rounds in (null: it does not run beside the residual layer)
+        auto search2_snapshot = [&]() -> const DevChunk * {
+            if (!snap2) return nullptr;
+            EBCC_HIP_CHECK(hipEventSynchronize(ctx->ev_e));
+            return snap2;
+        };
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
         fetch_frame_states(rc, n);
         bool any_resid = false;
@@ -1116,6 +1141,70 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         }
         pt.mark("tails + residual range");
 
+        if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+        // ---- the entropy stage's state (the stage itself follows the truncation search; the frames whose search ends first
+        //      - the early group, below - enter it while the others still search).
+        //      jobs on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so the host is never
+        //      oversubscribed however many slices run
+        std::vector<const uint8_t *> coeff_ptr(n, nullptr);             // the kept prefix of a frame in pinned host memory
+        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0}, bound_us{0};    // core time, longest job, bytes
+        enum : uint8_t { kZNone = 0, kZQueued = 1, kZRunning = 2, kZSkipped = 3 };
+        std::unique_ptr<std::atomic<uint8_t>[]> zstate(new std::atomic<uint8_t>[n]);
+        for (size_t f = 0; f < n; f++) zstate[f] = kZNone;
+        std::vector<size_t> zfloor(n, 0);                               // lower bound of z (0: none)
+        std::vector<char> floor_done(n, 0);
+        using PoolBatches = std::vector<std::shared_ptr<HostPool::Batch>>;
+        PoolBatches zbatches, fbatches;                                 // level-22 jobs; lower bounds
+        struct WaitOnExit { PoolBatches &v; ~WaitOnExit() { for (auto &b : v) if (b) b->wait(); } } wait_on_exit{zbatches}, wait_on_exit_f{fbatches};   // (error paths too: the jobs point into this frame)
+        // level-22 zstd of the frames in `list`, in the order given; a frame that was decided in the meantime (kZSkipped)
+        // is passed over
+        auto submit_zstd = [&](std::vector<size_t> list) {
+            for (size_t f : list) zstate[f] = kZQueued;
+            auto order = std::make_shared<std::vector<size_t>>(std::move(list));
+            zbatches.push_back(HostPool::instance().submit(order->size(), entropy_threads(slices), [&, order](size_t i) {
+                const size_t f = (*order)[i];
+                uint8_t expect = kZQueued;
+                if (!zstate[f].compare_exchange_strong(expect, kZRunning)) return;
+                Job &j = jobs[f];
+                const auto z0 = std::chrono::steady_clock::now();
+                j.zbytes.resize(zstd().bound(j.coeffs_size));
+                const size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_ptr[f], j.coeffs_size, env.zstd_level);
+                if ((zstd().is_error && zstd().is_error(z)) || z > j.zbytes.size()) throw std::runtime_error("ZSTD_compress failed on a residual prefix");
+                j.zbytes.resize(z);
+                const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+                zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
+                long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
+            }));
+        };
+        // the lower bounds of z for the frames in `list` (zstd_size_lower_bound)
+        auto submit_floors = [&](const std::vector<size_t> &frames_) {
+            auto list = std::make_shared<std::vector<size_t>>(frames_);
+            fbatches.push_back(HostPool::instance().submit(list->size(), entropy_threads(slices), [&, list](size_t i) {
+                const size_t f = (*list)[i];
+                const auto z0 = std::chrono::steady_clock::now();
+                zfloor[f] = zstd_size_lower_bound(coeff_ptr[f], jobs[f].coeffs_size);
+                floor_done[f] = 1;
+                bound_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+            }));
+        };
+        // longest first: level 22 takes ~0.2 ms per KB on one core and a batch has frames whose prefix is ten times the
+        // average - started last, such a frame alone decides when the slice can go on
+        auto longest_first = [&](std::vector<size_t> &list) {
+            std::stable_sort(list.begin(), list.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
+        };
+        long long wait_us = 0;
+        auto join = [&](PoolBatches &v) -> bool {
+            const auto w0 = std::chrono::steady_clock::now();
+            bool ok = true;
+            std::string why;
+            for (auto &b : v) if (b && !b->wait()) { ok = false; if (why.empty()) why = b->error; }
+            v.clear();
+            wait_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count();
+            if (!ok) { log_fatal("entropy stage failed: %s", why.c_str()); set_error("%s", why.c_str()); }
+            return ok;
+        };
+        auto zjoin = [&]() -> bool { const bool a = join(fbatches), c = join(zbatches); return a && c; };
+        const bool use_floor = want_pure && zstd_floor_usable() && !getenv("EBCC_HIP_NO_SHORTCUTS");
         if (any_resid) {
             // ---- residual layer: SPIHT with a budget of the base layer's size (:744-754)
             b.push_ractive();
@@ -1174,26 +1263,150 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 }
                 EBCC_HIP_CHECK(hipMemcpyAsync(d, h, sizeof(DevChunk) * n, hipMemcpyHostToDevice, rs));
                 EBCC_HIP_CHECK(hipMemsetAsync(rc->d_counter, 0, sizeof(int) * 4, rs));
-                int rounds = getenv("EBCC_HIP_SEARCH_ROUNDS") ? search_rounds() : 18;
+                // rounds a chunk can still need: a cut halves the interval (rounded up to a byte: + 8 bits at most) until it is
+                // 32 bits wide (:777), then one more advance sees that nothing is left
+                auto rounds_left = [](const DevChunk &c) {
+                    if (!c.trunc_active) return 0;
+                    double w = c.t_hi - c.t_lo;
+                    int r = 1;
+                    while (w > 32 && r < 64) { w = w / 2 + 8; r++; }
+                    return r;
+                };
+                const bool forced_rounds = getenv("EBCC_HIP_SEARCH_ROUNDS") != nullptr;
+                auto rounds_for = [&](const DevChunk *st, auto member) {
+                    if (forced_rounds) return search_rounds();
+                    int r = 1;
+                    for (size_t f = 0; f < n; f++) if (member(f)) r = std::max(r, rounds_left(st[f]));
+                    return r;
+                };
+                // `rounds` rounds of the chunks of one group (null: all) on stream `on` with the mask `mask`, then their states
+                // into `mirror`; repeated while one of them is still searching
+                auto run_rounds = [&](hipStream_t on, int *mask, const int *group, int which, int rounds, DevChunk *mirror, auto member) {
+                    for (;;) {
+                        for (int r = 0; r < rounds; r++) {
+                            launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, mask, on);
+                            launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, mask, (int) n, (double) n_pix, rc->d_counter, on, group, which);
+                        }
+                        EBCC_HIP_CHECK(hipMemcpyAsync(mirror, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, on));
+                        wait_stream(on);
+                        bool done = true;
+                        for (size_t f = 0; f < n; f++) if (member(f)) done &= !mirror[f].trunc_active;
+                        if (done) break;
+                        rounds = 6;
+                    }
+                };
+                auto take_result = [&](const DevChunk &c, Job &j) {
+                    j.t_hi = c.t_hi; j.t_lo = c.t_lo; j.t_best = c.t_best; j.mean_err = c.mean_err; j.best_err = c.best_err;
+                    j.trunc_active = false;
+                };
+                const auto everyone = [](size_t) { return true; };
                 launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
-                for (;;) {
-                    for (int r = 0; r < rounds; r++) {
+                // ---- The early group.  The level-22 zstd of the longest kept prefixes is the slice's last and longest host job
+                //      (15 - 30 ms for 60 - 100 KB on one core) and could only start when EVERY frame's search had ended.  A few
+                //      rounds tell which frames keep the longest prefixes (the kept length lies above t_lo): those go on on a
+                //      stream of their own - a dozen frames per round instead of the slice's, a third of the time - and their
+                //      prefixes are downloaded, bounded and (where the bound does not already decide for the pure base layer)
+                //      handed to the workers while the other frames are still searching.  Same cuts, same results: a chunk's
+                //      search does not depend on which stream runs its rounds.
+                const int split_after = getenv("EBCC_HIP_EARLY_ROUNDS") ? std::max(1, atoi(getenv("EBCC_HIP_EARLY_ROUNDS"))) : 3;
+                const bool early_ok = tiles == 1 && rc == ctx && n >= 12 && !getenv("EBCC_HIP_NO_EARLY_GROUP");
+                std::vector<char> in_early(n, 0);
+                bool split = false;
+                if (early_ok) {
+                    for (int r = 0; r < split_after; r++) {
                         launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
                         launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                     }
                     EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
                     wait_stream(rs);
-                    bool done = true;
-                    for (size_t f = 0; f < n; f++) done &= !h[f].trunc_active;
-                    if (done) break;
-                    rounds = 6;
+                    std::vector<size_t> open;
+                    for (size_t f = 0; f < n; f++) if (h[f].trunc_active) open.push_back(f);
+                    const size_t k = std::min<size_t>(16, std::max<size_t>(2, open.size() / 6));
+                    if (open.size() >= 12) {
+                        std::stable_sort(open.begin(), open.end(), [&](size_t a, size_t c) { return h[a].t_lo > h[c].t_lo; });
+                        for (size_t i = 0; i < k; i++) in_early[open[i]] = 1;
+                        split = true;
+                    }
                 }
-                for (size_t f = 0; f < n; f++) {
-                    Job &j = jobs[f];
-                    if (!j.trunc_active) continue;
-                    const DevChunk &c = h[f];
-                    j.t_hi = c.t_hi; j.t_lo = c.t_lo; j.t_best = c.t_best; j.mean_err = c.mean_err; j.best_err = c.best_err;
-                    j.trunc_active = false;
+                if (!split) {
+                    run_rounds(rs, rc->d_active, nullptr, 0, rounds_for(h, everyone), h, everyone);
+                    for (size_t f = 0; f < n; f++) if (jobs[f].trunc_active) take_result(h[f], jobs[f]);
+                } else {
+                    int *const h_group = reinterpret_cast<int *>(rc->h_u64c), *const d_group = reinterpret_cast<int *>(rc->d_u64c);
+                    for (size_t f = 0; f < n; f++) h_group[f] = in_early[f];
+                    if (!rc->stream3) {
+                        int lo_p = 0, hi_p = 0;
+                        EBCC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));   // (hi_p: numerically lowest = most urgent)
+                        EBCC_HIP_CHECK(hipStreamCreateWithPriority(&rc->stream3, hipStreamNonBlocking, hi_p));
+                    }
+                    hipStream_t s3 = rc->stream3;
+                    DevChunk *const hA = static_cast<DevChunk *>(rc->h_search) + 2 * rc->max_frames;
+                    EBCC_HIP_CHECK(hipMemcpyAsync(d_group, h_group, sizeof(int) * n, hipMemcpyHostToDevice, rs));
+                    launch_trunc_split(d_group, rc->d_active, rc->d_active3, (int) n, rs);
+                    EBCC_HIP_CHECK(hipEventRecord(ctx->ev_d, rs));
+                    EBCC_HIP_CHECK(hipStreamWaitEvent(s3, ctx->ev_d, 0));
+                    const auto early = [&](size_t f) { return in_early[f] != 0; };
+                    const auto late = [&](size_t f) { return in_early[f] == 0; };
+                    // the others' rounds are queued first (their stream is never left empty), then the early group is seen through
+                    const int rounds_late = rounds_for(h, late);
+                    for (int r = 0; r < rounds_late; r++) {
+                        launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
+                        launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs, d_group, 0);
+                    }
+                    pt.mark("truncation: first rounds, split");
+                    run_rounds(s3, rc->d_active3, d_group, 1, rounds_for(h, early), hA, early);
+                    pt.mark("truncation: early group's rounds");
+                    std::vector<size_t> group;
+                    std::vector<size_t> len(n, 0), off(n, 0);
+                    for (size_t f = 0; f < n; f++) {
+                        if (!in_early[f]) continue;
+                        Job &j = jobs[f];
+                        take_result(hA[f], j);
+                        j.coeffs_size = (size_t) (j.t_best / 8.);                             // :796
+                        if (j.coeffs_size <= 16) j.coeffs_size = 0;                           // :811
+                        if (j.coeffs_size) { len[f] = j.coeffs_size; group.push_back(f); }
+                    }
+                    if (!group.empty()) {
+                        stage_download_async(rc, rc->aux_stage[1], (const uint8_t *) rc->rb.stream, rc->rb.stream_words * sizeof(uint32_t), len.data(), off.data(), n, s3);
+                        wait_stream(s3);
+                        for (size_t f : group) coeff_ptr[f] = rc->aux_stage[1].h + off[f];
+                        std::vector<size_t> go = group;
+                        if (want_pure) {
+                            // A bound that already says "the pure base layer wins" spares the job; whether it does depends on
+                            // len2, which the second rate search (on its own stream since the first one ended) has not delivered
+                            // yet - but its bracket has: len2 is at most the size of the probe at its lower end.  That is an
+                            // ESTIMATE used for nothing but the decision to start now; :838 is decided below from the final sizes.
+                            go.clear();
+                            std::vector<size_t> bounded;
+                            for (size_t f : group) if (use_floor && jobs[f].coeffs_size <= kZstdFloorMaxBytes) bounded.push_back(f); else go.push_back(f);
+                            if (!bounded.empty()) {
+                                submit_floors(bounded);
+                                if (!join(fbatches)) return 1;
+                                const DevChunk *snap = search2_snapshot();
+                                for (size_t f : bounded) {
+                                    double x_max = HUGE_VAL;                                  // len2 - len1 is at most this (probably)
+                                    if (snap) {
+                                        const DevRateSearch &R = snap[f].rs[1];
+                                        if (R.phase >= 2)
+                                            for (int i = 0; i < snap[f].n_probes; i++)
+                                                if (snap[f].probes[i].cr == R.lo) x_max = (double) snap[f].probes[i].stream_bytes - (double) jobs[f].len1;
+                                    }
+                                    if (!(zfloor[f] > 0 && x_max < (double) zfloor[f])) go.push_back(f);
+                                }
+                            }
+                        }
+                        longest_first(go);
+                        if (!go.empty()) submit_zstd(go);
+                        if (pt.on) fprintf(stderr, "ebcc-mi355x early group: %zu frames, %zu prefixes, %zu compressed ahead\n", (size_t) std::count(in_early.begin(), in_early.end(), 1), group.size(), go.size());
+                    }
+                    pt.mark("truncation: early group off to the workers");
+                    // the others
+                    EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
+                    wait_stream(rs);
+                    bool late_done = true;
+                    for (size_t f = 0; f < n; f++) if (!in_early[f]) late_done &= !h[f].trunc_active;
+                    if (!late_done) run_rounds(rs, rc->d_active, d_group, 0, 6, h, late);
+                    for (size_t f = 0; f < n; f++) if (!in_early[f] && jobs[f].trunc_active) take_result(h[f], jobs[f]);
                 }
             } else
             for (;;) {
@@ -1241,69 +1454,28 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         //      ~95 % of ERA5-like frames the base layer alone wins.  So z is only worked out where it can matter: a frame
         //      whose z is PROVABLY above len2 - len1 (zstd_size_lower_bound: the literals no match can cover cost at least
         //      their entropy) takes the pure base layer without being compressed - the same decision, bytes unchanged.
-        if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
-        // the kept SPIHT prefixes of the batch in one packed download; the workers read them where they land (the staging
-        // buffer of the residual engine is not touched again before they are done)
+        // the kept SPIHT prefixes of the batch (but those of the early group, which left during the truncation search) in one
+        // packed download; the workers read them where they land (the staging buffer of the residual engine is not touched
+        // again before they are done)
         std::vector<size_t> coeff_len(n, 0), coeff_off(n, 0);
         for (size_t f = 0; f < n; f++) {
             Job &j = jobs[f];
             if (j.coeffs_size <= 16) j.coeffs_size = 0;
-            coeff_len[f] = j.coeffs_size;
+            if (!coeff_ptr[f]) coeff_len[f] = j.coeffs_size;
         }
         stage_download(rc, (const uint8_t *) rc->rb.stream, rc->rb.stream_words * sizeof(uint32_t), coeff_len.data(), coeff_off.data(), n, rs);
-        const uint8_t *const coeff_base = rc->h_stage;
-        // jobs on the process-wide pool (HostPool): every slice of a batch feeds the same workers, so the host is never
-        // oversubscribed however many slices run
-        std::atomic<long long> zstd_us{0}, zstd_max_us{0}, zstd_bytes{0}, bound_us{0};    // core time, longest job, bytes
-        enum : uint8_t { kZNone = 0, kZQueued = 1, kZRunning = 2, kZSkipped = 3 };
-        std::unique_ptr<std::atomic<uint8_t>[]> zstate(new std::atomic<uint8_t>[n]);
-        for (size_t f = 0; f < n; f++) zstate[f] = kZNone;
-        std::vector<size_t> zfloor(n, 0);                               // lower bound of z (0: none)
-        std::vector<std::shared_ptr<HostPool::Batch>> zbatches;
-        struct WaitOnExit { std::vector<std::shared_ptr<HostPool::Batch>> &v; ~WaitOnExit() { for (auto &b : v) if (b) b->wait(); } } wait_on_exit{zbatches};   // (error paths too: the jobs point into this frame)
-        // level-22 zstd of the frames in `list`, in the order given; a frame that was decided in the meantime (kZSkipped)
-        // is passed over
-        auto submit_zstd = [&](std::vector<size_t> list) {
-            for (size_t f : list) zstate[f] = kZQueued;
-            auto order = std::make_shared<std::vector<size_t>>(std::move(list));
-            zbatches.push_back(HostPool::instance().submit(order->size(), entropy_threads(slices), [&, order](size_t i) {
-                const size_t f = (*order)[i];
-                uint8_t expect = kZQueued;
-                if (!zstate[f].compare_exchange_strong(expect, kZRunning)) return;
-                Job &j = jobs[f];
-                const auto z0 = std::chrono::steady_clock::now();
-                j.zbytes.resize(zstd().bound(j.coeffs_size));
-                const size_t z = zstd().compress(j.zbytes.data(), j.zbytes.size(), coeff_base + coeff_off[f], j.coeffs_size, env.zstd_level);
-                if ((zstd().is_error && zstd().is_error(z)) || z > j.zbytes.size()) throw std::runtime_error("ZSTD_compress failed on a residual prefix");
-                j.zbytes.resize(z);
-                const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
-                zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
-                long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
-            }));
-        };
-        // longest first: level 22 takes ~0.2 ms per KB on one core and a batch has frames whose prefix is ten times the
-        // average - started last, such a frame alone decides when the slice can go on
-        auto longest_first = [&](std::vector<size_t> &list) {
-            std::stable_sort(list.begin(), list.end(), [&](size_t a, size_t c) { return jobs[a].coeffs_size > jobs[c].coeffs_size; });
-        };
-        long long wait_us = 0;
-        auto zjoin = [&]() -> bool {
-            const auto w0 = std::chrono::steady_clock::now();
-            bool ok = true;
-            std::string why;
-            for (auto &b : zbatches) if (b && !b->wait()) { ok = false; if (why.empty()) why = b->error; }
-            zbatches.clear();
-            wait_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - w0).count();
-            if (!ok) { log_fatal("entropy stage failed: %s", why.c_str()); set_error("%s", why.c_str()); }
-            return ok;
-        };
+        for (size_t f = 0; f < n; f++) if (coeff_len[f]) coeff_ptr[f] = rc->h_stage + coeff_off[f];
         std::vector<size_t> with_prefix;
         for (size_t f = 0; f < n; f++) if (jobs[f].coeffs_size > 0) with_prefix.push_back(f);
-        const bool use_floor = want_pure && zstd_floor_usable() && !getenv("EBCC_HIP_NO_SHORTCUTS");
         std::vector<size_t> cand;
+        auto not_started = [&](std::vector<size_t> v) {                 // (the early group's jobs are on their way)
+            v.erase(std::remove_if(v.begin(), v.end(), [&](size_t f) { return zstate[f] != kZNone; }), v.end());
+            return v;
+        };
         if (!want_pure) {
-            longest_first(with_prefix);
-            submit_zstd(with_prefix);                                   // no fallback: every prefix is part of its stream
+            std::vector<size_t> rest = not_started(with_prefix);
+            longest_first(rest);
+            submit_zstd(rest);                                          // no fallback: every prefix is part of its stream
         } else {
             // frames whose residual layer could not reach the target are coded by the base layer whatever z is (:838 need_pure)
             std::vector<size_t> now;
@@ -1311,17 +1483,12 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 if (jobs[f].need_pure) { zstate[f] = kZSkipped; continue; }
                 if (use_floor && jobs[f].coeffs_size <= kZstdFloorMaxBytes) cand.push_back(f); else now.push_back(f);
             }
+            now = not_started(now);
             longest_first(now);
             if (!now.empty()) submit_zstd(now);
-            if (!cand.empty()) {
-                auto list = std::make_shared<std::vector<size_t>>(cand);
-                zbatches.push_back(HostPool::instance().submit(list->size(), entropy_threads(slices), [&, list](size_t i) {
-                    const size_t f = (*list)[i];
-                    const auto z0 = std::chrono::steady_clock::now();
-                    zfloor[f] = zstd_size_lower_bound(coeff_base + coeff_off[f], jobs[f].coeffs_size);
-                    bound_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
-                }));
-            }
+            std::vector<size_t> want_floor;
+            for (size_t f : cand) if (!floor_done[f]) want_floor.push_back(f);
+            if (!want_floor.empty()) submit_floors(want_floor);
         }
         pt.mark("zstd: queued");
         if (want_pure) {
@@ -1339,13 +1506,13 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 drain2.armed = false;
                 pt.mark("rate search 2");
                 gpu_phase_over.tell();                                                        // (what follows is host work and one small launch)
-                if (!zjoin()) return 1;                                                       // (the floors)
+                if (!join(fbatches)) return 1;                                                // (the floors)
             } else {
                 start_search2();
                 if (!host_loop) device_rate_search(b, 1, jobs, n_pix, slices, 0, kSearchStart);
                 if (!cand.empty()) {
-                    if (!zjoin()) return 1;                                                   // (the floors - and with them the prefixes too long for one)
-                    std::vector<size_t> spec = cand;
+                    if (!join(fbatches)) return 1;                                            // (the floors)
+                    std::vector<size_t> spec = not_started(cand);
                     std::stable_sort(spec.begin(), spec.end(), [&](size_t a, size_t c) {
                         return (double) zfloor[a] * (double) jobs[c].coeffs_size < (double) zfloor[c] * (double) jobs[a].coeffs_size; });
                     submit_zstd(spec);
@@ -1360,8 +1527,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 const size_t len2 = (size_t) j.last[1].stream_bytes;
                 // z >= zfloor: len2 < zfloor + len1 implies len2 < z + len1 - the base layer alone wins (:838)
                 if (!(zfloor[f] > 0 && len2 < zfloor[f] + j.len1)) continue;
-                uint8_t expect = overlap2 ? kZNone : kZQueued;
-                if (zstate[f].compare_exchange_strong(expect, kZSkipped)) { skipped++; skipped_bytes += (long long) j.coeffs_size; }
+                // (decided before a worker took it up: not queued yet, or queued - by the early group or the speculative list)
+                uint8_t expect = kZNone;
+                bool struck = zstate[f].compare_exchange_strong(expect, kZSkipped);
+                if (!struck) { expect = kZQueued; struck = zstate[f].compare_exchange_strong(expect, kZSkipped); }
+                if (struck) { skipped++; skipped_bytes += (long long) j.coeffs_size; }
             }
             if (overlap2) {
                 std::vector<size_t> open;

@@ -170,10 +170,13 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
 
 // ---- :765-796 ------------------------------------------------------------------------------------------
 __global__ void k_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *active, int n_chunks,
-                                double n_pix, int *unfinished)
+                                double n_pix, int *unfinished, const int *group, int which)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_chunks) return;
+    // the frames of the other group belong to another stream's rounds (their state may be changing right now): not one of
+    // their words is read or written, only this group's mask says "not mine"
+    if (group && group[f] != which) { active[f] = 0; return; }
     DevChunk &C = chunks[f];
     if (!C.trunc_active) { active[f] = 0; return; }
     if (C.trunc_pending) {
@@ -210,10 +213,25 @@ void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_
 }
 
 void launch_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
-                          double n_pix, int *unfinished, hipStream_t s)
+                          double n_pix, int *unfinished, hipStream_t s, const int *group, int which)
 {
     hipLaunchKernelGGL(k_trunc_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, fs, trunc_bits, d_active, n_chunks, n_pix,
-                       unfinished);
+                       unfinished, group, which);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
+// the mask of the frames still searching, taken apart by group: mask1 gets group 1's entries, mask0 keeps the others
+__global__ void k_trunc_split(const int *group, int *mask0, int *mask1, int n_chunks)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_chunks) return;
+    const int a = mask0[f], g = group[f];
+    mask1[f] = g ? a : 0;
+    mask0[f] = g ? 0 : a;
+}
+void launch_trunc_split(const int *group, int *mask0, int *mask1, int n_chunks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trunc_split, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, group, mask0, mask1, n_chunks);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

@@ -62,7 +62,11 @@ void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_
 
 // One round of the truncation bisection: take in the statistics of the cut made in the previous round, choose the next
 // cut (trunc_bits[f], active[f] = 1) or finish.
+// group / which (optional): only the chunks with group[f] == which are advanced - the others are left alone word for word
+// (another stream runs their rounds) and get d_active[f] = 0 in THIS call's mask.
 void launch_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
-                          double n_pix, int *unfinished, hipStream_t s);
+                          double n_pix, int *unfinished, hipStream_t s, const int *group = nullptr, int which = 0);
+// mask1[f] = group[f] ? mask0[f] : 0; mask0[f] = group[f] ? 0 : mask0[f]
+void launch_trunc_split(const int *group, int *mask0, int *mask1, int n_chunks, hipStream_t s);
 
 }  // namespace ebcc

@@ -482,3 +482,20 @@ def formula_frames(n, h, w):
     k, y, x = np.mgrid[0:n, 0:h, 0:w]
     return (250.0 + ((x * 3 + y * 5 + k * 11) % 1024).astype(np.float32) / np.float32(64.0)
             + (((x // 16) * 7 + (y // 16) * 13 + k * 5) % 97).astype(np.float32)).astype(np.float32)
+
+
+def _orc_encode_job(arg):
+    frame, cfg_fields = arg
+    oracle().orc_set_j2k_backend(0)
+    cfg = make_config(cfg_fields[0], base_cr=cfg_fields[1], error=cfg_fields[2], residual_type=cfg_fields[3])
+    return orc_encode(frame, cfg)
+
+
+def orc_encode_many(frames, cfg, workers=6):
+    """orc_encode of several single-frame inputs side by side (the restated JPEG 2000 search takes seconds per full-size
+    frame).  Spawned workers: a process that has initialised HIP is never forked; the workers load the oracle only."""
+    import multiprocessing as mp
+    fields = (tuple(cfg.dims), float(cfg.base_cr), float(cfg.error), int(cfg.residual_compression_type))
+    jobs = [(np.ascontiguousarray(f, np.float32), fields) for f in frames]
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        return pool.map(_orc_encode_job, jobs, chunksize=1)

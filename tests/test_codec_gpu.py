@@ -592,6 +592,55 @@ def test_host_frame_entry_points_take_any_number_of_frames():
         assert codec.encode(frames[:9], bcfg) == want[:9]            # (and the codec goes on working)
 
 
+def _ebck_streams(blob):
+    """the chunk streams of an EBCK container (80-byte header, then u64 size | stream per chunk: reference :204-213, :1037-1038)"""
+    import struct
+    n = struct.unpack_from("<Q", blob, 64)[0]
+    at, out = 80, []
+    for _ in range(n):
+        (m,) = struct.unpack_from("<Q", blob, at)
+        out.append(blob[at + 8:at + 8 + m])
+        at += 8 + m
+    assert at == len(blob)
+    return out
+
+
+@pytest.mark.parametrize("mode,err", [(L.MAX_ERROR, 0.5), (L.RELATIVE_ERROR, 1e-3)], ids=["max_error", "relative_error"])
+def test_full_size_shard_of_several_batches(mode, err, monkeypatch):
+    """BASELINE configs[2] / [3] at full frame size on one GPU: 56 frames of 721 x 1440 through an engine that holds 24 (two
+    full device batches and a ragged one of 8) - ebcc_hip_encode_shard / ebcc_hip_decode_shard (alternating engine sets) and
+    the reference's own ebcc_encode_chunking / ebcc_decode_chunking with EBCC_HIP_MAX_BATCH = 24
+    (/root/reference/src/ebcc_codec.c:1007-1046 is the loop being batched): the bound holds on EVERY frame, both entry points
+    give the same streams and fields, three sampled streams (first batch, second batch, ragged tail) are byte-identical to
+    the oracle's and their decoded frames equal the oracle's decode."""
+    h, w, cap, m = 721, 1440, 24, 56
+    frames = np.stack([L.era5_like(h, w, 3000 + s, 1.5 if s % 4 else 1.0, (2.5 if s % 4 else 0.7) * (0.6 + 0.05 * (s % 9))) for s in range(m)]).astype(np.float32)
+    cfg = L.make_config((1, h, w), base_cr=30.0, error=err, residual_type=mode)
+    with L.Context(cap, h, w) as ctx:
+        streams = ctx.encode_shard(frames, cfg)
+        assert streams is not None and len(streams) == m
+        dec = ctx.decode_frames(streams, shard=True)
+    rng_ = frames.reshape(m, -1).max(axis=1) - frames.reshape(m, -1).min(axis=1)
+    target = np.full(m, err, np.float64) if mode == L.MAX_ERROR else err * rng_.astype(np.float64)
+    worst = np.abs(dec - frames).reshape(m, -1).max(axis=1)
+    # (the reference folds the mean error into the header AFTER the bound was checked: the bound is soft by ~1 %, INTEGRATION.md)
+    assert (worst <= target * 1.01 + 1e-3).all(), (worst / target).max()
+    kept = sum(int.from_bytes(s[16:24], "little") > 0 for s in streams)
+    # the reference's host-pointer entry points on the same array, three device batches behind one call
+    monkeypatch.setenv("EBCC_HIP_MAX_BATCH", str(cap))
+    ccfg = L.make_config((m, h, w), (1, h, w), base_cr=30.0, error=err, residual_type=mode)
+    blob = api_encode(frames, ccfg, "ebcc_encode_chunking")
+    assert _ebck_streams(blob) == streams
+    back = api_decode(blob, "ebcc_decode_chunking")
+    assert np.array_equal(back.reshape(m, h, w), dec)
+    picks = (3, cap + 5, m - 1)
+    want = L.orc_encode_many([frames[i] for i in picks], cfg)
+    for i, s in zip(picks, want):
+        assert streams[i] == s, (i, len(streams[i]), len(s))
+        assert np.array_equal(np.asarray(L.orc_decode(s)).ravel(), dec[i].ravel()), i
+    print(f"full-size shard: {kept} of {m} frames keep a residual layer, worst error / target {float((worst / target).max()):.4f}")
+
+
 _SHARD = r"""
 import ctypes, hashlib, sys
 import numpy as np

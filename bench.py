@@ -113,10 +113,12 @@ def cpu_baseline(sample, cores, checks=()):
     frames += [np.ascontiguousarray(sample[i % len(sample)]) for i in range(max(0, 2 * cores - len(frames)))]
     t0 = time.time()
     with mp.get_context("spawn").Pool(cores) as pool:      # (never fork a process that has initialised HIP)
-        res = pool.map(_cpu_one, [(kind, f) for f in frames], chunksize=1)
+        modes = [c[3] if len(c) > 3 else "max" for c in checks] + ["max"] * (len(frames) - len(checks))
+        res = pool.map(_cpu_one, [(kind, f, m) for f, m in zip(frames, modes)], chunksize=1)
     wall = time.time() - t0
-    enc = float(np.median([r[0] for r in res]))
-    dec = float(np.median([r[1] for r in res]))
+    timed = [r for r, m in zip(res, modes) if m == "max"]          # (the timing is the MAX_ERROR workload's)
+    enc = float(np.median([r[0] for r in timed]))
+    dec = float(np.median([r[1] for r in timed]))
     out = {"value": round(len(frames) * FRAME_BYTES / wall / 1e9, 6), "unit": "GB/s", "cores": cores, "kind": kind,
            "sample": f"{len(frames)} frames 721x1440 (base_cr 30, MAX_ERROR 0.5), two per process on {cores} processes, encode+decode; "
                      f"median {enc:.2f}s enc / {dec:.3f}s dec per frame, {wall:.1f}s wall",
@@ -131,9 +133,10 @@ def cpu_baseline(sample, cores, checks=()):
 
 def _cpu_one(arg):
     import hashlib
-    kind, frame = arg
+    kind, frame, mode = arg
     from tests import _lib as L
-    cfg = L.make_config((1, H, W), base_cr=BASE_CR, error=MAX_ERR, residual_type=L.MAX_ERROR)
+    cfg = (L.make_config((1, H, W), base_cr=BASE_CR, error=MAX_ERR, residual_type=L.MAX_ERROR) if mode == "max" else
+           L.make_config((1, H, W), base_cr=BASE_CR, error=1e-3, residual_type=L.RELATIVE_ERROR))
     if kind == "reference":
         lib = ctypes.CDLL(L.REF_SO)
         lib.ebcc_encode.restype = ctypes.c_size_t
@@ -208,7 +211,8 @@ def main():
         assert rc == 0, lib.ebcc_hip_last_error()
         t2 = time.perf_counter()
         nbytes = sum(sizes[i] for i in range(n))
-        step.first_hashes = [hashlib.sha256(ctypes.string_at(outs[i], sizes[i])).hexdigest() for i in range(min(n, 2))]
+        if step.hash:                                            # (the last warm-up step only: not inside the timed region)
+            step.first_hashes = [hashlib.sha256(ctypes.string_at(outs[i], sizes[i])).hexdigest() for i in range(min(n, 2))]
         for i in range(n):
             lib.free_buffer(outs[i])
         return t1 - t0, t2 - t1, nbytes
@@ -222,8 +226,11 @@ def main():
     lib.ebcc_hip_host_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     lib.ebcc_hip_host_stats.restype = None
     hstats = (ctypes.c_double * 8)()
-    for _ in range(args.warmup):
+    step.hash = False
+    for w in range(max(1, args.warmup)):
+        step.hash = w == max(1, args.warmup) - 1
         step()
+    step.hash = False
     lib.ebcc_hip_timing_enable(ctx, 1)
     lib.ebcc_hip_host_stats(hstats, 1)                          # (reset)
     barrier()
@@ -244,7 +251,9 @@ def main():
     lib.ebcc_hip_host_stats(hstats, 0)
     # host side of this rank over the timed region (per step): what the entropy stage cost, what the process burnt in all
     # its threads, and whether the container's CPU quota throttled it
-    host = {"pool_threads": lib.ebcc_hip_host_threads(int(os.environ.get("EBCC_HIP_SLICES", "3"))) if hasattr(lib, "ebcc_hip_host_threads") else None,
+    lib.ebcc_hip_default_encode_slices.restype = ctypes.c_int
+    default_slices = int(os.environ.get("EBCC_HIP_SLICES", lib.ebcc_hip_default_encode_slices()))
+    host = {"pool_threads": lib.ebcc_hip_host_threads(default_slices),
             "usable_cpus": int(hstats[0]), "quota_cpus": hstats[1] or None,
             "zstd_core_s_per_step": round(hstats[2] / args.steps, 4), "zstd_wait_ms_per_step": round(hstats[3] / args.steps * 1e3, 2),
             "zstd_MB_per_step": round(hstats[4] / args.steps / 1e6, 3),
@@ -328,19 +337,25 @@ def main():
         """Measured in the same run (N = 1 only): the other single-GPU populations of SURVEY section 8(d) and the
         reference's own host-pointer entry points."""
         ex = {}
-        # ---- BASELINE configs[2] on a bounded sample: RELATIVE_ERROR 1e-3, per-frame amplitude ramp, 512 frames in
-        #      batches of the engine's capacity (what EBCC_HIP_MAX_BATCH does behind the host-pointer API)
-        m3 = 512 if n >= 256 else 2 * n
+        # ---- BASELINE configs[2] at its stated size: 4096 frames resident in HBM, RELATIVE_ERROR 1e-3, per-frame amplitude
+        #      ramp, batches of the engine's capacity on the two alternating engine sets; the relative bound checked on
+        #      EVERY frame, three streams sent to the reference codec with the CPU baseline (byte parity)
+        m3 = 4096 if n >= 256 else 4 * n
         data = synth_frames(torch, m3, device, seed=77, ramp=(0.25, 1.75))
         cfg3 = L.make_config((1, H, W), base_cr=BASE_CR, error=1e-3, residual_type=L.RELATIVE_ERROR)
         run_batches(data[:n + min(n, 16)], cfg3)                                  # (warm-up: two batches, so that the second engine set exists before the timed run)
-        te, td, nb, resid, worst = run_batches(data, cfg3)
+        te, td, nb, resid, worst = run_batches(data, cfg3, keep_streams=(1, m3 // 2, m3 - 2))
         rng_ = (data.amax(dim=(1, 2)) - data.amin(dim=(1, 2)))
+        rel_ = run_batches.per_frame / rng_
+        assert float(rel_.amax()) <= 1e-3 * 1.01 + 1e-6, float(rel_.amax())
+        for i, digest in run_batches.kept.items():
+            parity_checks.append((f"config3[{i}]", data[i].cpu().numpy(), digest, "rel"))
         ex["config3"] = {"workload": f"{m3} frames 721x1440, base_cr=30 RELATIVE_ERROR=1e-3, amplitude ramp 0.25..1.75, batches of {n}",
                          "value": round(m3 * FRAME_BYTES / (te + td) / 1e9, 4), "unit": "GB/s",
                          "encode_GBps": round(m3 * FRAME_BYTES / te / 1e9, 4), "decode_GBps": round(m3 * FRAME_BYTES / td / 1e9, 4),
                          "compressed_bytes_per_frame": int(nb / m3), "frames_with_residual_layer": round(resid / m3, 4),
-                         "max_error_over_range": round(float((run_batches.per_frame / rng_).amax()), 6)}     # per frame: its error / its range
+                         "max_error_over_range": round(float(rel_.amax()), 6),                        # per frame: its error / its range
+                         "frames_within_bound": int((rel_ <= 1e-3 * 1.01 + 1e-6).sum()), "seconds": round(te + td, 3)}
         del data
         # ---- the population that keeps the residual layer (slope 1.0, amp 0.7)
         mr = min(n, 128)
@@ -367,7 +382,7 @@ def main():
                            "max_abs_error_over_all_frames": round(worst, 5), "frames_within_bound": int((run_batches.per_frame <= MAX_ERR * 1.01 + 1e-3).sum()),
                            "seconds": round(te + td, 3)}
         for i, digest in run_batches.kept.items():
-            parity_checks.append((f"shard4096[{i}]", data[i].cpu().numpy(), digest))
+            parity_checks.append((f"shard4096[{i}]", data[i].cpu().numpy(), digest, "max"))
         del data
         # ---- BASELINE configs[4]'s path: EBCC-filtered HDF5 datasets of one frame per chunk, written and read (i) through the
         #      plain filter-308 callback (one chunk per call) and (ii) as device batches of pre-filtered chunks
@@ -403,9 +418,37 @@ def main():
                           "round_trip_GBps": round(n * FRAME_BYTES / (te + td) / 1e9, 4), "container_bytes": int(nb), "max_abs_error": round(err, 5)}
         return ex
 
+    def rehearsal_8_ranks():
+        """What ONE rank sees when eight share this box's CPU quota (the driver's 8-GPU scaling run cannot be rehearsed on a
+        one-GPU box; its host side can): the timed step again in child processes (i) with LOCAL_WORLD_SIZE=8 - the library then
+        sizes its host pool from an eighth of the CPUs - and (ii) confined to an eighth of the quota's CPUs (taskset), i.e.
+        with an eighth of the CPU TIME as well, which is what eight busy ranks leave each other."""
+        import subprocess
+        quota = hosts[0]["quota_cpus"] or len(os.sched_getaffinity(0))
+        share = max(1, int(quota // 8))
+        cpus = sorted(os.sched_getaffinity(0))[:share]
+        base = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+        out_ = {"cpus_per_rank": share, "of_quota": quota}
+        for tag, cmd, env in (("pool_sized_for_8_ranks", base, dict(os.environ, LOCAL_WORLD_SIZE="8")),
+                              ("confined_to_an_eighth_of_the_cpus", ["taskset", "-c", ",".join(map(str, cpus))] + base, dict(os.environ))):
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                h0 = d["host"]["ranks"][0]
+                out_[tag] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "encode_GBps": d["encode_GBps"], "decode_GBps": d["decode_GBps"],
+                             "pool_threads": h0["pool_threads"], "zstd_core_s_per_step": h0["zstd_core_s_per_step"],
+                             "zstd_wait_ms_per_step": h0["zstd_wait_ms_per_step"],
+                             "throttled_ms_per_step": (h0.get("cgroup") or {}).get("throttled_ms_per_step")}
+            except Exception as e:                                  # (a report, never a gate)
+                out_[tag] = {"error": repr(e)}
+        return out_
+
     extras = None
+    rehearsal = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = extra_workloads()
+        torch.cuda.empty_cache()
+        rehearsal = rehearsal_8_ranks()
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -425,22 +468,22 @@ def main():
         def kernel_sources_sha():
             import hashlib
             hsh = hashlib.sha256()
-            for f in ("j2k_analysis.hip", "t1_core.hpp"):
+            for f in ("j2k_analysis.hip", "t1_core.hpp", "j2k_rate.hip", "residual_dwt.hip", "residual_spiht.hip"):
                 hsh.update(open(os.path.join(ROOT, "ebcc_amd", "csrc", f), "rb").read())
             return hsh.hexdigest()[:16]
 
         def pmc_traffic(frames_per_launch):
-            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r03_pmc_tier1.json,
+            """HBM bytes per launch of the tier-1 encoder from the committed PMC passes (profiles/r04_pmc_tier1.json,
             tools/gpu/profile.sh: separate FETCH_SIZE and WRITE_SIZE runs of `--frames 64` on one slice = 64 frames per
             dispatch; gfx950 correction of the micro-architecture guide: FETCH_SIZE x 2; units of 1 KB).  The file names
             the kernel sources it was taken with; a file that predates the last change to them gives no figure."""
             try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_tier1.json")))
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_tier1.json")))
                 if pj.get("kernel_sources_sha") != kernel_sources_sha():
-                    return None, "profiles/r03_pmc_tier1.json predates the current tier-1 kernel sources"
+                    return None, "profiles/r04_pmc_tier1.json predates the current tier-1 kernel sources"
                 per = float(pj["frames_per_dispatch"])
                 per_frame = sum(2.0 * pj["fetch_kb"][k] + pj["write_kb"][k] for k in pj["kernels"]) * 1024.0 / per
-                return int(per_frame * frames_per_launch), "profiles/r03_pmc_tier1.json@" + pj["kernel_sources_sha"]
+                return int(per_frame * frames_per_launch), "profiles/r04_pmc_tier1.json@" + pj["kernel_sources_sha"]
             except Exception as e:
                 return None, "no usable PMC file: " + repr(e)
 
@@ -459,10 +502,10 @@ def main():
             # HBM bytes of a whole frame round trip (every k_* kernel of encode + decode, counters as above) against the 8.49 MB
             # a round trip has to move: what the search probes cost
             try:
-                st = json.load(open(os.path.join(ROOT, "profiles", "r03_step_traffic.json")))
+                st = json.load(open(os.path.join(ROOT, "profiles", "r04_step_traffic.json")))
                 roof["step_traffic"] = {"bytes_per_frame_round_trip": st["bytes_per_frame_round_trip"],
                                         "algorithmic_bytes_per_frame_round_trip": st["algorithmic_bytes_per_frame_round_trip"],
-                                        "source": "profiles/r03_step_traffic.json@" + st.get("kernel_sources_sha", "?"),
+                                        "source": "profiles/r04_step_traffic.json@" + st.get("kernel_sources_sha", "?"),
                                         "current_sources": st.get("kernel_sources_sha") == kernel_sources_sha()}
             except Exception as e:
                 roof["step_traffic"] = None
@@ -473,11 +516,23 @@ def main():
         if c.value:
             avg_s = a.value / c.value / 1e3
             algo = (n * FRAME_BYTES + comp) * args.steps / c.value
+            # counter traffic of the kernel per launch: its row of the per-kernel step traffic (FETCH_SIZE x 2 + WRITE_SIZE over one
+            # warm step of 256 frames, one launch per step: tools/gpu/hbm_table.sh), scaled to the frames of a launch
+            dec_traffic, dec_src = None, None
+            try:
+                st = json.load(open(os.path.join(ROOT, "profiles", "r04_step_traffic.json")))
+                if st.get("kernel_sources_sha") == kernel_sources_sha() and "k_t1_decode_lds" in st["by_kernel"]:
+                    dec_traffic = int(st["by_kernel"]["k_t1_decode_lds"] * n * args.steps / c.value)
+                    dec_src = "profiles/r04_step_traffic.json@" + st["kernel_sources_sha"]
+                else:
+                    dec_src = "profiles/r04_step_traffic.json predates the current kernel sources"
+            except Exception as e:
+                dec_src = "no usable PMC file: " + repr(e)
             roof_dec = {"bound": "hbm", "kernel": "tier-1 decoder (k_t1_decode_lds)", "achieved": round(algo / avg_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(algo / avg_s / 1e9 / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 4),
+                        "frac": round(algo / avg_s / 1e9 / 8000.0, 6), "traffic": dec_traffic, "traffic_source": dec_src, "avg_launch_ms": round(avg_s * 1e3, 4),
                         "algorithmic_bytes_per_launch": algo, "frames_per_launch": n * args.steps / c.value,
                         "note": "a serial entropy decoder: latency- and issue-bound by nature; decode_GBps is the phase as a whole"}
-        slices = int(os.environ.get("EBCC_HIP_SLICES", "3"))            # (host_codec.hip: default_encode_slices)
+        slices = default_slices
         lib.ebcc_hip_host_threads.restype = ctypes.c_int
         line = {
             "metric": "fp32 GB/s encode+decode, 721x1440 ERA5 frames MAX_ERROR=0.5",
@@ -501,14 +556,16 @@ def main():
                         "zstd_core_s_per_step_all_ranks": round(sum(h["zstd_core_s_per_step"] for h in hosts), 4),
                         "cpus_shared_by_ranks": cpus_shared,
                         "projected_host_bound_ms_per_step": round(sum(h["zstd_core_s_per_step"] for h in hosts) / cpus_shared * 1e3, 2)}
+        if rehearsal:
+            line["host"]["rehearsal_8_ranks"] = rehearsal
         try:                                                    # HBM-bound kernels, measured alone (tools/gpu/hbm_table.sh): best and worst of the table
-            hk = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_kernels.json")))
+            hk = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_kernels.json")))
             # rows that are HBM measurements: at least 1 MB per frame to move by role, counter traffic within 2x of it either
             # way (below: the input was still in the Infinity Cache; above: re-reads), and not latency-bound by design
             rows = [r for r in hk["kernels"] if r.get("frac_of_6290") is not None and r["algorithmic_bytes"] >= hk["frames_per_dispatch"] * (1 << 20)
                     and 0.5 <= r["counter_over_algorithmic"] <= 2.5 and "latency-bound" not in r.get("what", "")]
             if rows:
-                line["hbm_kernels"] = {"source": "profiles/r03_hbm_kernels.json@" + hk.get("kernel_sources_sha", "?"),
+                line["hbm_kernels"] = {"source": "profiles/r04_hbm_kernels.json@" + hk.get("kernel_sources_sha", "?"),
                                        "best": max(rows, key=lambda r: r["frac_of_6290"]), "worst": min(rows, key=lambda r: r["frac_of_6290"])}
         except Exception:
             pass
@@ -518,7 +575,7 @@ def main():
             try:
                 cores = min(16, len(os.sched_getaffinity(0)))
                 host_frames = frames[:4].cpu().numpy()
-                checks = [(f"configs[1] frame {i}", host_frames[i], h_) for i, h_ in enumerate(getattr(step, "first_hashes", []))] + parity_checks
+                checks = [(f"configs[1] frame {i}", host_frames[i], h_, "max") for i, h_ in enumerate(getattr(step, "first_hashes", []))] + parity_checks
                 line["cpu_baseline"] = cpu_baseline(host_frames, cores, checks)
             except Exception as e:                              # the baseline is a report, never a gate
                 line["cpu_baseline"] = {"error": repr(e)}

@@ -134,58 +134,6 @@ void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const 
     wait_stream(s);
 }
 
-void stage_area_free(StageArea &a)
-{
-    if (a.h) hipHostFree(a.h);
-    if (a.d) hipFree(a.d);
-    if (a.h_pack) hipHostFree(a.h_pack);
-    if (a.d_pack) hipFree(a.d_pack);
-    a = StageArea{};
-}
-
-void stage_download_async(ebcc_hip_ctx *ctx, StageArea &a, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s, bool copy_now)
-{
-    a.packed = 0;
-    if (a.pack_cap < 2 * n) {
-        if (a.h_pack) hipHostFree(a.h_pack);
-        if (a.d_pack) hipFree(a.d_pack);
-        a.h_pack = nullptr; a.d_pack = nullptr; a.pack_cap = 0;
-        const size_t cap = 2 * std::max(n, ctx->max_frames);
-        EBCC_HIP_CHECK(hipHostMalloc((void **) &a.h_pack, cap * sizeof(unsigned long long)));
-        EBCC_HIP_CHECK(device_malloc((void **) &a.d_pack, cap * sizeof(unsigned long long)));
-        a.pack_cap = cap;
-    }
-    size_t total = 0;
-    for (size_t f = 0; f < n; f++) {
-        off[f] = total;
-        a.h_pack[2 * f] = total; a.h_pack[2 * f + 1] = len[f];
-        total += (len[f] + 15) & ~(size_t) 15;
-    }
-    if (!total) return;
-    if (total > a.cap) {
-        if (a.h) hipHostFree(a.h);
-        if (a.d) hipFree(a.d);
-        a.h = nullptr; a.d = nullptr; a.cap = 0;
-        const size_t cap = total + total / 2 + 4096;
-        uint8_t *h_new = nullptr, *d_new = nullptr;
-        EBCC_HIP_CHECK(hipHostMalloc((void **) &h_new, cap));
-        const hipError_t e = device_malloc((void **) &d_new, cap);
-        if (e != hipSuccess) { hipHostFree(h_new); EBCC_HIP_CHECK(e); }
-        a.h = h_new; a.d = d_new; a.cap = cap;
-    }
-    a.packed = total;
-    EBCC_HIP_CHECK(hipMemcpyAsync(a.d_pack, a.h_pack, 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_stage, dim3((unsigned) n, 4), dim3(256), 0, s, const_cast<uint8_t *>(src), stride, a.d_pack, a.d, 1);
-    if (copy_now) EBCC_HIP_CHECK(hipMemcpyAsync(a.h, a.d, total, hipMemcpyDeviceToHost, s));
-}
-
-void stage_area_fetch(StageArea &a, hipStream_t s)
-{
-    if (!a.packed) return;
-    EBCC_HIP_CHECK(hipMemcpyAsync(a.h, a.d, a.packed, hipMemcpyDeviceToHost, s));
-    wait_stream(s);
-}
-
 void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m) { stage_layout(ctx, len, off, m); }
 
 void stage_send(ebcc_hip_ctx *ctx, size_t m, hipStream_t s)
@@ -200,6 +148,31 @@ void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first,
 {
     if (!count) return;
     hipLaunchKernelGGL(k_stage, dim3((unsigned) count, 4), dim3(256), 0, s, dst, stride, ctx->d_pack + 2 * first, ctx->d_stage, 0);
+}
+
+bool ensure_cut_slots(ebcc_hip_ctx *ctx, int capacity)
+{
+    if (ctx->cut.capacity >= capacity) return true;
+    if (ctx->cut_failed || ctx->cut.capacity > 0) return false;          // (made once, for 3 slots per frame of the engine)
+    const int cap = std::max(capacity, 3 * (int) ctx->max_frames);
+    if (!prefix_slots_supported(ctx->rb, cap)) { ctx->cut_failed = true; return false; }
+    CutSlots c;
+    c.stride = (size_t) (ctx->rb.g.ny >> 1) * (size_t) ctx->rb.g.nx;
+    bool ok = true;
+    ok &= (c.A = ctx_alloc<float>(ctx, c.stride * cap)) != nullptr;
+    ok = ok && (c.T = ctx_alloc<float>(ctx, c.stride * cap)) != nullptr;
+    ok = ok && (c.D = ctx_alloc<float>(ctx, c.stride * cap)) != nullptr;
+    ok = ok && (c.fs = ctx_alloc<FrameState>(ctx, cap)) != nullptr;
+    ok = ok && (c.partial = ctx_alloc<double>(ctx, (size_t) kPartials * cap)) != nullptr;
+    ok = ok && (c.bits = ctx_alloc<unsigned long long>(ctx, cap)) != nullptr;
+    ok = ok && (c.active = (int *) ctx_alloc<uint32_t>(ctx, cap)) != nullptr;
+    ok = ok && (c.frame_of = (int *) ctx_alloc<uint32_t>(ctx, cap)) != nullptr;
+    if (!ok) { ctx->cut_failed = true; clear_error(); return false; }    // (what was allocated stays with the context until it goes)
+    EBCC_HIP_CHECK(hipMemsetAsync(c.active, 0, sizeof(int) * cap, ctx->stream));
+    EBCC_HIP_CHECK(hipMemsetAsync(c.frame_of, 0, sizeof(int) * cap, ctx->stream));
+    c.capacity = cap;
+    ctx->cut = c;
+    return true;
 }
 
 void fetch_frame_states(ebcc_hip_ctx *ctx, size_t n)
@@ -346,7 +319,6 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
     ok &= (ctx->d_u64c = ctx_alloc<unsigned long long>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_active = (int *) ctx_alloc<uint32_t>(ctx, 2 * max_frames)) != nullptr;      // (second half: the overlapped search's mask)
     ok &= (ctx->d_pack = ctx_alloc<unsigned long long>(ctx, 4 * max_frames)) != nullptr;
-    ok &= (ctx->d_active3 = (int *) ctx_alloc<uint32_t>(ctx, max_frames)) != nullptr;
     ok &= (ctx->d_search = ctx_alloc<uint8_t>(ctx, 2 * sizeof(DevChunk) * max_frames)) != nullptr;   // (second half: the overlapped search)
     ok &= (ctx->d_counter = (int *) ctx_alloc<uint32_t>(ctx, 8)) != nullptr;
     if (ok) {
@@ -357,7 +329,7 @@ ebcc_hip_ctx *ebcc::create_engine(int device, size_t max_frames, size_t height, 
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_fs, max_frames * sizeof(FrameState)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_pack, 4 * max_frames * sizeof(unsigned long long)));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_act, 2 * max_frames * sizeof(int)));
-        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, 4 * sizeof(DevChunk) * max_frames));
+        EBCC_HIP_CHECK(hipHostMalloc(&ctx->h_search, 2 * sizeof(DevChunk) * max_frames));
         EBCC_HIP_CHECK(hipHostMalloc((void **) &ctx->h_counter, 8 * sizeof(int)));
         EBCC_HIP_CHECK(hipMemsetAsync(rb.fs, 0, max_frames * sizeof(FrameState), ctx->stream));
         ok = j2k_create(ctx);
@@ -401,14 +373,10 @@ void ebcc_hip_destroy(ebcc_hip_ctx *ctx)
     if (ctx->h_table) hipHostFree(ctx->h_table);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->d_stage) hipFree(ctx->d_stage);
-    for (StageArea &a : ctx->aux_stage) ebcc::stage_area_free(a);
     if (ctx->d_io) hipFree(ctx->d_io);
     if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
-    if (ctx->ev_d) hipEventDestroy(ctx->ev_d);
-    if (ctx->ev_e) hipEventDestroy(ctx->ev_e);
-    if (ctx->stream3) hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

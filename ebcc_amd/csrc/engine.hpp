@@ -7,17 +7,6 @@
 
 #include "residual.hpp"
 
-// A staging area of its own for transfers whose bytes are read while the engine's main area (h_stage / d_stage) is used for
-// something else: the kept SPIHT prefixes of the frames whose truncation search ends first are compressed from here
-// while the others still search and then use the main area (host_codec.hip).
-struct StageArea {
-    uint8_t *h = nullptr, *d = nullptr;
-    size_t cap = 0;
-    unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 per piece] offset, length
-    size_t pack_cap = 0;
-    size_t packed = 0;                                        // bytes the last stage_download_async packed into d
-};
-
 struct ebcc_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -38,18 +27,17 @@ struct ebcc_hip_ctx {
     void *h_jf = nullptr;                  // [max_frames] J2kFrame (j2k.hpp)
     int *h_act = nullptr;                  // [2 * max_frames]: probe mask, residual mask
     int *h_table = nullptr;                // [max_frames * code-block slots * 4] decode tables (lazily sized by j2k_create)
-    void *d_search = nullptr, *h_search = nullptr;   // [2][max_frames] DevChunk: state of the device-driven searches (search.hpp: both rate searches); pinned mirror [4][max_frames]: those two, the early truncation group's results, the second search in mid-flight
+    void *d_search = nullptr, *h_search = nullptr;   // [2][max_frames] DevChunk: state of the device-driven searches (search.hpp; second half: the overlapped search), pinned mirror
     int *d_counter = nullptr, *h_counter = nullptr;  // [4] small device counters and their pinned mirror
     std::vector<void *> allocs;
     void *j2k = nullptr;                   // base-layer state (j2k.hpp)
     hipStream_t stream2 = nullptr;          // second stream of the engine (decode: residual layer beside the base layer)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;   // ordering between the two streams (created on first use)
-    hipEvent_t ev_d = nullptr;                   // the truncation search is split in two groups (host_codec.hip)
-    hipEvent_t ev_e = nullptr;                   // the mid-flight snapshot of the second rate search has arrived
     // Sub-batch engines of the frames API: a batch is cut into a few slices that run concurrently, each on its
     // own stream and host thread (the kernels of one slice are latency-bound and leave most of the chip idle).
     std::vector<ebcc_hip_ctx *> lanes;
     ebcc_hip_ctx *twin = nullptr;           // second engine set of ebcc_hip_encode_shard (batch k + 1 computes while batch k is in its entropy stage)
+    bool twin_failed = false;               // (it could not be made: not tried again until ebcc_hip_release_engines)
     // Staging for the many small per-frame transfers (codestreams, SPIHT bytes): the pieces are packed by a kernel
     // into one device buffer and cross PCIe as one copy into / out of one pinned buffer (engine.hip: stage_*).
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
@@ -59,9 +47,8 @@ struct ebcc_hip_ctx {
     size_t io_cap = 0;                      // bytes
     uint8_t *h_bounce = nullptr;            // 2 x kBounceBytes pinned: pageable host arrays cross PCIe through it (host_codec.hip)
     unsigned long long *h_pack = nullptr, *d_pack = nullptr;   // [2 pieces per frame][offset, length]
-    StageArea aux_stage[2];                 // [1] SPIHT prefixes of the early group ([0] free)
-    hipStream_t stream3 = nullptr;          // third stream of the engine (truncation search of the early group)
-    int *d_active3 = nullptr;               // [max_frames] its frame mask
+    ebcc::CutSlots cut{};                   // look-ahead storage of the truncation search (made on first use: ensure_cut_slots)
+    bool cut_failed = false;                // (no memory for it: the search probes one cut per round)
 };
 
 namespace ebcc {
@@ -75,21 +62,15 @@ T *ctx_alloc(ebcc_hip_ctx *ctx, size_t count);
 // Device -> host: the first len[f] bytes of the slot src + f * stride of every frame with len[f] > 0, as ONE copy.
 // Fills off[f] (offsets into ctx->h_stage, 16-byte aligned) and returns after the data has arrived.
 void stage_download(ebcc_hip_ctx *ctx, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s);
-// The same into a staging area of its own, without waiting: off[f] are offsets into area.h, valid once everything queued on s
-// so far has run (the caller waits for the stream, or for an event recorded behind this call).
-// copy_now = false: the pieces are only packed on the device (area.d); stage_area_fetch brings them over later, with a wait.
-// (A device-to-host copy queued long before the kernels it depends on have run holds up the copies of every other stream
-//  of the process - measured: 12 ms per step with the codestreams of search #1 sent off that way.)
-void stage_download_async(ebcc_hip_ctx *ctx, StageArea &area, const uint8_t *src, size_t stride, const size_t *len, size_t *off, size_t n, hipStream_t s,
-                          bool copy_now = true);
-void stage_area_fetch(StageArea &area, hipStream_t s);
-void stage_area_free(StageArea &area);
 // Host -> device: stage_reserve makes room for m <= 2 * max_frames pieces of len[k] bytes in ctx->h_stage (off[k] filled
 // in); after the caller has written them stage_send ships them as one copy (asynchronous on s), and stage_scatter
 // moves pieces first .. first + count - 1 to the slots dst, dst + stride, ... (on any stream ordered after the send).
 void stage_reserve(ebcc_hip_ctx *ctx, const size_t *len, size_t *off, size_t m);
 void stage_send(ebcc_hip_ctx *ctx, size_t m, hipStream_t s);
 void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first, size_t count, hipStream_t s);
+
+// cut slots for `capacity` simultaneous probes (residual.hpp); false: not available (unsupported grid or no memory)
+bool ensure_cut_slots(ebcc_hip_ctx *ctx, int capacity);
 
 // header of a SPIHT stream against the context's grid and a usable bit budget (non-zero: reject, message set)
 int check_ims_header(ebcc_hip_ctx *ctx, const uint8_t *b, size_t n, size_t num_bits);

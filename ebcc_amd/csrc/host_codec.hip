@@ -836,12 +836,8 @@ int search_rounds()
     return 16;
 }
 constexpr int kSearchAll = 0, kSearchStart = 1, kSearchFinish = 2;
-// snap_dst / snap_event (kSearchStart only): after a few rounds the states are copied to snap_dst (pinned) and the event is
-// recorded behind the copy - a look at the search in mid-flight for whoever wants to guess where it is heading.
-constexpr int kSnapshotAfterRounds = 5;
 template <class Jobs>
-void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices, int lane = 0, int part = kSearchAll,
-                        DevChunk *snap_dst = nullptr, hipEvent_t snap_event = nullptr)
+void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slices, int lane = 0, int part = kSearchAll)
 {
     // lane 1: the search runs on the engine's second stream with its own state, counters and active mask, beside whatever
     // the first stream does (search #2 beside the residual layer).  part: enqueue the first batch of rounds only
@@ -917,15 +913,7 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
         EBCC_HIP_CHECK(hipMemsetAsync(jb.have_rate, 0, sizeof(int) * b.nt, s));
     }
     advance();
-    if (snap_dst && part == kSearchStart) {
-        const int before = std::min(kSnapshotAfterRounds, search_rounds());
-        enqueue_rounds(before);
-        EBCC_HIP_CHECK(hipMemcpyAsync(snap_dst, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, s));
-        EBCC_HIP_CHECK(hipEventRecord(snap_event, s));
-        enqueue_rounds(search_rounds() - before);
-    } else {
-        enqueue_rounds(search_rounds());
-    }
+    enqueue_rounds(search_rounds());
     }
     if (part == kSearchStart) return;
     if (speculate && !s2) s2 = second_stream(ctx);
@@ -1090,8 +1078,6 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             if (!jobs[f].const_field) { jobs[f].cr = jobs[f].rs[0].result; jobs[f].len1 = (size_t) jobs[f].last[0].stream_bytes; }
         }
         pt.mark("rate search 1");
-        if (!ctx->ev_d) EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_d, hipEventDisableTiming));
-        if (!ctx->ev_e) EBCC_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_e, hipEventDisableTiming | hipEventBlockingSync));
         // base layer of search #1.  (Sending the codestreams off without waiting for them - written and packed on the second
         // search's stream, fetched at the assembly - was measured: the slice's next stages are queued 2 ms earlier and the step
         // gets 1 - 5 ms LONGER, three alternating runs on two boxes; the wait stays.)
@@ -1114,19 +1100,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             ebcc_hip_ctx *c; bool armed;
             ~DrainSecond() { if (armed && c->stream2) hipStreamSynchronize(c->stream2); }
         } drain2{ctx, false};
-        DevChunk *snap2 = nullptr;
         if (overlap2) {
             start_search2();
-            if (!getenv("EBCC_HIP_NO_SNAPSHOT")) snap2 = static_cast<DevChunk *>(ctx->h_search) + 3 * ctx->max_frames;
-            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart, snap2, ctx->ev_e);
+            device_rate_search(b, 1, jobs, n_pix, slices, 1, kSearchStart);
             drain2.armed = true;
         }
-        // the second search a few rounds in (null: it does not run beside the residual layer)
-        auto search2_snapshot = [&]() -> const DevChunk * {
-            if (!snap2) return nullptr;
-            EBCC_HIP_CHECK(hipEventSynchronize(ctx->ev_e));
-            return snap2;
-        };
         launch_residual_minmax(d_frames, jb.DEC, (int) n, n_pix, rc->rb.fs, rs);             // :730-733
         fetch_frame_states(rc, n);
         bool any_resid = false;
@@ -1221,6 +1199,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64a, rc->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
             launch_spiht_encode(rc->rb, (int) n, rc->d_u64a, rc->d_active, rs);
             fetch_frame_states(rc, n);
+            pt.mark("residual: analysis, SPIHT");
             for (size_t f = 0; f < n; f++) {
                 if (!b.active[f]) continue;
                 jobs[f].coeffs_orig = rc->h_fs[f].stream_bytes;
@@ -1235,6 +1214,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 fetch_frame_states(rc, n);
             };
             probe_residual();
+            pt.mark("residual: whole-stream probe");
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
                 if (!b.active[f]) continue;
@@ -1273,140 +1253,53 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                     return r;
                 };
                 const bool forced_rounds = getenv("EBCC_HIP_SEARCH_ROUNDS") != nullptr;
-                auto rounds_for = [&](const DevChunk *st, auto member) {
-                    if (forced_rounds) return search_rounds();
-                    int r = 1;
-                    for (size_t f = 0; f < n; f++) if (member(f)) r = std::max(r, rounds_left(st[f]));
-                    return r;
-                };
-                // `rounds` rounds of the chunks of one group (null: all) on stream `on` with the mask `mask`, then their states
-                // into `mirror`; repeated while one of them is still searching
-                auto run_rounds = [&](hipStream_t on, int *mask, const int *group, int which, int rounds, DevChunk *mirror, auto member) {
-                    for (;;) {
-                        for (int r = 0; r < rounds; r++) {
-                            launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, mask, on);
-                            launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, mask, (int) n, (double) n_pix, rc->d_counter, on, group, which);
-                        }
-                        EBCC_HIP_CHECK(hipMemcpyAsync(mirror, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, on));
-                        wait_stream(on);
-                        bool done = true;
-                        for (size_t f = 0; f < n; f++) if (member(f)) done &= !mirror[f].trunc_active;
-                        if (done) break;
-                        rounds = 6;
-                    }
-                };
+                int cuts_left = 1;                                       // cuts the longest search still visits, + the advance that ends it
+                for (size_t f = 0; f < n; f++) cuts_left = std::max(cuts_left, rounds_left(h[f]));
                 auto take_result = [&](const DevChunk &c, Job &j) {
                     j.t_hi = c.t_hi; j.t_lo = c.t_lo; j.t_best = c.t_best; j.mean_err = c.mean_err; j.best_err = c.best_err;
                     j.trunc_active = false;
                 };
-                const auto everyone = [](size_t) { return true; };
-                launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
-                // ---- The early group.  The level-22 zstd of the longest kept prefixes is the slice's last and longest host job
-                //      (15 - 30 ms for 60 - 100 KB on one core) and could only start when EVERY frame's search had ended.  A few
-                //      rounds tell which frames keep the longest prefixes (the kept length lies above t_lo): those go on on a
-                //      stream of their own - a dozen frames per round instead of the slice's, a third of the time - and their
-                //      prefixes are downloaded, bounded and (where the bound does not already decide for the pure base layer)
-                //      handed to the workers while the other frames are still searching.  Same cuts, same results: a chunk's
-                //      search does not depend on which stream runs its rounds.
-                const int split_after = getenv("EBCC_HIP_EARLY_ROUNDS") ? std::max(1, atoi(getenv("EBCC_HIP_EARLY_ROUNDS"))) : 3;
-                const bool early_ok = tiles == 1 && rc == ctx && n >= 12 && !getenv("EBCC_HIP_NO_EARLY_GROUP");
-                std::vector<char> in_early(n, 0);
-                bool split = false;
-                if (early_ok) {
-                    for (int r = 0; r < split_after; r++) {
-                        launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
-                        launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
+                // ---- Look-ahead (search.hpp: launch_trunc_advance_multi): a round probes the cut :779 chooses now and the cuts
+                //      either outcome leads to - `levels` levels of the bisection tree, 2^levels - 1 cut slots per frame - so the
+                //      search takes 1 / levels of the rounds.  The rounds are latency (a chain of six small launches beside the
+                //      other slices' work), the probes off the path mostly stop early (a cut shorter than an infeasible one is
+                //      infeasible too: its first wave over the target ends it).  EBCC_HIP_TRUNC_LEVELS=1: one cut per round.
+                int levels = getenv("EBCC_HIP_TRUNC_LEVELS") ? std::min(3, std::max(1, atoi(getenv("EBCC_HIP_TRUNC_LEVELS")))) : 2;
+                while (levels > 1 && !ensure_cut_slots(rc, (int) n * ((1 << levels) - 1))) levels--;
+                if (levels > 1) {
+                    const CutSlots &cs = rc->cut;
+                    const int n_slots = (int) n * ((1 << levels) - 1);
+                    launch_trunc_advance_multi(d, rc->rb.fs, cs, (int) n, (double) n_pix, levels, nullptr, rc->d_counter, rs);
+                    int rounds = forced_rounds ? search_rounds() : (cuts_left + levels - 1) / levels + 1;
+                    for (;;) {
+                        for (int r = 0; r < rounds; r++) {
+                            launch_prefix_synthesis_slots(d_frames, jb.DEC, rc->rb, cs, n_slots, rs);
+                            launch_trunc_advance_multi(d, rc->rb.fs, cs, (int) n, (double) n_pix, levels, nullptr, rc->d_counter, rs);
+                        }
+                        EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
+                        wait_stream(rs);
+                        bool done = true;
+                        for (size_t f = 0; f < n; f++) done &= !h[f].trunc_active;
+                        if (done) break;
+                        rounds = 3;
                     }
-                    EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
-                    wait_stream(rs);
-                    std::vector<size_t> open;
-                    for (size_t f = 0; f < n; f++) if (h[f].trunc_active) open.push_back(f);
-                    const size_t k = std::min<size_t>(16, std::max<size_t>(2, open.size() / 6));
-                    if (open.size() >= 12) {
-                        std::stable_sort(open.begin(), open.end(), [&](size_t a, size_t c) { return h[a].t_lo > h[c].t_lo; });
-                        for (size_t i = 0; i < k; i++) in_early[open[i]] = 1;
-                        split = true;
-                    }
-                }
-                if (!split) {
-                    run_rounds(rs, rc->d_active, nullptr, 0, rounds_for(h, everyone), h, everyone);
                     for (size_t f = 0; f < n; f++) if (jobs[f].trunc_active) take_result(h[f], jobs[f]);
                 } else {
-                    int *const h_group = reinterpret_cast<int *>(rc->h_u64c), *const d_group = reinterpret_cast<int *>(rc->d_u64c);
-                    for (size_t f = 0; f < n; f++) h_group[f] = in_early[f];
-                    if (!rc->stream3) {
-                        int lo_p = 0, hi_p = 0;
-                        EBCC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));   // (hi_p: numerically lowest = most urgent)
-                        EBCC_HIP_CHECK(hipStreamCreateWithPriority(&rc->stream3, hipStreamNonBlocking, hi_p));
-                    }
-                    hipStream_t s3 = rc->stream3;
-                    DevChunk *const hA = static_cast<DevChunk *>(rc->h_search) + 2 * rc->max_frames;
-                    EBCC_HIP_CHECK(hipMemcpyAsync(d_group, h_group, sizeof(int) * n, hipMemcpyHostToDevice, rs));
-                    launch_trunc_split(d_group, rc->d_active, rc->d_active3, (int) n, rs);
-                    EBCC_HIP_CHECK(hipEventRecord(ctx->ev_d, rs));
-                    EBCC_HIP_CHECK(hipStreamWaitEvent(s3, ctx->ev_d, 0));
-                    const auto early = [&](size_t f) { return in_early[f] != 0; };
-                    const auto late = [&](size_t f) { return in_early[f] == 0; };
-                    // the others' rounds are queued first (their stream is never left empty), then the early group is seen through
-                    const int rounds_late = rounds_for(h, late);
-                    for (int r = 0; r < rounds_late; r++) {
-                        launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
-                        launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs, d_group, 0);
-                    }
-                    pt.mark("truncation: first rounds, split");
-                    run_rounds(s3, rc->d_active3, d_group, 1, rounds_for(h, early), hA, early);
-                    pt.mark("truncation: early group's rounds");
-                    std::vector<size_t> group;
-                    std::vector<size_t> len(n, 0), off(n, 0);
-                    for (size_t f = 0; f < n; f++) {
-                        if (!in_early[f]) continue;
-                        Job &j = jobs[f];
-                        take_result(hA[f], j);
-                        j.coeffs_size = (size_t) (j.t_best / 8.);                             // :796
-                        if (j.coeffs_size <= 16) j.coeffs_size = 0;                           // :811
-                        if (j.coeffs_size) { len[f] = j.coeffs_size; group.push_back(f); }
-                    }
-                    if (!group.empty()) {
-                        stage_download_async(rc, rc->aux_stage[1], (const uint8_t *) rc->rb.stream, rc->rb.stream_words * sizeof(uint32_t), len.data(), off.data(), n, s3);
-                        wait_stream(s3);
-                        for (size_t f : group) coeff_ptr[f] = rc->aux_stage[1].h + off[f];
-                        std::vector<size_t> go = group;
-                        if (want_pure) {
-                            // A bound that already says "the pure base layer wins" spares the job; whether it does depends on
-                            // len2, which the second rate search (on its own stream since the first one ended) has not delivered
-                            // yet - but its bracket has: len2 is at most the size of the probe at its lower end.  That is an
-                            // ESTIMATE used for nothing but the decision to start now; :838 is decided below from the final sizes.
-                            go.clear();
-                            std::vector<size_t> bounded;
-                            for (size_t f : group) if (use_floor && jobs[f].coeffs_size <= kZstdFloorMaxBytes) bounded.push_back(f); else go.push_back(f);
-                            if (!bounded.empty()) {
-                                submit_floors(bounded);
-                                if (!join(fbatches)) return 1;
-                                const DevChunk *snap = search2_snapshot();
-                                for (size_t f : bounded) {
-                                    double x_max = HUGE_VAL;                                  // len2 - len1 is at most this (probably)
-                                    if (snap) {
-                                        const DevRateSearch &R = snap[f].rs[1];
-                                        if (R.phase >= 2)
-                                            for (int i = 0; i < snap[f].n_probes; i++)
-                                                if (snap[f].probes[i].cr == R.lo) x_max = (double) snap[f].probes[i].stream_bytes - (double) jobs[f].len1;
-                                    }
-                                    if (!(zfloor[f] > 0 && x_max < (double) zfloor[f])) go.push_back(f);
-                                }
-                            }
+                    launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
+                    int rounds = forced_rounds ? search_rounds() : cuts_left + 1;
+                    for (;;) {
+                        for (int r = 0; r < rounds; r++) {
+                            launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
+                            launch_trunc_advance(d, rc->rb.fs, rc->d_u64b, rc->d_active, (int) n, (double) n_pix, rc->d_counter, rs);
                         }
-                        longest_first(go);
-                        if (!go.empty()) submit_zstd(go);
-                        if (pt.on) fprintf(stderr, "ebcc-mi355x early group: %zu frames, %zu prefixes, %zu compressed ahead\n", (size_t) std::count(in_early.begin(), in_early.end(), 1), group.size(), go.size());
+                        EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
+                        wait_stream(rs);
+                        bool done = true;
+                        for (size_t f = 0; f < n; f++) done &= !h[f].trunc_active;
+                        if (done) break;
+                        rounds = 6;
                     }
-                    pt.mark("truncation: early group off to the workers");
-                    // the others
-                    EBCC_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(DevChunk) * n, hipMemcpyDeviceToHost, rs));
-                    wait_stream(rs);
-                    bool late_done = true;
-                    for (size_t f = 0; f < n; f++) if (!in_early[f]) late_done &= !h[f].trunc_active;
-                    if (!late_done) run_rounds(rs, rc->d_active, d_group, 0, 6, h, late);
-                    for (size_t f = 0; f < n; f++) if (!in_early[f] && jobs[f].trunc_active) take_result(h[f], jobs[f]);
+                    for (size_t f = 0; f < n; f++) if (jobs[f].trunc_active) take_result(h[f], jobs[f]);
                 }
             } else
             for (;;) {
@@ -1446,7 +1339,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 else j.coeffs_size = (size_t) (j.t_best / 8.);                                // :796
             }
         }
-        pt.mark("residual layer + truncation");
+        pt.mark("truncation search");
         // ---- entropy stage of the kept SPIHT prefix on host cores (:811-817) and the pure base-layer fallback (:819-854).
         //      Level-22 zstd is by far the longest host step (~160 ns per byte on one core: 1.3 core-seconds per 256 frames
         //      of the bench workload on a box whose container has 16 CPUs), and the reference throws most of it away: the
@@ -1957,17 +1850,45 @@ int encode_batches_alternating(ebcc_hip_ctx *ctx, size_t n_frames, const codec_c
 {
     const size_t cap = ctx->max_frames, batches = (n_frames + cap - 1) / cap;
     if (batches == 1) return run_encode_slices(ctx, stage(ctx, (size_t) 0, n_frames), n_frames, cfg, outs, sizes);
-    if (!ctx->twin) ctx->twin = ebcc_hip_create(ctx->device, cap, (size_t) ctx->height, (size_t) ctx->width);
+    // (a second set that could not be made is not tried again at every call - tens of GB allocated and freed each time -
+    //  until ebcc_hip_release_engines / a new context gives the memory a chance to have changed)
+    if (!ctx->twin && !ctx->twin_failed) {
+        ctx->twin = ebcc_hip_create(ctx->device, cap, (size_t) ctx->height, (size_t) ctx->width);
+        if (!ctx->twin) ctx->twin_failed = true;
+    }
     ebcc_hip_ctx *const set[2] = {ctx, ctx->twin};
     GpuPhase phase;
     std::atomic<int> worst{0};
+    std::atomic<size_t> next{0};
+    std::mutex redo_m;
+    std::vector<size_t> redo;                                        // batches the second set could not stage
     std::string err[2];
     auto work = [&](int t) {
         try {
             EBCC_HIP_CHECK(hipSetDevice(ctx->device));
-            for (size_t b = (size_t) t; b < batches && !worst.load(); b += set[1] ? 2 : 1) {
+            for (;;) {
+                size_t b = next++;
+                if (b >= batches) {
+                    if (t != 0) break;
+                    std::lock_guard<std::mutex> l(redo_m);
+                    if (redo.empty()) break;
+                    b = redo.back(); redo.pop_back();
+                }
+                if (worst.load()) break;
                 const size_t lo = b * cap, cnt = std::min(cap, n_frames - lo);
-                const int r = run_encode_slices(set[t], stage(set[t], lo, cnt), cnt, cfg, outs + lo, sizes + lo, &phase);
+                const float *where = nullptr;
+                try { where = stage(set[t], lo, cnt); }
+                catch (const std::exception &e) {
+                    // the second set has no room for its image of the frames: the first set does its batches after its own
+                    if (t == 0) throw;
+                    log_warn("second engine set: %s - its batches run on the first", e.what());
+                    clear_error();
+                    std::lock_guard<std::mutex> l(redo_m);
+                    redo.push_back(b);
+                    for (size_t r = next++; r < batches; r = next++) redo.push_back(r);
+                    return;
+                }
+                const int r = run_encode_slices(set[t], where, cnt, cfg, outs + lo, sizes + lo, &phase);
                 if (r) { err[t] = ebcc_hip_last_error(); int e = 0; worst.compare_exchange_strong(e, r); }
             }
         } catch (const std::exception &e) { err[t] = e.what(); int z = 0; worst.compare_exchange_strong(z, 1); }
@@ -1976,6 +1897,7 @@ int encode_batches_alternating(ebcc_hip_ctx *ctx, size_t n_frames, const codec_c
         std::thread second(work, 1);
         work(0);
         second.join();
+        work(0);                                                      // (what the second set handed back after the first had finished)
     } else {
         work(0);
     }
@@ -1991,7 +1913,10 @@ int decode_batches_alternating(ebcc_hip_ctx *ctx, size_t n_frames, size_t cap, E
 {
     const size_t batches = (n_frames + cap - 1) / cap;
     if (batches == 1) return each(ctx, (size_t) 0, n_frames);
-    if (!ctx->twin) ctx->twin = ebcc_hip_create(ctx->device, ctx->max_frames, (size_t) ctx->height, (size_t) ctx->width);
+    if (!ctx->twin && !ctx->twin_failed) {
+        ctx->twin = ebcc_hip_create(ctx->device, ctx->max_frames, (size_t) ctx->height, (size_t) ctx->width);
+        if (!ctx->twin) ctx->twin_failed = true;
+    }
     ebcc_hip_ctx *const set[2] = {ctx, ctx->twin};
     std::atomic<int> worst{0};
     std::string err[2];
@@ -2124,6 +2049,7 @@ static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env
     const size_t k = slice_engines(ctx, n_frames, env_name, default_slices);
     if (k == 1) return fn(ctx, (size_t) 0, n_frames, (SliceGate *) nullptr, 1u);
     const size_t per = (n_frames + k - 1) / k;
+    const unsigned started = (unsigned) ((n_frames + per - 1) / per);   // (the last slices of a fine slicing can be empty: 8 slices of 33 frames)
     std::vector<int> rc(k, 0);
     std::vector<std::string> err(k);
     std::vector<SliceGate> gates(k);
@@ -2136,7 +2062,7 @@ static int run_slices(ebcc_hip_ctx *ctx, size_t n_frames, Fn fn, const char *env
             try {
                 EBCC_HIP_CHECK(hipSetDevice(ctx->device));
                 if (i > 0) gates[i - 1].wait();
-                rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i], (unsigned) k);
+                rc[i] = fn(i == 0 ? ctx : ctx->lanes[i - 1], lo, hi - lo, &gates[i], started);
                 if (rc[i]) err[i] = ebcc_hip_last_error();
             } catch (const std::exception &e) {
                 rc[i] = 1; err[i] = e.what();
@@ -2211,6 +2137,7 @@ void print_config(codec_config_t *c)
 }
 
 int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) std::max(1, slices)); }
+int ebcc_hip_default_encode_slices(void) { return (int) default_encode_slices(); }
 
 // out[0..6] = usable CPUs (affinity mask cut to the cgroup quota), CPU quota (0: none), zstd core-seconds, seconds the
 // slices waited for the zstd workers, bytes compressed, entropy batches, prefix bytes whose compression was proved
@@ -2219,7 +2146,7 @@ int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) 
 // inverse level for every s in [0, 65535]; v / 255.0f and x / kXi of the residual synthesis (all significands)
 int ebcc_hip_selfcheck(void) { return j2k_selfcheck_div65535() + residual_selfcheck_divisions(); }
 
-// the lower bound of zstd_size_lower_bound (0: not applicable - longer than 128 KB, or a libzstd that may split blocks)
+// the lower bound of zstd_size_lower_bound (0: not applicable - longer than 4 MB, or a libzstd that may split blocks)
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n) { return zstd_floor_usable() ? zstd_size_lower_bound(src, n) : 0; }
 
 void ebcc_hip_host_stats(double *out, int reset)

@@ -596,7 +596,12 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     // Set-up that is the same at every call for this frame - the trees' static minima, the table offsets, the slope range,
     // the pass tables in the order they are staged - is worked out by the frame's first (recording) call and kept in
     // global memory (J2kBuffers::RateCache, reset by the analysis): 58 us of every later call had been this.
-    const bool cached = cache.ok[frame] != 0;
+    // (the flag is read ONCE per workgroup and handed round through LDS: every thread takes the same barrier path even if a
+    //  recording call of the frame were to publish while this one starts)
+    __shared__ int s_cached;
+    if (lane == 0) s_cached = __hip_atomic_load(&cache.ok[frame], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool cached = s_cached != 0;
     short *const c_mval = cache.mval + (size_t) frame * cache.nodes_cap;
     int *const c_off = cache.off + (size_t) frame * (size_t) (g.stride + 1);
     unsigned short *const c_rate = cache.crate + (size_t) frame * (size_t) cache.cap;
@@ -743,8 +748,16 @@ __global__ __launch_bounds__(kRateThreads) void k_rate(const int *__restrict__ n
     if ((lane & 63) == 0) { s_min[lane >> 6] = mn; s_max[lane >> 6] = mx; }
     __syncthreads();
     for (int i = 0; i < kRateThreads / 64; i++) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
-    // the first recording call leaves all of the above for the later ones (the flag last: they are later launches)
-    if (record && lane == 0) { cache.mnmx[2 * frame] = mn; cache.mnmx[2 * frame + 1] = mx; if (pt.lds) cache.ok[frame] = 1; }
+    // the first recording call leaves all of the above for the later ones: every thread's part of the cache is fenced, then
+    // the flag is stored with release order
+    if (record) {
+        __threadfence();
+        __syncthreads();
+        if (lane == 0) {
+            cache.mnmx[2 * frame] = mn; cache.mnmx[2 * frame + 1] = mx;
+            if (pt.lds) { __threadfence(); __hip_atomic_store(&cache.ok[frame], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+    }
     }
 
 #ifdef EBCC_RATE_PROFILE

@@ -57,6 +57,29 @@ struct ResidualBuffers {
 };
 constexpr int kPartials = 256;
 
+// Cut slots: several candidate cuts of a frame's SPIHT stream probed in ONE round of the truncation search
+// (/root/reference/src/ebcc_codec.c:777-795 visits one cut per iteration; which cut comes next depends on the outcome, so a
+// round probes the current cut AND the cuts either outcome leads to - the bisection tree a few levels deep - and the
+// search then walks the tree with the real outcomes: same cuts visited, same result, a fraction of the rounds).
+// A probe of slot v reads the bookkeeping, the frame and the base layer of frame `frame_of[v]` and keeps everything it
+// writes - the coarse reconstruction, the coarser levels' results, the statistics - in the slot's own storage.
+struct CutSlots {
+    int capacity = 0;                   // slots
+    size_t stride = 0;                  // floats per slot of A / T / D: the rows above the finest level's detail bands (np / 2)
+    float *A = nullptr, *T = nullptr, *D = nullptr;   // [capacity][stride] coarse reconstruction, level results (alternating)
+    FrameState *fs = nullptr;           // [capacity] the slot's copy of its frame's state + its own probe statistics
+    double *partial = nullptr;          // [capacity][kPartials]
+    unsigned long long *bits = nullptr; // [capacity] the cut
+    int *active = nullptr;              // [capacity]
+    int *frame_of = nullptr;            // [capacity]
+};
+// true: launch_prefix_synthesis_slots can be used for this grid (the fused kernels take it; otherwise: one cut per round)
+bool prefix_slots_supported(const ResidualBuffers &rb, int n_slots);
+// slot v's state = its frame's (everything a probe reads of it: budget, refinement bookkeeping, dc, residual range)
+void launch_slots_setup(const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s);
+// launch_prefix_synthesis_stats for the active slots: cut cs.bits[v] of frame cs.frame_of[v] -> cs.fs[v].maxerr_bits / err_sum
+void launch_prefix_synthesis_slots(const float *data, const float *decoded, const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s);
+
 // ---------------------------------------------------------------- launchers (all asynchronous on `s`)
 
 // min/max of r = data - decoded  -> fs.rmin/rmax   (src/ebcc_codec.c:712-716,730-733)

@@ -501,15 +501,19 @@ constexpr int kFusePairs = 60;
 constexpr int kFuseMaxWaves = 16;
 __global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const float *__restrict__ src, Grid g, size_t np, const int32_t *__restrict__ Cb,
                                                         const uint32_t *__restrict__ sigordb, const uint32_t *__restrict__ lspidxb,
-                                                        const unsigned long long *trunc_bits, const int *active, RowUse u, int strips, int n_frames, int pieces)
+                                                        const unsigned long long *trunc_bits, const int *active, RowUse u, int strips, int n_frames, int pieces,
+                                                        const int *frame_of, size_t src_stride)
 {
     // workgroup = `blockDim.x / 64` neighbouring strips (one per wave) of tile blockIdx.y = piece * n_frames + frame;
-    // one by default (launch_prefix_synthesis_stats has the measurements)
+    // one by default (launch_prefix_synthesis_stats has the measurements).
+    // frame_of (cut slots, residual.hpp): "frame" is a slot - its state, cut, mask, LL input (src) and statistics are the
+    // slot's own; the bookkeeping, the frame and the base layer are those of frame frame_of[slot].
     struct { int strip, frame, piece; } tb{(int) blockIdx.x * ((int) blockDim.x >> 6) + ((int) threadIdx.x >> 6), (int) blockIdx.y % n_frames, (int) blockIdx.y / n_frames};
-    const int frame = tb.frame;
-    if (active && !active[frame]) return;
-    const FrameState &fs = u.fs[frame];
-    unsigned long long nb = trunc_bits[frame], bits0 = fs.budget + 128;   // spiht_decode: num_bits = min(num_bits, bits0) - 128 (spiht_re.c:495-500)
+    const int slot = tb.frame;
+    if (active && !active[slot]) return;
+    const int frame = frame_of ? frame_of[slot] : slot;
+    const FrameState &fs = u.fs[slot];
+    unsigned long long nb = trunc_bits[slot], bits0 = fs.budget + 128;   // spiht_decode: num_bits = min(num_bits, bits0) - 128 (spiht_re.c:495-500)
     if (nb > bits0) nb = bits0;
     const unsigned long long B = nb - 128;
     __shared__ unsigned int rbase[32], rreach[32];
@@ -522,20 +526,20 @@ __global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const flo
     const bool in_range = k >= 0 && k < hx;
     const bool owner = lane >= 2 && lane < 2 + kFusePairs && in_range;
     const int kc = min(max(k, 0), hx - 1);
-    const float *a = src + (size_t) frame * np;
+    const float *a = src + (size_t) slot * src_stride;
     const int32_t *C = Cb + (size_t) frame * np;
     const uint32_t *so = sigordb + (size_t) frame * np, *li = lspidxb + (size_t) frame * np;
     const float *x = u.data + (size_t) frame * u.n_pix, *d = u.decoded + (size_t) frame * u.n_pix;
     const float dc = fs.dc, rmin = fs.rmin, rng = fs.rmax - fs.rmin;
     const int per = (half + pieces - 1) / pieces, ka = tb.piece * per, kb = min(half, ka + per);
-    const size_t part = (size_t) frame * kPartials + (size_t) (tb.strip + strips * tb.piece);
+    const size_t part = (size_t) slot * kPartials + (size_t) (tb.strip + strips * tb.piece);
     const int jstart = max(ka - 2, 0);
     // A probe that only has to answer "is the maximum error above the target?" (the truncation bisection's rounds,
     // /root/reference/src/ebcc_codec.c:788: cur > target moves trunc_lo and uses nothing else of the probe) is decided as
     // soon as one wave has seen such a sample: the waves that start after that leave at once.  Pieces are dispatched
     // piece-major over all frames, so most of an infeasible probe's waves never read their strip.
     const float exit_above = fs.exit_above;
-    if (exit_above > 0.0f && __uint_as_float(__hip_atomic_load(&u.fs[frame].maxerr_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > exit_above) {
+    if (exit_above > 0.0f && __uint_as_float(__hip_atomic_load(&u.fs[slot].maxerr_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > exit_above) {
         if (lane == 0) u.partial[part] = 0.0;
         return;
     }
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(64 * kFuseMaxWaves) void k_finest_inv_use(const flo
     for (int q = 32; q >= 1; q >>= 1) { acc += __shfl_xor(acc, q); mx = fmaxf(mx, __shfl_xor(mx, q)); }
     if (lane == 0) {
         u.partial[part] = acc;
-        atomicMax(&u.fs[frame].maxerr_bits, __float_as_uint(mx));
+        atomicMax(&u.fs[slot].maxerr_bits, __float_as_uint(mx));
     }
 }
 
@@ -1206,7 +1210,7 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
         const int wave_cap = 1;
         const int wg = std::min(strips, wave_cap);
         hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) ceil_div(strips, wg), (unsigned) (n_frames * pieces)), dim3(64 * wg), 0, s, fine_ll, g, rb.np, rb.C, rb.sigord, rb.lspidx,
-                           d_trunc_bits, d_active, u, strips, n_frames, pieces);
+                           d_trunc_bits, d_active, u, strips, n_frames, pieces, (const int *) nullptr, rb.np);
         partials = strips * pieces;
     } else {
         hipLaunchKernelGGL(k_cols_inv_stream, dim3(ceil_div(g.nx, kStreamT), n_frames, pieces), dim3(kStreamT), 0, s, rb.A, rb.T, g, rb.np, rb.C,
@@ -1214,6 +1218,53 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
         partials = synthesis_tail(rb, n_frames, d_active, s, u);
     }
     hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.partial, partials, rb.fs, n_frames, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
+// ---- cut slots (residual.hpp): the same probe for slot v = cut cs.bits[v] of frame cs.frame_of[v]
+void launch_reconstruct_coarse_slots(const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s);   // residual_spiht.hip
+__global__ void k_slots_setup(FrameState *vfs, const FrameState *fs, const int *frame_of, int n_slots)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n_slots) vfs[v] = fs[frame_of[v]];
+}
+bool prefix_slots_supported(const ResidualBuffers &rb, int n_slots)
+{
+    const Grid &g = rb.g;
+    if (g.stages < 2 || g.ny < 32 || (g.nx >> 1) < 2) return false;
+    const int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
+    return ceil_div(g.nx >> 1, kFusePairs) * 8 <= kPartials && (long long) n_slots * 8 <= 65535 && ceil_div(g.nx >> 1, kFusePairs) * pieces <= kPartials;
+}
+void launch_slots_setup(const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_slots_setup, dim3(ceil_div(n_slots, 64)), dim3(64), 0, s, cs.fs, rb.fs, cs.frame_of, n_slots);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+void launch_prefix_synthesis_slots(const float *data, const float *decoded, const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s)
+{
+    const Grid &g = rb.g;
+    hipLaunchKernelGGL(k_probe_init, dim3(ceil_div(n_slots, 64)), dim3(64), 0, s, cs.fs, n_slots, cs.active);
+    launch_reconstruct_coarse_slots(rb, cs, n_slots, s);
+    float *scratch[2] = {cs.T, cs.D};
+    const float *ll = cs.A;
+    int turn = 0;
+    for (int lv = g.stages - 1; lv >= 1; lv--) {
+        const int nx = g.nx >> lv, ny = g.ny >> lv;
+        const int lstrips = ceil_div(nx >> 1, kFusePairs), lpieces = std::max(1, std::min(8, (ny >> 1) / 16));
+        hipLaunchKernelGGL(k_level_inv_fused, dim3((unsigned) lstrips, (unsigned) (n_slots * lpieces)), dim3(64), 0, s, ll, cs.A, scratch[turn], g.nx, cs.stride,
+                           nx, ny, cs.active, lstrips, n_slots, lpieces);
+        ll = scratch[turn];
+        turn ^= 1;
+    }
+    int pieces = std::max(1, std::min(8, (g.ny >> 1) / 16));
+    while (pieces > 1 && (long long) n_slots * pieces > 65535) pieces--;
+    RowUse u{};
+    u.data = data; u.decoded = decoded;
+    u.size_x = g.size_x; u.size_y = g.size_y; u.n_pix = (size_t) g.size_x * g.size_y; u.fs = cs.fs; u.partial = cs.partial;
+    const int strips = ceil_div(g.nx >> 1, kFusePairs);
+    hipLaunchKernelGGL(k_finest_inv_use, dim3((unsigned) strips, (unsigned) (n_slots * pieces)), dim3(64), 0, s, ll, g, rb.np, rb.C, rb.sigord, rb.lspidx,
+                       cs.bits, cs.active, u, strips, n_slots, pieces, cs.frame_of, cs.stride);
+    hipLaunchKernelGGL(k_probe_finish, dim3(ceil_div(n_slots, 64)), dim3(64), 0, s, cs.partial, strips * pieces, cs.fs, n_slots, cs.active);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

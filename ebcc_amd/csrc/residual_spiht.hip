@@ -438,13 +438,17 @@ __global__ __launch_bounds__(kEncThreads) void k_spiht_encode(
 __global__ __launch_bounds__(256) void k_reconstruct(const int32_t *__restrict__ Cb, const uint32_t *__restrict__ sigordb,
                                                       const uint32_t *__restrict__ lspidxb, float *__restrict__ Ab,
                                                       size_t np, const FrameState *fsb,
-                                                      const unsigned long long *trunc_bits, const int *active, Grid g, int coarse_only)
+                                                      const unsigned long long *trunc_bits, const int *active, Grid g, int coarse_only,
+                                                      const int *frame_of, size_t a_stride)
 {
-    const int frame = blockIdx.y;
-    if (active && !active[frame]) return;
-    const FrameState &fs = fsb[frame];
+    // frame_of (cut slots, residual.hpp): blockIdx.y is a slot - state, cut, mask and output are the slot's, the bookkeeping
+    // is its frame's
+    const int slot = blockIdx.y;
+    if (active && !active[slot]) return;
+    const int frame = frame_of ? frame_of[slot] : slot;
+    const FrameState &fs = fsb[slot];
     // spiht_decode: num_bits = min(num_bits, bits0) - 128   (spiht_re.c:495-500)
-    unsigned long long nb = trunc_bits[frame], bits0 = fs.budget + 128;
+    unsigned long long nb = trunc_bits[slot], bits0 = fs.budget + 128;
     if (nb > bits0) nb = bits0;
     const unsigned long long B = nb - 128;
     __shared__ unsigned int rbase[32], rreach[32];
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(const int32_t *__restrict__
     const int32_t *C = Cb + (size_t) frame * np;
     const uint32_t *so = sigordb + (size_t) frame * np;
     const uint32_t *li = lspidxb + (size_t) frame * np;
-    float *A = Ab + (size_t) frame * np;
+    float *A = Ab + (size_t) slot * a_stride;
     // (coarse_only: the LL quadrant of the finest level - what the coarser synthesis levels need; the finest level takes
     //  its three detail bands straight from the bookkeeping, k_cols_inv_stream in residual_dwt.hip)
     const int cx = coarse_only ? g.nx >> 1 : g.nx, cy = coarse_only ? g.ny >> 1 : g.ny;
@@ -935,7 +939,7 @@ void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned 
                         const int *d_active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_reconstruct, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, rb.A, rb.np,
-                       rb.fs, d_trunc_bits, d_active, rb.g, 0);
+                       rb.fs, d_trunc_bits, d_active, rb.g, 0, (const int *) nullptr, rb.np);
     EBCC_HIP_LAUNCH_CHECK();
 }
 
@@ -943,7 +947,14 @@ void launch_reconstruct_coarse(const ResidualBuffers &rb, int n_frames, const un
                                const int *d_active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_reconstruct, dim3(64, n_frames), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, rb.A, rb.np,
-                       rb.fs, d_trunc_bits, d_active, rb.g, 1);
+                       rb.fs, d_trunc_bits, d_active, rb.g, 1, (const int *) nullptr, rb.np);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
+void launch_reconstruct_coarse_slots(const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reconstruct, dim3(64, n_slots), dim3(256), 0, s, rb.C, rb.sigord, rb.lspidx, cs.A, rb.np,
+                       cs.fs, cs.bits, cs.active, rb.g, 1, cs.frame_of, cs.stride);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

@@ -170,13 +170,10 @@ __global__ void k_search_advance(DevChunk *chunks, J2kFrame *jf, int *active, in
 
 // ---- :765-796 ------------------------------------------------------------------------------------------
 __global__ void k_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *active, int n_chunks,
-                                double n_pix, int *unfinished, const int *group, int which)
+                                double n_pix, int *unfinished)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_chunks) return;
-    // the frames of the other group belong to another stream's rounds (their state may be changing right now): not one of
-    // their words is read or written, only this group's mask says "not mine"
-    if (group && group[f] != which) { active[f] = 0; return; }
     DevChunk &C = chunks[f];
     if (!C.trunc_active) { active[f] = 0; return; }
     if (C.trunc_pending) {
@@ -213,25 +210,72 @@ void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_
 }
 
 void launch_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
-                          double n_pix, int *unfinished, hipStream_t s, const int *group, int which)
+                          double n_pix, int *unfinished, hipStream_t s)
 {
     hipLaunchKernelGGL(k_trunc_advance, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, fs, trunc_bits, d_active, n_chunks, n_pix,
-                       unfinished, group, which);
+                       unfinished);
     EBCC_HIP_LAUNCH_CHECK();
 }
 
-// the mask of the frames still searching, taken apart by group: mask1 gets group 1's entries, mask0 keeps the others
-__global__ void k_trunc_split(const int *group, int *mask0, int *mask1, int n_chunks)
+// ---- the same with look-ahead (cut slots, residual.hpp): a round probes the bisection tree `levels` deep below the current
+//      interval - node 0 the cut :779 would choose now, node 2 i + 1 the cut it would choose next if node i turns out
+//      feasible (t_hi = cut), node 2 i + 2 if not (t_lo = cut) - and this kernel then walks the tree with the real
+//      outcomes, statement for statement what `levels` iterations of :777-795 do: same cuts consumed in the same order,
+//      same t_lo / t_hi / best error / mean error; the probes off the path are simply not looked at.
+__global__ void k_trunc_advance_multi(DevChunk *chunks, const FrameState *fs, CutSlots cs, int n_chunks, double n_pix, int levels,
+                                      const int *rank, int *unfinished)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_chunks) return;
-    const int a = mask0[f], g = group[f];
-    mask1[f] = g ? a : 0;
-    mask0[f] = g ? 0 : a;
+    const int r = rank ? rank[f] : f;
+    if (r < 0) return;                                                   // (not in this launch: not a word of it is touched)
+    const int K = (1 << levels) - 1, v0 = r * K;
+    DevChunk &C = chunks[f];
+    if (!C.trunc_active) { for (int i = 0; i < K; i++) cs.active[v0 + i] = 0; return; }
+    const double eps = 1e-8;
+    auto goes_on = [&]() { return ((C.target - C.best_err) / C.target > eps) && (C.t_hi - C.t_lo > 8 * 4); };   // :777
+    if (C.trunc_pending) {
+        int node = 0;
+        for (int depth = 0; depth < levels && goes_on(); depth++) {
+            // (cs.bits[v0 + node] is the cut the loop chooses at this point: the proposals below follow its arithmetic)
+            const double tb = (double) cs.bits[v0 + node];
+            const float cur = __uint_as_float(cs.fs[v0 + node].maxerr_bits);
+            if (cur > C.target) { C.t_lo = tb; node = 2 * node + 2; }
+            else {
+                C.t_hi = tb;
+                if (cur >= C.best_err) { C.best_err = cur; C.t_best = tb; C.mean_err = cs.fs[v0 + node].err_sum / n_pix; }
+                node = 2 * node + 1;
+            }
+        }
+        C.trunc_pending = 0;
+    }
+    if (!goes_on()) {
+        C.trunc_active = 0;
+        for (int i = 0; i < K; i++) cs.active[v0 + i] = 0;
+        return;
+    }
+    double lo[7], hi[7];
+    bool on[7];
+    lo[0] = C.t_lo; hi[0] = C.t_hi;
+    for (int i = 0; i < K; i++) {
+        on[i] = (i == 0 || on[(i - 1) >> 1]) && (hi[i] - lo[i] > 8 * 4);
+        cs.active[v0 + i] = on[i] ? 1 : 0;
+        if (!on[i]) continue;
+        const unsigned long long cut = (unsigned long long) ceil((hi[i] + lo[i]) / 2 / 8) * 8ull;     // :779
+        cs.bits[v0 + i] = cut;
+        cs.frame_of[v0 + i] = f;
+        cs.fs[v0 + i] = fs[f];                                           // (what a probe reads of the frame's state)
+        cs.fs[v0 + i].exit_above = C.target;                             // (cur > target is all that is asked of an infeasible cut)
+        if (2 * i + 2 < K) { lo[2 * i + 1] = lo[i]; hi[2 * i + 1] = (double) cut; lo[2 * i + 2] = (double) cut; hi[2 * i + 2] = hi[i]; }
+    }
+    C.trunc_pending = 1;
+    atomicAdd(unfinished, 1);
 }
-void launch_trunc_split(const int *group, int *mask0, int *mask1, int n_chunks, hipStream_t s)
+
+void launch_trunc_advance_multi(DevChunk *chunks, const FrameState *fs, const CutSlots &cs, int n_chunks, double n_pix, int levels,
+                                const int *rank, int *unfinished, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_trunc_split, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, group, mask0, mask1, n_chunks);
+    hipLaunchKernelGGL(k_trunc_advance_multi, dim3(ceil_div(n_chunks, 64)), dim3(64), 0, s, chunks, fs, cs, n_chunks, n_pix, levels, rank, unfinished);
     EBCC_HIP_LAUNCH_CHECK();
 }
 

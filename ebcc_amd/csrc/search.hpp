@@ -62,11 +62,12 @@ void launch_search_advance(DevChunk *chunks, J2kFrame *jf, int *d_active, int n_
 
 // One round of the truncation bisection: take in the statistics of the cut made in the previous round, choose the next
 // cut (trunc_bits[f], active[f] = 1) or finish.
-// group / which (optional): only the chunks with group[f] == which are advanced - the others are left alone word for word
-// (another stream runs their rounds) and get d_active[f] = 0 in THIS call's mask.
 void launch_trunc_advance(DevChunk *chunks, FrameState *fs, unsigned long long *trunc_bits, int *d_active, int n_chunks,
-                          double n_pix, int *unfinished, hipStream_t s, const int *group = nullptr, int which = 0);
-// mask1[f] = group[f] ? mask0[f] : 0; mask0[f] = group[f] ? 0 : mask0[f]
-void launch_trunc_split(const int *group, int *mask0, int *mask1, int n_chunks, hipStream_t s);
+                          double n_pix, int *unfinished, hipStream_t s);
+// One round of the bisection with look-ahead: `levels` (1..3) iterations of :777-795 per round from the outcomes of the
+// 2^levels - 1 cuts the previous round proposed (cut slots, residual.hpp); chunk f uses slots rank[f] * K .. (rank null: f;
+// rank[f] < 0: the chunk is not part of this launch).  Writes cs.bits / active / frame_of / fs of its slots.
+void launch_trunc_advance_multi(DevChunk *chunks, const FrameState *fs, const CutSlots &cs, int n_chunks, double n_pix, int levels,
+                                const int *rank, int *unfinished, hipStream_t s);
 
 }  // namespace ebcc

@@ -122,15 +122,27 @@ class BatchCodec:
 _SUPER = 16         # batches handed to the engine per call by write_frames / read_frames (filling and draining the two sets costs ~half a batch)
 
 # Engines are expensive to make (tens of GB of device workspace for 256 frames of 721 x 1440) and cheap to keep: the
-# helpers below share one per (height, width, capacity, device) for the life of the process (close_cached() lets go).
+# helpers below share ONE per (height, width, device) for the life of the process - a codec made for more frames serves a
+# request for fewer, a larger request replaces it (the old one is closed first), and when the device has no room for a new
+# engine every cached one is closed and the creation is tried once more.  close_cached() gives the memory back; callers
+# that hold datasets of many geometries in one process and want the memory between them call it themselves.
 _codecs = {}
 
 
 def cached_codec(height, width, max_frames=256, device=0):
-    key = (int(height), int(width), int(max_frames), int(device))
+    key = (int(height), int(width), int(device))
     c = _codecs.get(key)
-    if c is None or not c.ctx:
-        c = _codecs[key] = BatchCodec(height, width, max_frames, device)
+    if c is not None and c.ctx and c.max_frames >= int(max_frames):
+        return c
+    if c is not None:
+        c.close()
+        del _codecs[key]
+    try:
+        c = BatchCodec(height, width, max_frames, device)
+    except RuntimeError:
+        close_cached()                                          # (other geometries' engines may hold the memory)
+        c = BatchCodec(height, width, max_frames, device)
+    _codecs[key] = c
     return c
 
 

@@ -91,8 +91,8 @@ int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t 
  * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
  * one frame / ebcc_encode_chunking with chunk_dims {1,H,W} produce).  Streams are malloc'd (free_buffer).
  * Return 0 = ok, 1 = error, 2 = NaN/Inf in the input; on failure entries of out_streams that are not NULL
- * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default 2), each on its own engine, stream and host thread; results do not depend on the
- * slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
+ * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default: ebcc_hip_default_encode_slices() = 3),
+ * each on its own engine, stream and host thread; results do not depend on the slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
  * n_frames (part of setting a context up, like ebcc_hip_create).  Returns 0. */
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
 /* ebcc_encode / ebcc_decode / the chunking entry points and the HDF5 filter (/root/reference/src/ebcc_codec.h:41-49) keep
@@ -140,10 +140,13 @@ int ebcc_hip_decode_shard(ebcc_hip_ctx *ctx, const uint8_t *const *streams, cons
                           float *d_frames_out);
 
 /* Worker threads of the process-wide host pool that runs the entropy stage (level-22 zstd of the residual prefixes) of
- * every slice of every call: EBCC_HOST_THREADS, else the CPUs the process may really use - its affinity mask cut down to
- * the container's CPU quota (cgroup cpu.max) - divided by LOCAL_WORLD_SIZE when the process is one rank of a multi-process
- * job, minus one per slice for the threads that steer the GPU. */
+ * every slice of every call: EBCC_HOST_THREADS, else min(affinity mask, TWICE the container's CPU quota (cgroup cpu.max): the
+ * stage comes in bursts, a burst may run wider than the quota as long as a period's total stays below it) divided by
+ * LOCAL_WORLD_SIZE when the process is one rank of a multi-process job, minus min(slices, 2) for the threads that steer the
+ * GPU (none subtracted from a share of 4 or fewer); at most 64. */
 int ebcc_hip_host_threads(int slices);
+/* Slices an encode batch runs as when EBCC_HIP_SLICES is not set. */
+int ebcc_hip_default_encode_slices(void);
 /* Host-side accounting since the last reset: out[0] usable CPUs (affinity and quota), out[1] CPU quota of the container in
  * CPUs (0: none), out[2] core-seconds spent in zstd, out[3] seconds the slices waited for the zstd workers, out[4] bytes
  * compressed, out[5] entropy batches, out[6] prefix bytes whose compression was proved unnecessary (ebcc_hip_zstd_floor).  bench.py prints them per rank (a run bound by the host's CPUs shows here). */

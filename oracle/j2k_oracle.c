@@ -10,7 +10,10 @@
  * the algorithms restated here are ITU-T T.800 (JPEG 2000 part 1): Annex B (codestream/packets),
  * C (MQ coder), D (coefficient bit modelling), E (quantisation), F (9/7 wavelet), J.14 (PCRD), written
  * to reproduce OpenJPEG 2.4.0's arithmetic order.  Pinned against golden vectors generated with that
- * library through opj_backend.c (tests/golden/j2k_*.npz) - see tests/test_oracle_j2k.py.
+ * library through opj_backend.c: tests/golden/j2k_openjpeg.json + j2k_inputs.npz (oracle/make_golden_j2k.py; 37
+ * codestreams of 8 images at rates 1 ... 900 with their decoded samples), checked on any box by
+ * tests/test_oracle_golden.py::test_j2k_restatement_against_openjpeg_fixtures, and live against the library where it
+ * exists (test_j2k_restatement_matches_openjpeg_live); the whole-frame fixtures pin it once more through the frame codec.
  */
 #include "oracle.h"
 

@@ -482,14 +482,18 @@ def test_host_and_device_search_loops_agree(monkeypatch):
         cfg = L.make_config((1, 96, 160), base_cr=40.0, error=err, residual_type=mode)
         got = {}
         for name, env in (("device", {}), ("host", {"EBCC_HIP_HOST_SEARCH": "1"}), ("short", {"EBCC_HIP_SEARCH_ROUNDS": "3"}),
-                          ("plain", {"EBCC_HIP_SPECULATION": "0"}), ("spec", {"EBCC_HIP_SPECULATION": "1"}), ("exact", {"EBCC_HIP_NO_SHORTCUTS": "1"})):
+                          ("plain", {"EBCC_HIP_SPECULATION": "0"}), ("spec", {"EBCC_HIP_SPECULATION": "1"}), ("exact", {"EBCC_HIP_NO_SHORTCUTS": "1"}),
+                          # the truncation bisection one cut per round, three levels of look-ahead per round (default: two), and the
+                          # look-ahead in batches of rounds too short for the search
+                          ("cut1", {"EBCC_HIP_TRUNC_LEVELS": "1"}), ("cut3", {"EBCC_HIP_TRUNC_LEVELS": "3"}),
+                          ("cut2short", {"EBCC_HIP_TRUNC_LEVELS": "2", "EBCC_HIP_SEARCH_ROUNDS": "2"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             with L.Context(len(frames), 96, 160) as ctx:
                 got[name] = ctx.encode_frames(frames, cfg)
             for k in env:
                 monkeypatch.delenv(k)
-        assert got["device"] == got["host"] == got["short"] == got["plain"] == got["spec"] == got["exact"], mode
+        assert all(v == got["device"] for v in got.values()), (mode, [k for k, v in got.items() if v != got["device"]])
         L.oracle().orc_set_j2k_backend(0)
         assert got["device"][3] == L.orc_encode(frames[3], cfg)
 

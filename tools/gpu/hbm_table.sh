@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU box: every bandwidth-bound kernel measured alone -> gpurun_out/hbm/r03_hbm_kernels.json (copy to profiles/), and the
-# tier-1 encoder's counter traffic -> gpurun_out/hbm/r03_pmc_tier1.json.   gpurun --timeout 1100 -- 'bash tools/gpu/hbm_table.sh'
+# GPU box: every bandwidth-bound kernel measured alone -> gpurun_out/hbm/r04_hbm_kernels.json (copy to profiles/), and the
+# tier-1 encoder's counter traffic -> gpurun_out/hbm/r04_pmc_tier1.json.   gpurun --timeout 1100 -- 'bash tools/gpu/hbm_table.sh'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/hbm
 F=${1:-256}
@@ -14,10 +14,10 @@ done
 T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 A=$(find $O/FETCH_SIZE -name "*counter_collection.csv" | head -1)
 B=$(find $O/WRITE_SIZE -name "*counter_collection.csv" | head -1)
-SHA=$(cat ebcc_amd/csrc/j2k_analysis.hip ebcc_amd/csrc/t1_core.hpp | sha256sum | cut -c1-16)
+SHA=$(cat ebcc_amd/csrc/j2k_analysis.hip ebcc_amd/csrc/t1_core.hpp ebcc_amd/csrc/j2k_rate.hip ebcc_amd/csrc/residual_dwt.hip ebcc_amd/csrc/residual_spiht.hip | sha256sum | cut -c1-16)
 head -1 $T > $O/trace_header.txt; head -1 $A > $O/counter_header.txt
-python3 tools/hbm_table.py $T $A $B $F $SHA > $O/r03_hbm_kernels.json
-python3 - $A $B $F $SHA > $O/r03_pmc_tier1.json <<'PY'
+python3 tools/hbm_table.py $T $A $B $F $SHA > $O/r04_hbm_kernels.json
+python3 - $A $B $F $SHA > $O/r04_pmc_tier1.json <<'PY'
 import csv, json, re, sys
 def per_kernel(path, counter):
     acc = {}
@@ -35,7 +35,7 @@ print(json.dumps({"kernels": ks, "fetch_kb": f, "write_kb": w, "frames_per_dispa
                   "bytes_per_frame_fetch_x2_plus_write": int(per_frame),
                   "unit": "KB as reported by rocprofv3; FETCH_SIZE x 2 on gfx950 (micro-architecture guide)"}, indent=1))
 PY
-python3 - $A $B $F $SHA > $O/r03_step_traffic.json <<'PY'
+python3 - $A $B $F $SHA > $O/r04_step_traffic.json <<'PY'
 import csv, json, re, sys
 def total(path, counter):
     acc = {}
@@ -57,10 +57,10 @@ PY
 rm -rf $O/trace $O/FETCH_SIZE $O/WRITE_SIZE
 python3 - <<'PY'
 import json
-d = json.load(open("gpurun_out/hbm/r03_hbm_kernels.json"))
+d = json.load(open("gpurun_out/hbm/r04_hbm_kernels.json"))
 print("unmatched", d["unmatched_dispatches"])
 for r in d["kernels"][:40]:
     print(f'{r["kernel"][:34]:34s} {r["grid_threads"]:9d} {r["duration_us"]:9.1f} us  {r["achieved_GBps"]:8.1f} GB/s  {100*(r["frac_of_6290"] or 0):5.1f}% of 6.29  x{r["counter_over_algorithmic"]:5.2f} counter  ({r["dispatches_all_frames_active"]}/{r["dispatches"]}) {"cache-served" if r.get("cache_served") else ""}')
-print(open("gpurun_out/hbm/r03_pmc_tier1.json").read()[:700])
-print(open("gpurun_out/hbm/r03_step_traffic.json").read()[:1500])
+print(open("gpurun_out/hbm/r04_pmc_tier1.json").read()[:700])
+print(open("gpurun_out/hbm/r04_step_traffic.json").read()[:1500])
 PY

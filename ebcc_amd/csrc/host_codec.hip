@@ -927,6 +927,11 @@ void device_rate_search(Batch &b, int k, Jobs &jobs, size_t n_pix, unsigned slic
         enqueue_rounds(6);
     }
     log_trace("rate search %d: %d probes of chunks over the rounds", k, h_counter[0]);
+    if (getenv("EBCC_HIP_PHASE_TIMING")) {
+        int most = 0; long long sum = 0;
+        for (size_t f = 0; f < n; f++) { most = std::max(most, h[f].n_probes); sum += h[f].n_probes; }
+        fprintf(stderr, "ebcc-mi355x rate search %d: %d probes over the rounds, probes on record per chunk: mean %.1f, most %d\n", k, h_counter[0], (double) sum / (double) n, most);
+    }
     if (getenv("EBCC_HIP_T1_STATS") && slices <= 1) j2k_probe_hist_dump(k == 0 ? "search #1" : "search #2");
     for (size_t f = 0; f < n; f++) {
         Job &j = jobs[f];
@@ -1188,24 +1193,20 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
             b.push_ractive();
             launch_pad_and_dc(d_frames, jb.DEC, rc->rb, (int) n, rc->d_active, rs);
             launch_analysis(rc->rb, (int) n, rc->d_active, rs);
-            fetch_frame_states(rc, n);
-            for (size_t f = 0; f < n; f++) {
-                unsigned long long bits0 = (unsigned long long) jobs[f].len1 * 8 + 128;       // trunc_bits + 128
-                rc->h_u64a[f] = bits0;
-                rc->h_fs[f].budget = bits0 - 128;
-                rc->h_fs[f].exit_above = 0.0f;                                               // (the host's own probes are exact)
-            }
-            push_frame_states(rc, n);
+            // (budgets, the encoder, the cut "everything" and its probe are queued without a look at the frame states in
+            //  between: the budget follows from the base layer's size, the whole stream's length stays on the device)
+            for (size_t f = 0; f < n; f++) rc->h_u64a[f] = (unsigned long long) jobs[f].len1 * 8 + 128;   // bits0 = trunc_bits + 128
             EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64a, rc->h_u64a, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
+            launch_residual_budget(rc->rb, (int) n, rc->d_u64a, rc->d_active, rs);
             launch_spiht_encode(rc->rb, (int) n, rc->d_u64a, rc->d_active, rs);
+            launch_whole_stream_cut(rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
+            launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);   // full decode, :749
             fetch_frame_states(rc, n);
-            pt.mark("residual: analysis, SPIHT");
             for (size_t f = 0; f < n; f++) {
                 if (!b.active[f]) continue;
                 jobs[f].coeffs_orig = rc->h_fs[f].stream_bytes;
                 jobs[f].coeffs_size = jobs[f].coeffs_orig;
-                rc->h_u64b[f] = (unsigned long long) jobs[f].coeffs_orig * 8;                // full decode, :749
-                rc->h_fs[f].dec_dc = (int) rc->h_fs[f].dc;
+                rc->h_u64b[f] = (unsigned long long) jobs[f].coeffs_orig * 8;
             }
             auto probe_residual = [&]() {
                 EBCC_HIP_CHECK(hipMemcpyAsync(rc->d_u64b, rc->h_u64b, n * sizeof(unsigned long long), hipMemcpyHostToDevice, rs));
@@ -1213,8 +1214,7 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 launch_prefix_synthesis_stats(d_frames, jb.DEC, rc->rb, (int) n, rc->d_u64b, rc->d_active, rs);
                 fetch_frame_states(rc, n);
             };
-            probe_residual();
-            pt.mark("residual: whole-stream probe");
+            pt.mark("residual: analysis, SPIHT, whole-stream probe");
             for (size_t f = 0; f < n; f++) {
                 Job &j = jobs[f];
                 if (!b.active[f]) continue;

@@ -101,6 +101,11 @@ void launch_analysis(const ResidualBuffers &rb, int n_frames, const int *d_activ
 void launch_spiht_encode(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, const int *d_active,
                          hipStream_t s);
 
+// fs[f].budget = d_bits0[f] - 128 (and exact probes) for the active frames: what the host used to set between the analysis
+// and the encoder; d_trunc_bits[f] = 8 * fs[f].stream_bytes: the cut "everything", for the probe of src/ebcc_codec.c:749-754
+void launch_residual_budget(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, const int *d_active, hipStream_t s);
+void launch_whole_stream_cut(const ResidualBuffers &rb, int n_frames, unsigned long long *d_trunc_bits, const int *d_active, hipStream_t s);
+
 // Decoder state after the first `trunc_bits[f]` stream bits, rebuilt from the encoder's bookkeeping:
 // A = coefficient grid as spiht_decode_process would leave it  (spiht_re.c:319-430 semantics)
 void launch_reconstruct(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_trunc_bits,

@@ -1221,6 +1221,32 @@ void launch_prefix_synthesis_stats(const float *data, const float *decoded, cons
     EBCC_HIP_LAUNCH_CHECK();
 }
 
+// ---- per-frame parameters of the residual layer set where they are used (no trip of the frame states through the host)
+__global__ void k_residual_budget(FrameState *fs, const unsigned long long *bits0, int n_frames, const int *active)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames || (active && !active[f])) return;
+    fs[f].budget = bits0[f] - 128;                                        // trunc_bits (src/spiht/spiht_re.c:433-446: bits0 = trunc_bits + 128)
+    fs[f].exit_above = 0.0f;                                              // (probes are exact unless a search says otherwise)
+}
+__global__ void k_whole_stream_cut(FrameState *fs, unsigned long long *trunc_bits, int n_frames, const int *active)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames || (active && !active[f])) return;
+    trunc_bits[f] = (unsigned long long) fs[f].stream_bytes * 8ull;       // src/ebcc_codec.c:749: decode of everything that was written
+    fs[f].dec_dc = (int) fs[f].dc;
+}
+void launch_residual_budget(const ResidualBuffers &rb, int n_frames, const unsigned long long *d_bits0, const int *d_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_residual_budget, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, d_bits0, n_frames, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+void launch_whole_stream_cut(const ResidualBuffers &rb, int n_frames, unsigned long long *d_trunc_bits, const int *d_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_whole_stream_cut, dim3(ceil_div(n_frames, 64)), dim3(64), 0, s, rb.fs, d_trunc_bits, n_frames, d_active);
+    EBCC_HIP_LAUNCH_CHECK();
+}
+
 // ---- cut slots (residual.hpp): the same probe for slot v = cut cs.bits[v] of frame cs.frame_of[v]
 void launch_reconstruct_coarse_slots(const ResidualBuffers &rb, const CutSlots &cs, int n_slots, hipStream_t s);   // residual_spiht.hip
 __global__ void k_slots_setup(FrameState *vfs, const FrameState *fs, const int *frame_of, int n_slots)

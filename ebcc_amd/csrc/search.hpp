@@ -5,7 +5,7 @@
 // The decision sequence is the reference's, evaluated unchanged (same float / double expressions in the same
 // order); what moves is where it runs: a one-thread-per-chunk kernel reads the statistics the previous probe left on
 // the device, advances the state machine and writes the next rate (or cut point) and the active mask, so a whole
-// search is enqueued as a fixed number of rounds without the host in the loop (host_codec.hip: device_rate_search,
+// search is enqueued as a fixed number of rounds without the host in the loop (batch_codec.hip: device_rate_search,
 // device_truncation).  Rounds in which no chunk is active cost their launches only - every probe kernel returns at
 // once for inactive frames.
 #pragma once

@@ -152,7 +152,7 @@ int ebcc_hip_default_encode_slices(void);
  * compressed, out[5] entropy batches, out[6] prefix bytes whose compression was proved unnecessary (ebcc_hip_zstd_floor).  bench.py prints them per rank (a run bound by the host's CPUs shows here). */
 void ebcc_hip_host_stats(double *out, int reset);
 /* Lower bound (bytes) of the zstd frame ZSTD_compress writes for [src, src + n) at any level, from the format alone (the
- * literals no match can cover cost at least their entropy; host_codec.hip: zstd_size_lower_bound); 0 = no bound (n above
+ * literals no match can cover cost at least their entropy; host_pool.hip: zstd_size_lower_bound); 0 = no bound (n above
  * 4 MB, or a libzstd that may split blocks).  The encoder uses it to decide the reference's "pure base layer beats base +
  * residual" comparison (src/ebcc_codec.c:838) without compressing prefixes that provably lose it. */
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n);

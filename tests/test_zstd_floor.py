@@ -1,4 +1,4 @@
-"""The entropy-stage shortcut of the encoder (host_codec.hip: zstd_size_lower_bound / ebcc_hip_zstd_floor).
+"""The entropy-stage shortcut of the encoder (host_pool.hip: zstd_size_lower_bound / ebcc_hip_zstd_floor).
 
 The reference compresses every kept SPIHT prefix at zstd level 22 and then compares the size z with the pure base-layer
 alternative (/root/reference/src/ebcc_codec.c:813-817, :838); the MI355X encoder skips the compression where a lower bound of z

@@ -287,4 +287,9 @@ bool tile_height_supported(size_t h);
 bool tile_geometry_uniform(size_t h);
 int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *streams, const size_t *sizes, size_t n, size_t tiles, float *d_out);
 
+// ---- frames in host memory <-> frame streams on the engines the reference-compatible entry points keep (host_codec.hip):
+//      any number of one-frame chunks of H x W, batches of EBCC_HIP_MAX_BATCH on alternating engine sets.  0 ok, 1 error, 2 NaN/Inf
+int cached_encode_host_frames(const float *h_frames, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes);
+int cached_decode_host_frames(const uint8_t *const *streams, const size_t *sizes, size_t n, int H, int W, float *h_out);
+
 }  // namespace ebcc

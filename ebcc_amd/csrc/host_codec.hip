@@ -490,6 +490,39 @@ int run_decode_slices(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const si
 
 }  // namespace
 
+namespace ebcc {
+
+int cached_encode_host_frames(const float *h_frames, size_t n, int H, int W, const codec_config_t *cfg, uint8_t **outs, size_t *sizes)
+{
+    return encode_host_frames(resolve_device(), h_frames, n, H, W, cfg, outs, sizes);
+}
+
+int cached_decode_host_frames(const uint8_t *const *streams, const size_t *sizes, size_t n, int H, int W, float *h_out)
+{
+    try {
+        const int device = resolve_device();
+        std::lock_guard<std::mutex> lock(device_mutex(device));
+        DeviceScope scope(device);
+        if (!zstd().ok) { log_fatal("libzstd not available"); return 1; }
+        const size_t n_pix = (size_t) H * W, cap = std::min(n, batch_capacity(n_pix));
+        ebcc_hip_ctx *ctx = get_context(device, H, W, cap);
+        if (!ctx) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
+        return decode_batches_alternating(ctx, n, ctx->max_frames, [&](ebcc_hip_ctx *set, size_t lo, size_t k) {
+            float *d = io_buffer(set, ctx->max_frames * n_pix * sizeof(float));
+            const int r = run_decode_slices(set, streams + lo, sizes + lo, k, d);
+            if (r) return r;
+            copy_pageable(set, h_out + lo * n_pix, d, k * n_pix * sizeof(float), true);
+            return 0;
+        });
+    } catch (const std::exception &e) {
+        log_fatal("MI355X engine failure: %s", e.what());
+        set_error("%s", e.what());
+        return 1;
+    }
+}
+
+}  // namespace ebcc
+
 extern "C" {
 
 void free_buffer(void *p) { if (p) free(p); }

@@ -139,6 +139,17 @@ int ebcc_hip_encode_shard(ebcc_hip_ctx *ctx, const float *d_frames, size_t n_fra
 int ebcc_hip_decode_shard(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t *sizes, size_t n_frames,
                           float *d_frames_out);
 
+/* Direct-chunk batch path for C callers (netCDF-C / CDO-style pipelines; ebcc_amd/h5_batch.py is the Python form): a dataset
+ * whose chunks are single frames - chunk dims (1, ..., 1, H, W), filter 308 as /root/reference/src/h5z_ebcc.c:38-93 reads it -
+ * is written / read in device batches instead of one filter callback per chunk (/root/reference/src/h5z_ebcc.c:124-148 is
+ * what HDF5 would call per chunk): frames [first_frame, first_frame + n_frames), counted in C order over the leading
+ * dimensions, are coded with the dataset's own filter parameters and stored pre-filtered with H5Dwrite_chunk, or fetched with
+ * H5Dread_chunk and decoded together.  dset_id: the hid_t (HDF5 >= 1.10) of the open dataset.  HDF5 is not linked: its
+ * functions are taken from the libhdf5 the calling process has loaded.  Chunk bytes are identical to the callback's.
+ * 0 = ok, 1 = error (logged); NaN / Inf in the frames exits with status 1 like the filter callback. */
+int ebcc_h5_write_frames(long long dset_id, size_t first_frame, size_t n_frames, const float *frames);
+int ebcc_h5_read_frames(long long dset_id, size_t first_frame, size_t n_frames, float *frames_out);
+
 /* Worker threads of the process-wide host pool that runs the entropy stage (level-22 zstd of the residual prefixes) of
  * every slice of every call: EBCC_HOST_THREADS, else min(affinity mask, TWICE the container's CPU quota (cgroup cpu.max): the
  * stage comes in bursts, a burst may run wider than the quota as long as a period's total stays below it) divided by

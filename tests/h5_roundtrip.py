@@ -40,6 +40,31 @@ assert raw_dc == raw_cb, [len(a) - len(b) for a, b in zip(raw_dc, raw_cb)]
 print("OK direct-chunk bytes == callback bytes", sum(len(r) for r in raw_dc))
 assert np.array_equal(via_callback, back) and np.array_equal(via_batch, back)
 print("OK batch read == callback read")
+# (2b) the same through the C entry points (ebcc_h5_write_frames / ebcc_h5_read_frames: what a netCDF-C / CDO-style caller
+#      uses; they find H5Dwrite_chunk / H5Dread_chunk in the HDF5 library h5py has loaded), on a dataset with two leading
+#      dimensions, written in two calls
+import ctypes  # noqa: E402
+import ebcc_amd  # noqa: E402
+lib = ctypes.CDLL(ebcc_amd.EBCC_FILTER_PATH)
+lib.ebcc_h5_write_frames.argtypes = [ctypes.c_longlong, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+lib.ebcc_h5_read_frames.argtypes = [ctypes.c_longlong, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+data4 = np.ascontiguousarray(data.reshape(2, 3, H, W))
+with h5py.File(os.path.join(out, "c.h5"), "w") as f:
+    d = h5_batch.create_dataset(f, "t", data4.shape, 20, opt)
+    assert lib.ebcc_h5_write_frames(d.id.id, 0, 4, data4.ctypes.data) == 0
+    assert lib.ebcc_h5_write_frames(d.id.id, 4, 2, data4.reshape(N, H, W)[4:].ctypes.data) == 0
+    assert lib.ebcc_h5_write_frames(d.id.id, 5, 2, data4.ctypes.data) != 0          # (past the end: refused)
+with h5py.File(os.path.join(out, "c.h5"), "r") as f:
+    raw_c = [f["t"].id.read_direct_chunk((k // 3, k % 3, 0, 0))[1] for k in range(N)]
+    via_cb4 = f["t"][...]
+    got = np.full((N, H, W), -1.0, np.float32)
+    ds = f["t"]                                                  # (the hid_t lives as long as this object)
+    assert lib.ebcc_h5_read_frames(ds.id.id, 0, N, got.ctypes.data) == 0
+    part = np.full((2, H, W), -1.0, np.float32)
+    assert lib.ebcc_h5_read_frames(ds.id.id, 3, 2, part.ctypes.data) == 0
+assert raw_c == raw_cb
+assert np.array_equal(via_cb4.reshape(N, H, W), back) and np.array_equal(got, back) and np.array_equal(part, back[3:5])
+print("OK C direct-chunk entry points: same chunk bytes, same frames")
 # (3) chunks of two frames: the filter callback receives both frames at once (one multi-tile codestream per chunk)
 h2, w2 = 45, 64                          # (not a multiple of 32: the second tile of a chunk has its own JPEG 2000 geometry)
 multi = np.stack([(260 + 8 * np.sin(x[:h2, :w2] / (5.0 + k)) + rng.normal(0, 0.2, (h2, w2))).astype(np.float32) for k in range(4)])

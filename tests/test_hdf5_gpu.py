@@ -23,7 +23,7 @@ def test_hdf5_filter_and_direct_chunk_batch(tmp_path):
     r = subprocess.run([CONDA_PY, os.path.join(L.ROOT, "tests", "h5_roundtrip.py"), str(tmp_path)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("OK") == 4, r.stdout
+    assert r.stdout.count("OK") == 5, r.stdout
     # what HDF5 stored == the oracle's frame streams for the same frames
     chunks = np.load(tmp_path / "chunks.npy", allow_pickle=True)
     data = np.load(tmp_path / "data.npy")

@@ -180,10 +180,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the codec has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # EBCC_BENCH_SHARE_GPU=1 (rehearsal on a box with fewer GPUs than ranks: tests/test_bench_ranks_gpu.py): the ranks take the
+    # visible devices round-robin and talk through gloo - RCCL refuses two ranks on one device; the rank logic (barrier,
+    # max-over-ranks time, gathered host figures, whole-job value) is the same
+    share = os.environ.get("EBCC_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from tests import _lib as L                     # ctypes bindings of the C-ABI (after torch: one HIP runtime)
     lib = L.product()
@@ -191,7 +199,7 @@ def main():
     lib.ebcc_hip_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_long)]
     n = args.frames
-    ctx = lib.ebcc_hip_create(local_rank, n, H, W)
+    ctx = lib.ebcc_hip_create(dev_index, n, H, W)
     assert ctx, lib.ebcc_hip_last_error()
     lib.ebcc_hip_prepare.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     assert lib.ebcc_hip_prepare(ctx, n) == 0                    # slice engines: part of the context, not of a step
@@ -269,7 +277,7 @@ def main():
     max_err = float((out - frames).abs().amax())
     assert max_err <= MAX_ERR * 1.01 + 1e-3, max_err
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
     hosts = [host]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -302,7 +302,7 @@ def main():
             if r.returncode != 0:
                 return {"error": (r.stderr or r.stdout)[-400:]}
             out_ = json.loads(r.stdout.strip().splitlines()[-1])
-            out_["workload"] = f"{frames_} one-frame chunks 721x1440 (error bound 0.5) through h5py {conda}: filter callback (16 frames), direct-chunk device batches, and a dataset of four such batches (on two alternating engine sets); files in memory-backed /dev/shm"
+            out_["workload"] = f"{frames_} one-frame chunks 721x1440 (error bound 0.5) through h5py {conda}: filter callback (16 frames after a warm-up chunk), direct-chunk device batches (Python helper and the C entry points), and a dataset of four such batches (on two alternating engine sets); files in memory-backed /dev/shm"
             return out_
         except Exception as e:                                      # (a report, never a gate)
             return {"error": repr(e)}

@@ -92,6 +92,7 @@ bool j2k_create(ebcc_hip_ctx *ctx)
     ok &= (jb->stream = ctx_alloc<uint8_t>(ctx, F * jb->stream_cap)) != nullptr;
     ok &= (jb->dec_table = (int *) ctx_alloc<int32_t>(ctx, groups * 64 * 4)) != nullptr;
     ok &= (jb->dec_order = (int *) ctx_alloc<int32_t>(ctx, groups * 64 + 128)) != nullptr;
+    ok &= (jb->mq_order = (int *) ctx_alloc<int32_t>(ctx, groups * 64 + 256)) != nullptr;
     ok &= (jb->jf = (J2kFrame *) ctx_alloc<uint8_t>(ctx, sizeof(J2kFrame) * F)) != nullptr;
     ok &= (jb->partial = ctx_alloc<double>(ctx, F * kPartials)) != nullptr;
     ok &= (jb->partial_u = ctx_alloc<unsigned long long>(ctx, F * kPartials)) != nullptr;

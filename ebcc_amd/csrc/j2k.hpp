@@ -164,6 +164,7 @@ struct J2kBuffers {
     int32_t *V;                   // [frames][H*W] tier-1 decoder output (half units), decode path
     int *dec_table;               // [frames*nblocks][4]: offset, len, numbps, npasses (decode path)
     int *dec_order;               // [frames*nblocks] code-blocks by falling segment length, then [128] counters (decode path)
+    int *mq_order;                // [groups*64] code-blocks by falling number of decision rows, then [256] counters (the MQ pass takes them in this order)
     J2kFrame *jf;                 // [frames]
     FrameState *fs;               // [frames] (shared with the residual layer)
     double *partial;              // [frames][kPartials]

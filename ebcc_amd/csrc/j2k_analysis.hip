@@ -1342,9 +1342,50 @@ struct MqSinkLds {
     __device__ void finish(int n) { row_end(n); if (fl < n) sector(); }
 };
 
+// The 64 code-blocks of a wave are coded in lock-step, row by row: the wave lasts as long as its code-block with the most
+// rows (the mean over the waves of that maximum was 25 % above the mean row count with the code-blocks in their natural
+// order - a quarter of the pass's instructions coded padding).  So the waves take the code-blocks in order of falling row
+// count (a counting sort over 128 classes of 32 rows: k_mq_hist / k_mq_offsets / k_mq_place, as the decoder orders its
+// chains): lanes of a wave hold code-blocks of nearly the same length, the longest chains start first, and the code-blocks
+// without rows gather in the last waves, which leave at once.  Results are per code-block: nothing depends on the order.
+constexpr int kMqClasses = 128;
+__device__ inline int mq_class(uint32_t rows, uint32_t sym_rows) { return rows == 0 || rows > sym_rows ? 0 : min(kMqClasses - 1, 1 + (int) (rows >> 5)); }
+__global__ __launch_bounds__(256) void k_mq_hist(const uint32_t *lanerows, int *counters, int total, uint32_t sym_rows)
+{
+    __shared__ int h[kMqClasses];
+    if (threadIdx.x < kMqClasses) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < total) atomicAdd(&h[mq_class(lanerows[gid], sym_rows)], 1);
+    __syncthreads();
+    if (threadIdx.x < kMqClasses && h[threadIdx.x]) atomicAdd(&counters[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_mq_offsets(int *counters)                           // [0,128) counts -> [128,256) first slot of every class (longest first)
+{
+    const int c = threadIdx.x;
+    int before = 0;
+    for (int k = kMqClasses - 1; k > c; k--) before += counters[k];
+    counters[kMqClasses + c] = before;
+}
+__global__ __launch_bounds__(256) void k_mq_place(const uint32_t *lanerows, int *counters, int *order, int total, int padded, uint32_t sym_rows)
+{
+    __shared__ int h[kMqClasses], base[kMqClasses];
+    if (threadIdx.x < kMqClasses) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = 0, rank = 0;
+    if (gid < total) { cls = mq_class(lanerows[gid], sym_rows); rank = atomicAdd(&h[cls], 1); }
+    __syncthreads();
+    if (threadIdx.x < kMqClasses && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&counters[kMqClasses + threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (gid < total) order[base[cls] + rank] = gid;
+    else if (gid < padded) order[gid] = -1;                            // (the last wave's lanes without a code-block)
+}
+
 __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uint32_t *lanerows, const int *blkmax, int *cblk_len,
                                                     int *rates, uint8_t *cblk_bytes, void *ckpt, const J2kGeom *geom,
-                                                    const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows)
+                                                    const J2kBlock *blocks, const FrameState *fs, J2kFrame *jf, int total, uint32_t sym_rows,
+                                                    const int *order)
 {
     __shared__ uint2 tab_store[128];
     __shared__ uint32_t ctxw[CtxSlotsLds::kBytes / 4];
@@ -1356,8 +1397,13 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
     const bool code_wave = threadIdx.x >= 64;
     fill_mq_table_next(tab_store);
     const LdsTableNext tab{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint2 *) tab_store};
-    const size_t grp = blockIdx.x;
-    const int gid = (int) (grp * 64) + lane;
+    // this lane's code-block: the order's entry (null: natural order); its decision rows lie where the emit put them - in the
+    // rows of ITS group of 64 (gid >> 6), at ITS lane's place (gid & 63)
+    const int slot = (int) (blockIdx.x * 64) + lane;
+    const int pick = order ? order[slot] : slot;
+    const int gid = pick < 0 ? total : pick;
+    const size_t grp = (size_t) (pick < 0 ? 0 : pick) >> 6;
+    const uint32_t home = (uint32_t) (pick < 0 ? 0 : pick) & 63u;
     const Tier1Lane l = tier1_lane(gid, total, blkmax, geom, blocks, fs);
     uint32_t nrows = l.live ? lanerows[gid] : 0u;
     if (nrows > sym_rows) nrows = 0;                                     // (overflow: the host retries, see k_t1_rowoffs)
@@ -1379,7 +1425,7 @@ __global__ __launch_bounds__(128) void k_t1_mqrows(const uint8_t *SYM, const uin
         return;
     }
     // ---- wave 1: loader + code chain.  Barrier k hands chunk k of the rows to wave 0 and chunk k - 1 of the hand-over words to this wave.
-    const uint8_t *sym = SYM + grp * sym_group_bytes(sym_rows) + (size_t) lane * 32u;
+    const uint8_t *sym = SYM + grp * sym_group_bytes(sym_rows) + (size_t) home * 32u;
     uint8_t *out = cblk_bytes + (size_t) (on ? gid : 0) * kJ2kCblkBytes;
     int *myrates = rates + (size_t) (on ? gid : 0) * kJ2kMaxPasses;
     MqSinkLds sink{(unsigned char *) bring + lane * 68, out, &jf[l.frame].overflow};
@@ -1595,8 +1641,18 @@ void launch_j2k_tier1(const J2kBuffers &jb, int n_frames, hipStream_t s, bool si
                     sum / (double) total, wsum / (double) groups, mx, jb.sym_rows);
         }
         timing_begin("t1_mq", s);
+        const int *order = nullptr;
+        if (!getenv("EBCC_HIP_MQ_NATURAL_ORDER")) {                      // (cross-check: the code-blocks in their natural order)
+            int *counters = jb.mq_order + groups * 64;
+            EBCC_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * kMqClasses * sizeof(int), s));
+            hipLaunchKernelGGL(k_mq_hist, dim3(ceil_div(total, 256)), dim3(256), 0, s, jb.lanerows, counters, total, (uint32_t) jb.sym_rows);
+            hipLaunchKernelGGL(k_mq_offsets, dim3(1), dim3(kMqClasses), 0, s, counters);
+            hipLaunchKernelGGL(k_mq_place, dim3(ceil_div((int) (groups * 64), 256)), dim3(256), 0, s, jb.lanerows, counters, jb.mq_order, total, (int) (groups * 64),
+                               (uint32_t) jb.sym_rows);
+            order = jb.mq_order;
+        }
         hipLaunchKernelGGL(k_t1_mqrows, dim3((unsigned) groups), dim3(128), 0, s, jb.SYM, jb.lanerows, jb.blkmax, jb.cblk_len, jb.rates,
-                           jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, (uint32_t) jb.sym_rows);
+                           jb.cblk_bytes, jb.ckpt, jb.d_geom, jb.d_blocks, fs, jb.jf, total, (uint32_t) jb.sym_rows, order);
         timing_end("t1_mq", s);
     }
     timing_end("t1_encode", s);

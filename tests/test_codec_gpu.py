@@ -241,7 +241,8 @@ def test_tuning_knobs_do_not_change_results(monkeypatch):
     assert base[0] == L.orc_encode(frames[0], cfg) and base[16] == L.orc_encode(frames[16], cfg)
     for env in ({"EBCC_HOST_THREADS": "3"}, {"EBCC_T1_LPW": "8"}, {"EBCC_T1_LPW": "16,32,1,2"}, {"EBCC_HIP_SLICES": "2", "EBCC_HIP_DECODE_SLICES": "3"},
                 {"EBCC_HIP_SLICES": "4"}, {"EBCC_HIP_HOST_SEARCH": "1"}, {"EBCC_HIP_NO_SHORTCUTS": "1"}, {"EBCC_HIP_SLICES": "2", "EBCC_HIP_SPECULATION": "1"},
-                {"EBCC_HIP_SLICES": "1", "EBCC_HIP_SPECULATION": "0"}, {"EBCC_HOST_CPU_QUOTA": "2"}):
+                {"EBCC_HIP_SLICES": "1", "EBCC_HIP_SPECULATION": "0"}, {"EBCC_HOST_CPU_QUOTA": "2"}, {"EBCC_HIP_MQ_NATURAL_ORDER": "1"},
+                {"EBCC_HIP_TRUNC_LEVELS": "1"}, {"EBCC_HIP_TRUNC_LEVELS": "3"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with L.Context(len(frames), 96, 160) as ctx:

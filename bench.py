@@ -396,6 +396,8 @@ def main():
         #      plain filter-308 callback (one chunk per call) and (ii) as device batches of pre-filtered chunks
         #      (ebcc_amd/h5_batch.py: H5Dwrite_chunk / H5Dread_chunk), with the image's conda h5py in a child process
         torch.cuda.empty_cache()                                                  # (the child makes its own engines: 125 GB for two sets)
+        lib.ebcc_hip_release_second_set.argtypes = [ctypes.c_void_p]
+        lib.ebcc_hip_release_second_set(ctx)                                      # (and this process has no use for its second set any more)
         ex["h5_path"] = h5_path_rates(n)
         # ---- the reference's host-pointer API: pageable host array in, EBCK container in host memory out (PCIe inclusive)
         host = frames.cpu().numpy()

@@ -1090,13 +1090,18 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
         if (s2 != s) EBCC_HIP_CHECK(hipEventRecord(ctx->ev_b, s2));
     }
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table, table_ints * sizeof(int), hipMemcpyHostToDevice, s));
-    launch_j2k_decode(jb, (int) n, s);
+    // the decoded field is written where the caller wants it (the engine's own field buffer and a 1 GB device-to-device copy
+    // per 256 frames only for an output that is not aligned the way the engine's buffers are)
+    const bool direct = ((uintptr_t) d_out & 255u) == 0;
+    J2kBuffers view = jb;
+    if (direct) view.DEC = d_out;
+    launch_j2k_decode(view, (int) n, s);
     if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
     if (any_resid) {
         if (s2 != s) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
-        launch_synthesis_tail_add(jb.DEC, ctx->rb, (int) n, ctx->d_active, s);       // last row pass: DEC += residual
+        launch_synthesis_tail_add(view.DEC, ctx->rb, (int) n, ctx->d_active, s);     // last row pass: field += residual
     }
-    EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!direct) EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n * n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
     // constant fields: fill on the host side of the copy (rare path)
     for (size_t f = 0; f < n; f++)
         if (ctx->h_fs[f].const_field) {

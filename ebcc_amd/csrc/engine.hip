@@ -54,7 +54,12 @@ hipError_t device_malloc(void **p, size_t bytes)
     static const long fail_at = getenv("EBCC_HIP_FAIL_ALLOC") ? strtol(getenv("EBCC_HIP_FAIL_ALLOC"), nullptr, 10) : 0;
     static std::atomic<long> count{0};
     if (fail_at > 0 && ++count == fail_at) { *p = nullptr; return hipErrorOutOfMemory; }
-    return hipMalloc(p, bytes);
+    const hipError_t e = hipMalloc(p, bytes);
+    // (a failed allocation is reported by its return value; the runtime also remembers it as the "last error", which the
+    //  next launch check - hipGetLastError - would take for its own: an engine that goes on without the memory would see
+    //  its next healthy launch fail with "out of memory")
+    if (e != hipSuccess) { *p = nullptr; (void) hipGetLastError(); }
+    return e;
 }
 
 template <typename T>
@@ -153,9 +158,19 @@ void stage_scatter(ebcc_hip_ctx *ctx, uint8_t *dst, size_t stride, size_t first,
 bool ensure_cut_slots(ebcc_hip_ctx *ctx, int capacity)
 {
     if (ctx->cut.capacity >= capacity) return true;
-    if (ctx->cut_failed || ctx->cut.capacity > 0) return false;          // (made once, for 3 slots per frame of the engine)
-    const int cap = std::max(capacity, 3 * (int) ctx->max_frames);
+    if (ctx->cut_failed) return false;
+    // sized for what is asked (a slice engine's batches are all of one size), grown if a larger batch comes: the old set goes first
+    const int cap = capacity;
     if (!prefix_slots_supported(ctx->rb, cap)) { ctx->cut_failed = true; return false; }
+    if (ctx->cut.capacity > 0) {
+        EBCC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        void *old[] = {ctx->cut.A, ctx->cut.T, ctx->cut.D, ctx->cut.fs, ctx->cut.partial, ctx->cut.bits, ctx->cut.active, ctx->cut.frame_of};
+        for (void *p : old) {
+            auto it = std::find(ctx->allocs.begin(), ctx->allocs.end(), p);
+            if (it != ctx->allocs.end()) { hipFree(p); ctx->allocs.erase(it); }
+        }
+        ctx->cut = CutSlots{};
+    }
     CutSlots c;
     c.stride = (size_t) (ctx->rb.g.ny >> 1) * (size_t) ctx->rb.g.nx;
     bool ok = true;
@@ -167,7 +182,7 @@ bool ensure_cut_slots(ebcc_hip_ctx *ctx, int capacity)
     ok = ok && (c.bits = ctx_alloc<unsigned long long>(ctx, cap)) != nullptr;
     ok = ok && (c.active = (int *) ctx_alloc<uint32_t>(ctx, cap)) != nullptr;
     ok = ok && (c.frame_of = (int *) ctx_alloc<uint32_t>(ctx, cap)) != nullptr;
-    if (!ok) { ctx->cut_failed = true; clear_error(); return false; }    // (what was allocated stays with the context until it goes)
+    if (!ok) { ctx->cut_failed = true; clear_error(); return false; }    // (what was allocated of the set stays with the context until it goes)
     EBCC_HIP_CHECK(hipMemsetAsync(c.active, 0, sizeof(int) * cap, ctx->stream));
     EBCC_HIP_CHECK(hipMemsetAsync(c.frame_of, 0, sizeof(int) * cap, ctx->stream));
     c.capacity = cap;

@@ -712,6 +712,19 @@ void ebcc_hip_release_engines(void)
     EBCC_API_CATCH_VOID
 }
 
+// The second engine set of a caller's context (made by the first shard / host-frames call of more than one batch: as much
+// device memory as the context itself) is destroyed; the next such call makes it again.
+void ebcc_hip_release_second_set(ebcc_hip_ctx *ctx)
+{
+    EBCC_API_TRY
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lock(device_mutex(ctx->device));
+    DeviceScope scope(ctx->device);
+    if (ctx->twin) { ebcc_hip_destroy(ctx->twin); ctx->twin = nullptr; }
+    ctx->twin_failed = false;
+    EBCC_API_CATCH_VOID
+}
+
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames)
 {
     EBCC_API_TRY

@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(64) void k_t1_resume(unsigned long long *T1S, const
     DecStoreLds st{(uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned long long *) dec_state + threadIdx.x * 8u, (uint32_t) lpw * 8u,
                    V + (size_t) frame * geom->W * geom->H + (size_t) blk.y * geom->W + blk.x, geom->W};
     // Decoder state when pass r reaches the restart stripe: rows above it are as at the start of pass r + 1,
-    // the rest as at the start of pass r (see DESIGN.md section 3).  Only the rows the remaining stripes can
+    // the rest as at the start of pass r (see DESIGN.md appendix A.2).  Only the rows the remaining stripes can
     // see are needed when no further pass follows, but all 64 are cheap next to the decode.
     const unsigned long long *sg = SGN + grp * 64 * 64 + gl;
     const unsigned long long *sps = SPS + grp * 64 * 64 + gl;

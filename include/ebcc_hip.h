@@ -100,6 +100,10 @@ int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
  * 721 x 1440.  This gives that memory back; the next call makes the engines again.  Contexts of ebcc_hip_create are not
  * touched. */
 void ebcc_hip_release_engines(void);
+/* The same for a caller's context: its second engine set (ebcc_hip_encode_shard / ebcc_hip_decode_shard / the host-frames
+ * entry points make it on their first call of more than one batch; it is as large as the context) is destroyed, the next
+ * such call makes it again (also after a call that found no memory for it). */
+void ebcc_hip_release_second_set(ebcc_hip_ctx *ctx);
 /* Pageable host memory <-> device memory through the engine's pinned bounce buffers with several copying host threads
  * (what the chunking entry points use for their own arrays): ~3x hipMemcpy on a fresh pageable array.  0 = ok. */
 int ebcc_hip_upload(ebcc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

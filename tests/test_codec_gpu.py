@@ -739,6 +739,21 @@ def test_rejected_chunk_of_a_large_container_returns_zero_from_a_live_process():
     assert lines[1] == f"good DECODED {20 * 721 * 1440}" and lines[3] == lines[1], lines
 
 
+def test_a_real_failed_allocation_does_not_poison_the_next_launch():
+    """hipMalloc that fails for real (not the EBCC_HIP_FAIL_ALLOC hook) leaves "out of memory" as the runtime's last error; the
+    library's launch checks read the last error - the allocation wrapper has to clear it, or the next healthy kernel launch
+    is reported as failed (seen in round 4: a child process whose second engine set did not fit failed its decode)."""
+    lib = L.product()
+    assert not lib.ebcc_hip_malloc(1 << 42)                             # 4 TB: no such device
+    name = sorted(_streams)[0]
+    c = _streams[name]
+    cfg = L.make_config((1, c["h"], c["w"]), base_cr=c["base_cr"], error=c["error"], residual_type=c["mode"])
+    if c["quantile"] is None:
+        assert api_encode(_inputs[c["input"]], cfg) == bytes.fromhex(c["stream_hex"])
+    dec = api_decode(bytes.fromhex(c["stream_hex"]))
+    assert sha(dec.tobytes()) == c["decoded_sha256"]
+
+
 _TWICE = r"""
 import ctypes, sys
 import numpy as np

@@ -79,6 +79,7 @@ static const H5Z_class2_t H5Z_EBCC[1] = {{1, 308, 1, 1, "HDF5 EBCC filter L&L", 
 // coded together and stored as pre-filtered chunks (H5Dwrite_chunk), or the raw chunks are fetched (H5Dread_chunk) and
 // decoded together.  The file is the same ordinary EBCC-filtered dataset either way (chunk bytes identical to what the
 // callback writes).  HDF5 is not linked: its functions are taken from the libhdf5 the calling process has already loaded.
+extern "C++" {
 namespace {
 typedef long long hid_like;                 // hid_t of HDF5 >= 1.10 (int64_t)
 typedef unsigned long long hsize_like;      // hsize_t
@@ -170,6 +171,7 @@ void chunk_offset(const FrameDataset &d, size_t frame, hsize_like *off)
     off[d.rank - 2] = 0; off[d.rank - 1] = 0;
 }
 }  // namespace
+}  // extern "C++"
 
 // frames [first_frame, first_frame + n_frames) of the dataset (counted in C order over its leading dimensions) from
 // `frames` (host, n_frames x H x W fp32), coded with the dataset's own filter-308 parameters.  0 = ok.

@@ -1269,7 +1269,7 @@ struct DecSrcSeq {
 // length classes, k_dec_hist / k_dec_offsets / k_dec_place) and the waves take them in that order: the long chains start
 // at once, the short ones fill in behind them, and the lanes of a wave hold blocks of similar length.
 constexpr int kDecClasses = 64;
-constexpr int kDecTierDen0 = 0, kDecTierDen1 = 32, kDecTierDen2 = 1;     // tiers of k_t1_decode_lds (launch_j2k_decode): the longest 1/32 at 2 lanes, the rest at 4
+constexpr int kDecTierDen0 = 0, kDecTierDen1 = 64, kDecTierDen2 = 1;     // tiers of k_t1_decode_lds (launch_j2k_decode): the longest 1/64 at 2 lanes, the rest at 4 (round 4, three alternating runs: 16.5-16.7 ms against 17.0-17.3 with 1/32)
 __device__ inline int dec_class(const int *e) { return e[3] <= 0 || e[2] <= 0 ? 0 : min(kDecClasses - 1, 1 + (e[1] >> 6)); }
 __global__ __launch_bounds__(256) void k_dec_hist(const int *dec_table, int *counters, int total)
 {

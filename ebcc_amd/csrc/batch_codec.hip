@@ -1095,7 +1095,7 @@ int decode_batch(ebcc_hip_ctx *ctx, const uint8_t *const *streams, const size_t 
     const bool direct = ((uintptr_t) d_out & 255u) == 0;
     J2kBuffers view = jb;
     if (direct) view.DEC = d_out;
-    launch_j2k_decode(view, (int) n, s);
+    launch_j2k_decode(view, (int) n, s, table);
     if (next) { next->release(); release_on_exit.g = nullptr; }     // host parsing done, kernels queued
     if (any_resid) {
         if (s2 != s) EBCC_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_b, 0));
@@ -1172,7 +1172,7 @@ int decode_tiled(ebcc_hip_ctx *ctx, ebcc_hip_ctx *rc, const uint8_t *const *stre
     }
     push_frame_states(ctx, nt);
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    launch_j2k_decode(jb, (int) nt, s);
+    launch_j2k_decode(jb, (int) nt, s, table.data());
     wait_stream(s);
     if (any_resid) {
         push_frame_states(rc, n);

@@ -467,7 +467,7 @@ __attribute__((visibility("default"))) int ebcc_hip_j2k_decode(ebcc_hip_ctx *ctx
     }
     push_frame_states(ctx, n_frames);
     EBCC_HIP_CHECK(hipMemcpyAsync(jb.dec_table, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    launch_j2k_decode(jb, (int) n_frames, s);
+    launch_j2k_decode(jb, (int) n_frames, s, table.data());
     EBCC_HIP_CHECK(hipMemcpyAsync(d_out, jb.DEC, n_frames * ctx->n_pix * sizeof(float), hipMemcpyDeviceToDevice, s));
     wait_stream(s);
     return 0;

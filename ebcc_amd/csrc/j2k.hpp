@@ -209,7 +209,8 @@ void launch_j2k_write(const J2kBuffers &jb, int n_frames, const int *d_active, h
 void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_frames, const int *d_active, hipStream_t s,
                              int keep_field = 1);
 // true decode of codestreams whose packet headers were parsed on the host into jb.dec_table
-// (fs[f].minv/maxv must hold the header's values); result in jb.DEC
-void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s);
+// (fs[f].minv/maxv must hold the header's values); result in jb.DEC.  host_table: the host's copy of jb.dec_table, from
+// which the launch sizes its waves (null: the fixed tiers tuned for 256 frames)
+void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s, const int *host_table = nullptr);
 
 }  // namespace ebcc

@@ -1691,7 +1691,43 @@ void j2k_probe_hist_dump(const char *what)
     EBCC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_round), &zero, sizeof zero));
 }
 
-void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
+// The lanes per wave of a launch from the lengths the host parsed out of the packet headers.  A wave lasts as long as its
+// lanes together (a lone lane: kDecChainMsPerByte of its segment; a wave of two 0.875 of its two chains one after the other,
+// a wave of four 0.68), and the launch cannot be shorter than its vector issue slots allow (kDecIssueMsPerByte[lanes] of all
+// segments: lanes of a wave share part of their instructions).  With 256 frames the issue slots bind and four lanes are
+// best (16.6 ms; 19.3 at two, 23.4 at one); a batch of 43 or 85 frames has issue slots to spare and ends soonest with
+// every chain alone in its wave (tools/gpu/dec_tiers_sweep.sh, four lanes -> one: 43 frames 17.6 -> 7.2 ms, 85 frames
+// 15.9 -> 9.1, 128 frames 16.4 -> 12.6, 11.7 at two).  The plan takes whichever of the three measured shapes the model
+// puts first.  (Finer mixtures - every wave filled up to the launch's duration - were built and measured: the waves of
+// the wider tiers start behind all narrower ones and last as long, 85 frames 10.7 - 12.4 ms.)
+constexpr double kDecChainMsPerByte = 3.0e-3;                            // (a 2.3 KB segment alone in its wave: 7 ms)
+constexpr double kDecIssueMsPerByte[3] = {1.0e-6, 0.82e-6, 0.706e-6};    // 1, 2, 4 lanes per wave: 23.4, 19.3, 16.6 ms for the 23.5 MB of 256 frames
+static DecTiers plan_dec_tiers(const int *host_table, int total)
+{
+    long long cnt[kDecClasses] = {0};
+    double all = 0;
+    int longest = 0;
+    for (int i = 0; i < total; i++) {
+        const int *e = host_table + (size_t) i * 4;
+        const int c = e[3] <= 0 || e[2] <= 0 ? 0 : std::min(kDecClasses - 1, 1 + (e[1] >> 6));    // == dec_class
+        cnt[c]++;
+        if (c) { all += e[1]; longest = std::max(longest, e[1]); }
+    }
+    // the longest segment a wave of four would hold with the longest 1/64 of the code-blocks in pairs (kDecTierDen1)
+    int c64 = kDecClasses - 1;
+    for (long long above = 0; c64 > 0 && above + cnt[c64] <= total / kDecTierDen1; c64--) above += cnt[c64];
+    const double len64 = std::min((double) longest, 64.0 * c64);
+    const double alone = std::max(kDecChainMsPerByte * longest, kDecIssueMsPerByte[0] * all);
+    const double pairs = std::max(2 * 0.875 * kDecChainMsPerByte * longest, kDecIssueMsPerByte[1] * all);
+    const double fours = std::max({2 * 0.875 * kDecChainMsPerByte * longest, 4 * 0.68 * kDecChainMsPerByte * len64, kDecIssueMsPerByte[2] * all});
+    DecTiers tiers{{0, 0, 0}, {1, 2, 4, 4}};
+    if (alone <= pairs && alone <= fours) tiers.lanes[3] = 1;
+    else if (pairs <= fours) tiers.lanes[3] = 2;
+    else tiers.n[1] = total / kDecTierDen1 / 2 * 2;
+    return tiers;
+}
+
+void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s, const int *host_table)
 {
     const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;
     const int total = n_frames * jb.geom.stride;
@@ -1736,6 +1772,7 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
         DecTiers tiers{{0, 0, 0}, {1, 2, 4, 4}};
         if (few_blocks) { tiers.lanes[3] = 1; }
         else if (getenv("EBCC_T1_LPW")) { tiers.lanes[3] = lpw; }
+        else if (host_table && !getenv("EBCC_T1_DEC_TIERS")) tiers = plan_dec_tiers(host_table, total);
         else {
             int den[3] = {kDecTierDen0, kDecTierDen1, kDecTierDen2};
             if (const char *e = getenv("EBCC_T1_DEC_TIERS")) {
@@ -1751,6 +1788,7 @@ void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s)
                 tiers.n[t] = n; before += n;
             }
         }
+        if (getenv("EBCC_HIP_T1_STATS")) fprintf(stderr, "ebcc-mi355x t1 decode tiers: %d code-blocks alone in their waves, %d in pairs, the rest %d to a wave\n", tiers.n[0], tiers.n[1], tiers.lanes[3]);
         unsigned waves = 0;
         int rest = total;
         for (int t = 0; t < 3; t++) { waves += (unsigned) (tiers.n[t] / tiers.lanes[t]); rest -= tiers.n[t]; }

@@ -334,13 +334,16 @@ int encode_host_frames(int device, const float *data, size_t n, int H, int W, co
         const size_t n_pix = (size_t) H * W * tiles;
         const size_t cap = std::min(n, batch_capacity(n_pix));
         ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
+        PhaseTimer pt;
         if (!chunk_engines(device, H, W, cap, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 1; }
+        pt.mark("host frames: engine");
         // (a batch is uploaded in one go: uploads issued from inside the slices slow every slice down - measured in round 1 with
         //  pageable copies, 5.6 against 3.7 GB/s, and again in round 2 through the bounce buffers, 7.1 against 6.5)
         if (tiles == 1 && ctx->max_frames == cap)                   // one-frame chunks: concurrent slices, batches on alternating engine sets
             return encode_batches_alternating(ctx, n, cfg, outs, sizes, [&](ebcc_hip_ctx *set, size_t lo, size_t cnt) {
                 float *d = io_buffer(set, cap * n_pix * sizeof(float));
                 copy_pageable(set, const_cast<float *>(data + lo * n_pix), d, cnt * n_pix * sizeof(float), false);
+                pt.mark("host frames: upload");
                 return (const float *) d;
             });
         float *d = io_buffer(ctx, cap * n_pix * sizeof(float));
@@ -868,14 +871,17 @@ size_t ebcc_decode(uint8_t *data, size_t data_size, float **out_buffer)
         ebcc_hip_ctx *ctx = nullptr, *rc = nullptr;
         if (!chunk_engines(device, th, W, 1, tiles, &ctx, &rc)) { log_fatal("no MI355X engine available: %s", ebcc_hip_last_error()); return 0; }
         const size_t n_pix = (size_t) H * W;
+        PhaseTimer pt;
         float *d = io_buffer(ctx, n_pix * sizeof(float));
         const uint8_t *sp = data;
         int rcode = tiles > 1 ? decode_tiled(ctx, rc, &sp, &data_size, 1, tiles, d) : decode_batch(ctx, &sp, &data_size, 1, d);
         if (rcode) return 0;
+        pt.mark("ebcc_decode: decode_batch");
         // :1126-1128: honour a caller-provided buffer
         float *o = *out_buffer ? *out_buffer : (float *) malloc(n_pix * sizeof(float));
         if (!o) { log_fatal("out of memory"); return 0; }
         EBCC_HIP_CHECK(hipMemcpy(o, d, n_pix * sizeof(float), hipMemcpyDeviceToHost));
+        pt.mark("ebcc_decode: download");
         *out_buffer = o;
         return n_pix;
     } catch (const std::exception &e) {

@@ -562,6 +562,7 @@ int ebcc_hip_default_encode_slices(void) { return (int) default_encode_slices();
 // arithmetic identities the kernels rely on, checked on the host (0 = all hold): the division-free s / 65535.0f of the fused
 // inverse level for every s in [0, 65535]; v / 255.0f and x / kXi of the residual synthesis (all significands)
 int ebcc_hip_selfcheck(void) { return j2k_selfcheck_div65535() + residual_selfcheck_divisions(); }
+void ebcc_hip_plan_decode_lanes(const int *table, int n_code_blocks, int out[4]) { plan_decode_lanes(table, std::max(0, n_code_blocks), out); }
 
 // the lower bound of zstd_size_lower_bound (0: not applicable - longer than 4 MB, or a libzstd that may split blocks)
 size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n) { return zstd_floor_usable() ? zstd_size_lower_bound(src, n) : 0; }

@@ -212,5 +212,6 @@ void launch_j2k_probe_decode(const float *data, const J2kBuffers &jb, int n_fram
 // (fs[f].minv/maxv must hold the header's values); result in jb.DEC.  host_table: the host's copy of jb.dec_table, from
 // which the launch sizes its waves (null: the fixed tiers tuned for 256 frames)
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s, const int *host_table = nullptr);
+void plan_decode_lanes(const int *host_table, int total, int out[4]);   // (what launch_j2k_decode chooses; ebcc_hip_plan_decode_lanes)
 
 }  // namespace ebcc

@@ -1727,6 +1727,13 @@ static DecTiers plan_dec_tiers(const int *host_table, int total)
     return tiers;
 }
 
+void plan_decode_lanes(const int *host_table, int total, int out[4])
+{
+    const DecTiers t = plan_dec_tiers(host_table, total);
+    for (int i = 0; i < 3; i++) out[i] = t.n[i];
+    out[3] = t.lanes[3];
+}
+
 void launch_j2k_decode(const J2kBuffers &jb, int n_frames, hipStream_t s, const int *host_table)
 {
     const size_t n_pix = (size_t) jb.geom.W * jb.geom.H;

@@ -174,6 +174,10 @@ size_t ebcc_hip_zstd_floor(const uint8_t *src, size_t n);
 /* Host-side check of the arithmetic identities the kernels rely on (the division-free s / 65535.0f of the fused inverse
  * wavelet level, for every s in [0, 65535]); returns the number of violations: 0. */
 int ebcc_hip_selfcheck(void);
+/* The tier-1 decoder's launch shape for a batch (host logic, no device work): table = the decode table the host parses out of
+ * the packet headers, four ints per code-block (offset, segment bytes, bit-planes, passes); out[0..2] = code-blocks (by rank in
+ * the longest-first order) that go 1, 2, 4 to a wave, out[3] = lanes per wave of all the others. */
+void ebcc_hip_plan_decode_lanes(const int *table, int n_code_blocks, int out[4]);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).  Names: "t1_encode",
  * "t1_probe_decode", "t1_decode", "rate_alloc", "j2k_dwt_fwd", "spiht_encode".  Process-wide switch. */

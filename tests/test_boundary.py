@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 from tests import _lib as L
@@ -230,3 +231,35 @@ def test_prefault_maps_a_destination_array():
     b = np.full(1 << 20, 7, np.uint8)                                # small: nothing is touched
     assert lib.ebcc_hip_prefault(b.ctypes.data, b.nbytes) == 0 and int(b.min()) == 7
     assert lib.ebcc_hip_prefault(None, 0) != 0
+
+
+def test_decoder_launch_shape_follows_the_batch():
+    """ebcc_hip_plan_decode_lanes (host logic of launch_j2k_decode): a small batch decodes one code-block per wave - its
+    launch is as long as its longest chain -, a batch that fills the issue slots four per wave with the longest 1/64 in
+    pairs; the counts are multiples of their waves' lanes and never exceed the batch."""
+    lib = L.product()
+    lib.ebcc_hip_plan_decode_lanes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.ebcc_hip_plan_decode_lanes.restype = None
+    rng = np.random.default_rng(5)
+
+    def plan(frames):
+        n = frames * 298
+        r = rng.integers(0, 100, n)
+        length = np.where(r < 50, 0, np.where(r < 90, rng.integers(1, 1034, n), np.where(r < 99, rng.integers(1034, 2056, n), rng.integers(2056, 2375, n))))
+        table = np.zeros((n, 4), np.int32)
+        table[:, 1] = length
+        table[:, 2] = np.where(length > 0, 13, 0)
+        table[:, 3] = np.where(length > 0, 14, 0)
+        out = (ctypes.c_int * 4)()
+        lib.ebcc_hip_plan_decode_lanes(table.ctypes.data, n, out)
+        assert out[0] >= 0 and out[1] >= 0 and out[1] % 2 == 0 and out[2] % 4 == 0 and out[0] + out[1] + out[2] <= n
+        return list(out)
+
+    assert plan(43)[3] == 1 and plan(85)[3] == 1
+    assert plan(160)[3] == 2
+    big = plan(256)
+    assert big[3] == 4 and big[0] == 0 and big[1] == 256 * 298 // 64 // 2 * 2
+    empty = (ctypes.c_int * 4)()
+    lib.ebcc_hip_plan_decode_lanes(np.zeros((64, 4), np.int32).ctypes.data, 64, empty)   # nothing coded: any shape will do
+    assert empty[3] in (1, 2, 4)
+    lib.ebcc_hip_plan_decode_lanes(None, 0, empty)

@@ -693,7 +693,10 @@ __global__ __launch_bounds__(kWave) void k_spiht_decode(const uint8_t *__restric
             lw.reset(cur, 0, ncur, lane);
             while (base < ncur && !stop) {
                 const int m = (int) min((unsigned int) kWave, ncur - base);
-                if (base + (unsigned int) m > lw.limit) { __threadfence_block(); lw.reset(cur, base, ncur, lane); }
+                if (base + (unsigned int) m > lw.limit) {
+                    __threadfence_block(); lw.reset(cur, base, ncur, lane);
+                    if (prof && lane == 0) atomicAdd(&g_spiht_prof[11], 1ull);
+                }
                 if (prof && lane == 0) atomicAdd(&g_spiht_prof[10], 1ull);
                 const unsigned long long typemask = lw.types(base);                      // types of the entries base .. base + 63
                 const unsigned long long X = stream64(kHeaderBits + cnt);                // first bit in bit 63
@@ -978,7 +981,7 @@ void launch_spiht_decode(const uint8_t *d_streams, size_t stream_stride, const u
         EBCC_HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_spiht_prof), sizeof v));
         fprintf(stderr, "spiht_decode profile (%d frames): LIP %.1f Mcycles %llu entries | LIS %.1f Mcycles %llu entries | refinement %.1f Mcycles %llu bits | %llu stream bits, longest %llu | slowest frame: %llu cycle-counter ticks in %.1f us (100 MHz clock)\n",
                 n_frames, v[0] / 1e6, v[1], v[2] / 1e6, v[3], v[4] / 1e6, v[5], v[6], v[7], v[8], v[9] / 100.0);
-        fprintf(stderr, "spiht_decode profile: %llu chunks in the LIS passes\n", v[10]);
+        fprintf(stderr, "spiht_decode profile: %llu chunks in the LIS passes, the list registers loaded afresh %llu times\n", v[10], v[11]);
     }
     hipLaunchKernelGGL(k_int_to_float, dim3(128, n_frames), dim3(256), 0, s, rb.C, rb.A, rb.np, d_active);
     EBCC_HIP_LAUNCH_CHECK();

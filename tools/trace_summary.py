@@ -14,14 +14,14 @@ with open(sys.argv[1]) as f:
         name = name.split("(")[0].replace("ebcc::", "")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 rows.sort()
-# last step = from the last k_in_init (input statistics open an encode batch) of the first slice onwards; keep it
-# simple: take the last 'k_in_init' whose predecessor gap is > 2 ms
+# last step = from the first k_in_init (input statistics open an encode slice) of the LAST cluster of them: the slices of a
+# step start within a few milliseconds of each other, the steps are a whole step apart
 starts = [i for i, r in enumerate(rows) if r[2].startswith("k_in_init")]
 first = starts[-1]
-for i in reversed(starts):
-    if i == 0 or rows[i][0] - max(r[1] for r in rows[max(0, i - 50):i]) > 2_000_000:
-        first = i
+for i in reversed(starts[:-1]):
+    if rows[first][0] - rows[i][0] > 30_000_000:
         break
+    first = i
 step = rows[first:]
 t0, t1 = step[0][0], max(r[1] for r in step)
 # union of busy intervals

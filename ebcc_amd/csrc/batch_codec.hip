@@ -565,7 +565,12 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
         struct WaitOnExit { PoolBatches &v; ~WaitOnExit() { for (auto &b : v) if (b) b->wait(); } } wait_on_exit{zbatches}, wait_on_exit_f{fbatches};   // (error paths too: the jobs point into this frame)
         // level-22 zstd of the frames in `list`, in the order given; a frame that was decided in the meantime (kZSkipped)
         // is passed over
+        const bool trace_jobs = pt.on && getenv("EBCC_HIP_ZSTD_TRACE");
         auto submit_zstd = [&](std::vector<size_t> list) {
+            if (trace_jobs) {
+                static const auto epoch0 = std::chrono::steady_clock::now(); (void) epoch0;
+                fprintf(stderr, "zstd-submit batch %p jobs %zu\n", (const void *) &jobs, list.size());
+            }
             for (size_t f : list) zstate[f] = kZQueued;
             auto order = std::make_shared<std::vector<size_t>>(std::move(list));
             zbatches.push_back(HostPool::instance().submit(order->size(), entropy_threads(slices), [&, order](size_t i) {
@@ -579,6 +584,11 @@ int encode_batch(ebcc_hip_ctx *ctx, const float *d_frames, size_t n, const codec
                 if ((zstd().is_error && zstd().is_error(z)) || z > j.zbytes.size()) throw std::runtime_error("ZSTD_compress failed on a residual prefix");
                 j.zbytes.resize(z);
                 const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - z0).count();
+                if (trace_jobs) {                                           // (EBCC_HIP_ZSTD_TRACE: when each job ran, on which CPU)
+                    static const auto epoch = std::chrono::steady_clock::now();
+                    const long long a = std::chrono::duration_cast<std::chrono::microseconds>(z0 - epoch).count();
+                    fprintf(stderr, "zstd-job batch %p bytes %zu start %lld us end %lld us cpu %d\n", (const void *) &jobs, j.coeffs_size, a, a + us, sched_getcpu());
+                }
                 zstd_us += us; zstd_bytes += (long long) j.coeffs_size;
                 long long m = zstd_max_us.load(); while (us > m && !zstd_max_us.compare_exchange_weak(m, us)) {}
             }));

@@ -198,6 +198,33 @@ def test_full_size_batch_is_configuration_independent(monkeypatch):
     assert digests["default"][3] == L.orc_encode(frames[47], cfg)
 
 
+def test_decoder_launch_shapes_give_the_same_fields(monkeypatch):
+    """The tier-1 decoder chooses its lanes per wave from the batch (launch_j2k_decode: one lane for a small batch, two for
+    a medium one, four from about 200 full-size frames on): a 160-frame batch of 721x1440 decodes to the same fields
+    whatever the shape - the planner's own choice (pairs here), one, two or four lanes forced, rank tiers."""
+    base = np.stack([L.era5_like(721, 1440, 300 + s, 1.5, 2.5) for s in range(5)])
+    frames = np.concatenate([base + np.float32(0.21 * k) for k in range(32)])                   # 160 distinct frames
+    cfg = L.make_config((1, 721, 1440), base_cr=30.0, error=0.5, residual_type=L.MAX_ERROR)
+    lib = L.product()
+    lib.ebcc_hip_plan_decode_lanes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.ebcc_hip_plan_decode_lanes.restype = None
+    digests = {}
+    with L.Context(len(frames), 721, 1440) as ctx:
+        got = ctx.encode_frames(frames, cfg)
+        for name, env in (("planned", {}), ("one lane", {"EBCC_T1_LPW": "64,64,4,1"}), ("two lanes", {"EBCC_T1_LPW": "64,64,4,2"}),
+                          ("four lanes", {"EBCC_T1_LPW": "64,64,4,4"}), ("rank tiers", {"EBCC_T1_DEC_TIERS": "32,8,2"})):
+            for k in ("EBCC_T1_LPW", "EBCC_T1_DEC_TIERS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            dec = ctx.decode_frames(got)
+            assert np.abs(dec - frames).max() <= 0.5 * 1.01 + 1e-3, name
+            digests[name] = sha(dec.tobytes())
+    assert len(set(digests.values())) == 1, digests
+    L.oracle().orc_set_j2k_backend(0)
+    assert got[0] == L.orc_encode(frames[0], cfg) and got[159] == L.orc_encode(frames[159], cfg)
+
+
 def test_sliced_batches_equal_single_engine(monkeypatch):
     """The frames API cuts a large batch into slices that run concurrently on their own engines / streams /
     host threads (EBCC_HIP_SLICES): streams and decoded fields must not depend on the slicing."""

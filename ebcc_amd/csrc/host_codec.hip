@@ -398,6 +398,7 @@ int run_on_devices(size_t n_chunks, Fn fn)
 // batch size, and the tier-1 decoder is bound by vector issue slots - two half batches side by side only shared them
 // (A/B on one box, tools/gpu/ab_dec.sh: 33 GB/s with one slice, 27 with two).
 constexpr size_t kDefaultDecodeSlices = 1;
+constexpr size_t kSliceFromFrames = 96;                             // smaller batches run as one slice unless the environment says otherwise
 static size_t default_encode_slices()
 {
     // Four with eight hardware queues in round 1; two at the end of round 2 (the search loops had moved to the device and every
@@ -409,7 +410,10 @@ static size_t default_encode_slices()
 }
 static size_t slice_engines(ebcc_hip_ctx *ctx, size_t n_frames, const char *env_name, size_t k)
 {
+    // (a batch below about a hundred frames is a chain whatever it is cut into - 43 frames of 721 x 1440: 53.9 ms per step as
+    //  one slice, 56.8 as two, 60.3 as three; 85 frames: 75.8 / 77.4 / 76.4; 128 frames: 85.9 / 84.6 / 83.0, tools/gpu/slices_frames.sh)
     if (const char *e = getenv(env_name)) k = (size_t) std::max(1L, strtol(e, nullptr, 10));
+    else if (n_frames < kSliceFromFrames) k = 1;
     k = std::min<size_t>(k, 8);
     if (k < 2 || n_frames < 4 * k) return 1;
     const size_t per = (ctx->max_frames + k - 1) / k;

@@ -91,7 +91,7 @@ int ebcc_hip_j2k_parse_check(const uint8_t *cs, size_t n, size_t height, size_t 
  * config->dims must be {1, height, width} of the context (one frame per stream, as HDF5 chunks of
  * one frame / ebcc_encode_chunking with chunk_dims {1,H,W} produce).  Streams are malloc'd (free_buffer).
  * Return 0 = ok, 1 = error, 2 = NaN/Inf in the input; on failure entries of out_streams that are not NULL
- * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default: ebcc_hip_default_encode_slices() = 3),
+ * still have to be freed.  A batch is coded as EBCC_HIP_SLICES concurrent slices (default: ebcc_hip_default_encode_slices() = 3 from 96 frames on, one slice below),
  * each on its own engine, stream and host thread; results do not depend on the slicing.  The slice engines are created on first use; ebcc_hip_prepare creates them ahead of time for batches of
  * n_frames (part of setting a context up, like ebcc_hip_create).  Returns 0. */
 int ebcc_hip_prepare(ebcc_hip_ctx *ctx, size_t n_frames);
@@ -160,7 +160,7 @@ int ebcc_h5_read_frames(long long dset_id, size_t first_frame, size_t n_frames, 
  * LOCAL_WORLD_SIZE when the process is one rank of a multi-process job, minus min(slices, 2) for the threads that steer the
  * GPU (none subtracted from a share of 4 or fewer); at most 64. */
 int ebcc_hip_host_threads(int slices);
-/* Slices an encode batch runs as when EBCC_HIP_SLICES is not set. */
+/* Slices an encode batch of 96 frames or more runs as when EBCC_HIP_SLICES is not set (smaller batches: one). */
 int ebcc_hip_default_encode_slices(void);
 /* Host-side accounting since the last reset: out[0] usable CPUs (affinity and quota), out[1] CPU quota of the container in
  * CPUs (0: none), out[2] core-seconds spent in zstd, out[3] seconds the slices waited for the zstd workers, out[4] bytes

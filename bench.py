@@ -260,7 +260,9 @@ def main():
     # host side of this rank over the timed region (per step): what the entropy stage cost, what the process burnt in all
     # its threads, and whether the container's CPU quota throttled it
     lib.ebcc_hip_default_encode_slices.restype = ctypes.c_int
-    default_slices = int(os.environ.get("EBCC_HIP_SLICES", lib.ebcc_hip_default_encode_slices()))
+    lib.ebcc_hip_encode_slices_for.restype = ctypes.c_int
+    lib.ebcc_hip_encode_slices_for.argtypes = [ctypes.c_size_t]
+    default_slices = int(lib.ebcc_hip_encode_slices_for(n))     # (what a batch of n frames runs as: the environment and the batch size decide)
     host = {"pool_threads": lib.ebcc_hip_host_threads(default_slices),
             "usable_cpus": int(hstats[0]), "quota_cpus": hstats[1] or None,
             "zstd_core_s_per_step": round(hstats[2] / args.steps, 4), "zstd_wait_ms_per_step": round(hstats[3] / args.steps * 1e3, 2),

@@ -559,6 +559,14 @@ void print_config(codec_config_t *c)
 
 int ebcc_hip_host_threads(int slices) { return (int) entropy_threads((unsigned) std::max(1, slices)); }
 int ebcc_hip_default_encode_slices(void) { return (int) default_encode_slices(); }
+int ebcc_hip_encode_slices_for(size_t n_frames)
+{
+    size_t k = default_encode_slices();
+    if (const char *e = getenv("EBCC_HIP_SLICES")) k = (size_t) std::max(1L, strtol(e, nullptr, 10));
+    else if (n_frames < kSliceFromFrames) k = 1;
+    k = std::min<size_t>(k, 8);
+    return k < 2 || n_frames < 4 * k ? 1 : (int) k;
+}
 
 // out[0..6] = usable CPUs (affinity mask cut to the cgroup quota), CPU quota (0: none), zstd core-seconds, seconds the
 // slices waited for the zstd workers, bytes compressed, entropy batches, prefix bytes whose compression was proved

@@ -162,6 +162,8 @@ int ebcc_h5_read_frames(long long dset_id, size_t first_frame, size_t n_frames, 
 int ebcc_hip_host_threads(int slices);
 /* Slices an encode batch of 96 frames or more runs as when EBCC_HIP_SLICES is not set (smaller batches: one). */
 int ebcc_hip_default_encode_slices(void);
+/* Slices an encode batch of n_frames runs as (EBCC_HIP_SLICES and the batch size taken into account). */
+int ebcc_hip_encode_slices_for(size_t n_frames);
 /* Host-side accounting since the last reset: out[0] usable CPUs (affinity and quota), out[1] CPU quota of the container in
  * CPUs (0: none), out[2] core-seconds spent in zstd, out[3] seconds the slices waited for the zstd workers, out[4] bytes
  * compressed, out[5] entropy batches, out[6] prefix bytes whose compression was proved unnecessary (ebcc_hip_zstd_floor).  bench.py prints them per rank (a run bound by the host's CPUs shows here). */

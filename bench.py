@@ -353,14 +353,17 @@ def main():
         m3 = 4096 if n >= 256 else 4 * n
         data = synth_frames(torch, m3, device, seed=77, ramp=(0.25, 1.75))
         cfg3 = L.make_config((1, H, W), base_cr=BASE_CR, error=1e-3, residual_type=L.RELATIVE_ERROR)
-        run_batches(data[:n + min(n, 16)], cfg3)                                  # (warm-up: two batches, so that the second engine set exists before the timed run)
+        # (warm-up: one whole pass - the second engine set exists afterwards, and so do the host pages of 2 GB of streams;
+        #  the first pass of a process measures the kernel's page zeroing: encode 8.0 - 11.9 GB/s on four leases where every
+        #  later pass gives 13.4 - 13.7, tools/gpu/config3_reps.py)
+        run_batches(data, cfg3)
         te, td, nb, resid, worst = run_batches(data, cfg3, keep_streams=(1, m3 // 2, m3 - 2))
         rng_ = (data.amax(dim=(1, 2)) - data.amin(dim=(1, 2)))
         rel_ = run_batches.per_frame / rng_
         assert float(rel_.amax()) <= 1e-3 * 1.01 + 1e-6, float(rel_.amax())
         for i, digest in run_batches.kept.items():
             parity_checks.append((f"config3[{i}]", data[i].cpu().numpy(), digest, "rel"))
-        ex["config3"] = {"workload": f"{m3} frames 721x1440, base_cr=30 RELATIVE_ERROR=1e-3, amplitude ramp 0.25..1.75, batches of {n}",
+        ex["config3"] = {"workload": f"{m3} frames 721x1440, base_cr=30 RELATIVE_ERROR=1e-3, amplitude ramp 0.25..1.75, batches of {n}, second pass over the data",
                          "value": round(m3 * FRAME_BYTES / (te + td) / 1e9, 4), "unit": "GB/s",
                          "encode_GBps": round(m3 * FRAME_BYTES / te / 1e9, 4), "decode_GBps": round(m3 * FRAME_BYTES / td / 1e9, 4),
                          "compressed_bytes_per_frame": int(nb / m3), "frames_with_residual_layer": round(resid / m3, 4),

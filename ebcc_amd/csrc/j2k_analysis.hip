@@ -1294,10 +1294,7 @@ __global__ __launch_bounds__(64) void k_t1_emit(const unsigned long long *BP, co
 // One workgroup barrier per chunk of kRowChunk rows keeps the three stages (load chunk q + 1 | interval chunk q | code
 // chunk q - 1) in step.  Wave 0 never waits for vector memory: its global accesses are stores only (on gfx9 a load's data
 // would wait for every older store of the wave: one counter, in issue order).
-#ifndef EBCC_MQ_ROW_CHUNK
-#define EBCC_MQ_ROW_CHUNK 2
-#endif
-constexpr int kRowChunk = EBCC_MQ_ROW_CHUNK;      // (tools/gpu/mq_chunk_ab.sh builds the alternatives)
+constexpr int kRowChunk = 2;
 struct RowSrcDev {
     uint32_t buf;                  // LDS byte address of this lane's 16 bytes of row 0 of buffer 0 (row stride 1 KB, buffers kRowChunk KB apart)
     uint32_t n, wn;                // rows of this lane, of the longest lane of the wave

@@ -263,3 +263,17 @@ def test_decoder_launch_shape_follows_the_batch():
     lib.ebcc_hip_plan_decode_lanes(np.zeros((64, 4), np.int32).ctypes.data, 64, empty)   # nothing coded: any shape will do
     assert empty[3] in (1, 2, 4)
     lib.ebcc_hip_plan_decode_lanes(None, 0, empty)
+
+
+def test_slices_follow_the_batch_size(monkeypatch):
+    """ebcc_hip_encode_slices_for: a batch below 96 frames runs as one slice, a larger one as three; EBCC_HIP_SLICES decides
+    for every batch that is large enough to be cut (four frames per slice at least)."""
+    lib = L.product()
+    lib.ebcc_hip_encode_slices_for.restype = ctypes.c_int
+    lib.ebcc_hip_encode_slices_for.argtypes = [ctypes.c_size_t]
+    monkeypatch.delenv("EBCC_HIP_SLICES", raising=False)
+    assert [lib.ebcc_hip_encode_slices_for(n) for n in (1, 43, 95, 96, 256)] == [1, 1, 1, 3, 3]
+    monkeypatch.setenv("EBCC_HIP_SLICES", "2")
+    assert [lib.ebcc_hip_encode_slices_for(n) for n in (1, 7, 8, 43, 256)] == [1, 1, 2, 2, 2]
+    monkeypatch.setenv("EBCC_HIP_SLICES", "1")
+    assert lib.ebcc_hip_encode_slices_for(256) == 1
